@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py — Mpix/s of the lens-reprojection hot path on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`;
+for N > 1 it is launched by torch.distributed.run, one rank per GPU.  Prints ONE
+JSON line on rank 0.
+
+A step = one pass of the hot path over one batch of `--batch` synthetic 4096x4096
+RGBA float frames that are already resident in HBM (generated on the device by
+the counter-based generator; seeds 0x5EED0000 + i).  The batch is sharded
+one-shard-per-GPU with no collective on the data path (images are independent,
+reference src/main.cpp:540-622), i.e. weak scaling: every rank renders `--batch`
+frames per step.  Inside a GPU the frames round-robin over `--streams` HIP
+streams.
+"""
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # BASELINE.json configs[1] (the config the metric is quoted on).  The reference
+    # rejects FISHEYE_EQUISOLID (src/reproject.cpp:395-397), so the fisheye is the
+    # equidistant one with fov = pi, as SURVEY.md §8d prescribes for parity.
+    "fisheye_to_rect_bicubic": dict(in_lens="eqd", out_lens="rect", interp=2, rot=None, channels=4, size=4096),
+    # north_star's roofline target case.
+    "equirect_to_rect_bicubic": dict(in_lens="eqr", out_lens="rect", interp=2, rot=(0.0, 0.0, 0.0), channels=4,
+                                     size=4096),
+    # BASELINE.json configs[2] shape.
+    "equirect_to_fisheye_bilinear": dict(in_lens="eqr", out_lens="eqd", interp=1, rot=(30.0, -15.0, 5.0), channels=4,
+                                         size=4096),
+}
+
+
+def make_lens(pkg, kind, w, h):
+    if kind == "rect":
+        return pkg.LensInfo.rectilinear(18.0, 36.0, w, h)
+    if kind == "eqd":
+        return pkg.LensInfo.equidistant(3.14159265)
+    return pkg.LensInfo.equirectangular()
+
+
+def make_rot(pkg, deg):
+    if deg is None:
+        return None
+    r = [d * math.pi / 180.0 for d in deg]
+    return pkg.rotation_matrix(*r)
+
+
+def cpu_baseline(pkg, wl, seconds_target):
+    """The oracle (kind "port": our C restatement of the reference loop, reference
+    flags) timed on this host, scheduled like the reference: one image (here: one
+    row band of a frame, rows are independent) per thread, all host cores."""
+    import numpy as np
+    import oracle_binding as oracle
+
+    cores = os.cpu_count() or 1
+    size = wl["size"]
+    c = wl["channels"]
+    src = oracle.synth_frame(size, size, c, 0x5EED0000)
+    lin, lout = make_lens(pkg, wl["in_lens"], size, size), make_lens(pkg, wl["out_lens"], size, size)
+    rot = make_rot(pkg, wl["rot"])
+    # calibrate on a thin band, then size the sample for ~seconds_target of wall time
+    rows_probe = 8 * cores
+    out = np.empty((size, size, c), dtype=np.float32)
+    t0 = time.perf_counter()
+    oracle.reproject(lin, src, lout, size, rows_probe, 1, wl["interp"], rot, threads=cores, out=out[:rows_probe])
+    dt = time.perf_counter() - t0
+    rate = rows_probe * size / dt
+    rows = int(min(size, max(rows_probe, rate * seconds_target / size)))
+    # same lens geometry as the full frame: render the first `rows` rows of the full-size output
+    import ctypes
+
+    L = oracle.lib()
+    cin = oracle._image(lin, size, size, c, src)
+    cout = oracle._image(lout, size, size, c, out)
+    keep, rp = oracle._rot(rot)
+    from concurrent.futures import ThreadPoolExecutor
+
+    # centre band of the frame (rows around the optical axis), split over the cores
+    y0 = (size - rows) // 2
+    bands = [(y0 + rows * i // cores, y0 + rows * (i + 1) // cores) for i in range(cores)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda b: L.lrpo_reproject_rows(ctypes.byref(cin), ctypes.byref(cout), 1, wl["interp"], rp, b[0],
+                                                    b[1]), bands))
+    dt = time.perf_counter() - t0
+    return {
+        "value": rows * size / dt / 1e6,
+        "unit": "Mpix/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{rows} centre rows of one {size}x{size}x{c} frame, {cores} threads, {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct resident source frames per GPU")
+    ap.add_argument("--streams", type=int, default=4)
+    ap.add_argument("--workload", default="fisheye_to_rect_bicubic", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+
+    pkg = importlib.import_module("image-lens-reproject_amd")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    wl = WORKLOADS[args.workload]
+    size, c = wl["size"], wl["channels"]
+    lin, lout = make_lens(pkg, wl["in_lens"], size, size), make_lens(pkg, wl["out_lens"], size, size)
+    rot = make_rot(pkg, wl["rot"])
+
+    # resident frames: `distinct` sources and as many destinations, cycled, so the
+    # working set (distinct x 512 MiB) is far beyond the 256 MiB Infinity Cache.
+    n_res = max(1, min(args.distinct, args.batch))
+    srcs, dsts = [], []
+    for i in range(n_res):
+        s = torch.empty((size, size, c), dtype=torch.float32, device=dev)
+        pkg.synth_fill(s, size, size, c, 0x5EED0000 + rank * args.batch + i)
+        srcs.append(s)
+        dsts.append(torch.empty((size, size, c), dtype=torch.float32, device=dev))
+    im_in = [pkg.Image(lin, size, size, c, s) for s in srcs]
+    im_out = [pkg.Image(lout, size, size, c, d) for d in dsts]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+    torch.cuda.synchronize()
+
+    def step():
+        for i in range(args.batch):
+            st = streams[i % len(streams)]
+            pkg.reproject(im_in[i % n_res], im_out[i % n_res], 1, wl["interp"], rot, stream=st)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel timed live with HIP events on the stream it is launched on
+    # (torch events recorded on that same stream), one frame per launch.
+    kst = streams[0]
+    reps = 40
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for i in range(reps):
+        ev[i][0].record(kst)
+        pkg.reproject(im_in[i % n_res], im_out[i % n_res], 1, wl["interp"], rot, stream=kst)
+        ev[i][1].record(kst)
+    torch.cuda.synchronize()
+    k_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    k_avg_ms = sum(k_ms) / len(k_ms)
+
+    if rank == 0:
+        pix_per_step = world * args.batch * size * size
+        value = pix_per_step * args.steps / elapsed / 1e6
+        algo_bytes = 2 * size * size * c * 4  # (inW*inH + outW*outH)*C*4 per launch
+        achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mpix/s reprojected (4K RGBA float, bicubic)",
+            "value": value,
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {size}x{size}x{c} f32 -> {size}x{size}x{c}, "
+                            f"{wl['in_lens']}->{wl['out_lens']}, interp={wl['interp']}, num_samples=1",
+                "frames_per_gpu_per_step": args.batch,
+                "resident_distinct_frames": n_res,
+                "streams": len(streams),
+                "parallelism": f"image-sharded x{world}, no collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel_ms_avg": k_avg_ms,
+                "kernel_ms_min": k_ms[0],
+                "algorithmic_bytes_per_launch": algo_bytes,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, wl, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,130 @@
+"""ctypes binding of liblrp_hip.so (the C ABI of include/lrp.h).
+
+There is no Python/numpy/torch implementation of the hot path in this package:
+if the shared library is missing, importing the binding raises.  PyTorch is used
+by callers only as plumbing (device memory, streams, torch.distributed).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblrp_hip.so")
+
+
+class LrpLens(ctypes.Structure):
+    """lrp_lens == reference LensInfo (src/config.hpp:15-37), 28 bytes."""
+
+    _fields_ = [
+        ("type", ctypes.c_int32),
+        ("raw", ctypes.c_float * 4),
+        ("sensor_width", ctypes.c_float),
+        ("sensor_height", ctypes.c_float),
+    ]
+
+
+class LrpImage(ctypes.Structure):
+    """lrp_image == reference Image (src/reproject.hpp:9-14), 56 bytes."""
+
+    _fields_ = [
+        ("lens", LrpLens),
+        ("width", ctypes.c_int32),
+        ("height", ctypes.c_int32),
+        ("channels", ctypes.c_int32),
+        ("data", ctypes.c_void_p),
+        ("data_layout", ctypes.c_int32),
+    ]
+
+
+class LrpPost(ctypes.Structure):
+    _fields_ = [("exposure", ctypes.c_float), ("reinhard", ctypes.c_float)]
+
+
+assert ctypes.sizeof(LrpLens) == 28
+assert ctypes.sizeof(LrpImage) == 56
+
+# Every symbol include/lrp.h declares: (restype, argtypes)
+_P = ctypes.POINTER
+_FLOATP = ctypes.c_void_p  # float* passed as raw address (host or device)
+SYMBOLS = {
+    "lrp_abi_version": (ctypes.c_int, []),
+    "lrp_device_count": (ctypes.c_int, []),
+    "lrp_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "lrp_last_error": (ctypes.c_char_p, []),
+    "lrp_reproject": (
+        ctypes.c_int,
+        [_P(LrpImage), _P(LrpImage), ctypes.c_int, ctypes.c_int, _FLOATP, _P(LrpPost), ctypes.c_int],
+    ),
+    "lrp_post_process": (ctypes.c_int, [_P(LrpImage), ctypes.c_float, ctypes.c_float, ctypes.c_int]),
+    "lrp_reproject_device": (
+        ctypes.c_int,
+        [_P(LrpImage), _P(LrpImage), ctypes.c_int, ctypes.c_int, _FLOATP, _P(LrpPost), ctypes.c_int, ctypes.c_void_p],
+    ),
+    "lrp_post_process_device": (
+        ctypes.c_int,
+        [_P(LrpImage), ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p],
+    ),
+    "lrp_reproject_multi_device": (
+        ctypes.c_int,
+        [
+            _P(LrpImage),
+            _P(LrpImage),
+            ctypes.c_int,
+            ctypes.c_int,
+            ctypes.c_int,
+            _FLOATP,
+            _P(LrpPost),
+            ctypes.c_int,
+            ctypes.c_void_p,
+        ],
+    ),
+    "lrp_context_create": (ctypes.c_int, [_P(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]),
+    "lrp_context_destroy": (None, [ctypes.c_void_p]),
+    "lrp_context_submit": (
+        ctypes.c_int,
+        [ctypes.c_void_p, _P(LrpImage), _P(LrpImage), ctypes.c_int, ctypes.c_int, _FLOATP, _P(LrpPost)],
+    ),
+    "lrp_context_wait": (ctypes.c_int, [ctypes.c_void_p]),
+    "lrp_synth_fill_device": (
+        ctypes.c_int,
+        [_FLOATP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
+    ),
+    "lrp_math_eval_device": (
+        ctypes.c_int,
+        [ctypes.c_int, _FLOATP, _FLOATP, _FLOATP, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p],
+    ),
+    "lrp_rotation_matrix": (None, [ctypes.c_float, ctypes.c_float, ctypes.c_float, _P(ctypes.c_float)]),
+    "lrp_lens_rectilinear": (
+        None,
+        [_P(LrpLens), ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float],
+    ),
+    "lrp_lens_equidistant": (None, [_P(LrpLens), ctypes.c_float]),
+    "lrp_lens_equirectangular": (
+        None,
+        [_P(LrpLens), ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float],
+    ),
+    "lrp_lens_equirectangular_full": (None, [_P(LrpLens)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load liblrp_hip.so and declare every entry point.  Raises if the library
+    or any symbol is missing — there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with image-lens-reproject_amd/csrc/build.sh "
+            "(or __graft_entry__.build()); the HIP library is the only implementation"
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.lrp_abi_version() != 1:
+        raise ImportError("liblrp_hip.so ABI version mismatch")
+    _lib = lib
+    return lib

@@ -1,0 +1,26 @@
+#!/usr/bin/env bash
+# Builds liblrp_hip.so (gfx950) in-tree.  Usage: build.sh [jobs]
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="$here/../lib"
+obj="$here/../lib/obj"
+mkdir -p "$out" "$obj"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+# Parity flags: no FMA contraction, IEEE divide/sqrt, denormals kept, no fast-math.
+FLAGS=(--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off
+       -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -fno-gpu-flush-denormals-to-zero
+       -Wall -Wno-unused-function -I"$here" -I"$here/../../include")
+srcs=(lrp_kernels_nn.hip lrp_kernels_bl.hip lrp_kernels_bc.hip lrp_aux_kernels.hip lrp_capi.cpp lrp_host_util.cpp)
+pids=()
+for s in "${srcs[@]}"; do
+  o="$obj/${s%.*}.o"
+  if [[ ! -f "$o" || "$here/$s" -nt "$o" || -n "$(find "$here" -maxdepth 1 -name '*.h' -newer "$o" -print -quit)" \
+        || "$here/../../include/lrp.h" -nt "$o" ]]; then
+    ( "$HIPCC" "${FLAGS[@]}" -x hip -c "$here/$s" -o "$o" ) &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/liblrp_hip.so" "$obj"/lrp_kernels_nn.o "$obj"/lrp_kernels_bl.o \
+  "$obj"/lrp_kernels_bc.o "$obj"/lrp_aux_kernels.o "$obj"/lrp_capi.o "$obj"/lrp_host_util.o
+echo "built $out/liblrp_hip.so"

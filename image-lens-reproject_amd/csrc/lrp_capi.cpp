@@ -1,0 +1,432 @@
+// lrp_capi.cpp — the C ABI declared in include/lrp.h: argument validation in the
+// reference's dispatch order, kernel-argument construction, device buffers,
+// streams and the batch context.  Host code only; the kernels live in the
+// lrp_kernels_*.hip / lrp_aux_kernels.hip translation units.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/lrp.h"
+#include "lrp_params.h"
+
+namespace lrp {
+hipError_t launch_nearest(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
+hipError_t launch_bilinear(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
+hipError_t launch_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
+hipError_t launch_post_process(float *data, uint32_t n_pixels, int channels, float exposure, float reinhard,
+                               hipStream_t stream);
+hipError_t launch_synth_fill(float *data, uint32_t n_elems, int channels, uint32_t seed, int depth_channel,
+                             hipStream_t stream);
+hipError_t launch_math_eval(int func, const float *a, const float *b, float *out, size_t n, hipStream_t stream);
+} // namespace lrp
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const std::string &detail) {
+  g_last_error = detail;
+  return status;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+  int st = (e == hipErrorOutOfMemory) ? LRP_ERR_OOM : LRP_ERR_HIP;
+  if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) st = LRP_ERR_NO_DEVICE;
+  return fail(st, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define LRP_HIP_TRY(expr)                                                                                    \
+  do {                                                                                                       \
+    hipError_t _e = (expr);                                                                                  \
+    if (_e != hipSuccess) return hip_fail(_e, #expr);                                                        \
+  } while (0)
+
+int device_count_cached() {
+  static int count = [] {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    return n < 0 ? 0 : n;
+  }();
+  return count;
+}
+
+int select_device(int device) {
+  const int n = device_count_cached();
+  if (n == 0) return fail(LRP_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU path");
+  if (device < 0 || device >= n) return fail(LRP_ERR_NO_DEVICE, "device index out of range");
+  LRP_HIP_TRY(hipSetDevice(device));
+  return LRP_OK;
+}
+
+bool lens_in_hot_path(int type) {
+  return type == LRP_RECTILINEAR || type == LRP_FISHEYE_EQUIDISTANT || type == LRP_EQUIRECTANGULAR;
+}
+
+int out_lens_index(int type) { return type == LRP_RECTILINEAR ? 0 : (type == LRP_FISHEYE_EQUIDISTANT ? 1 : 2); }
+
+// LoopHorizontally decision, reference src/reproject.cpp:386-394: float span,
+// compared in double against 2*M_PI with a float threshold.
+bool source_wraps(const lrp_lens &L) {
+  const float long_range = L.u.equirectangular.longitude_max - L.u.equirectangular.longitude_min;
+  return std::fabs((double)long_range - (2 * M_PI)) < 1e-5f;
+}
+
+int in_lens_mode(const lrp_lens &L) {
+  if (L.type == LRP_RECTILINEAR) return lrp::kInRect;
+  if (L.type == LRP_FISHEYE_EQUIDISTANT) return lrp::kInEquidistant;
+  return source_wraps(L) ? lrp::kInEquirectLoop : lrp::kInEquirect;
+}
+
+lrp::LensP pack_lens(const lrp_lens &L) {
+  lrp::LensP p;
+  std::memcpy(p.p, L.u.raw, sizeof(p.p));
+  p.sensor_width = L.sensor_width;
+  p.sensor_height = L.sensor_height;
+  return p;
+}
+
+size_t image_bytes(const lrp_image &im) { return (size_t)im.width * (size_t)im.height * (size_t)im.channels * 4u; }
+
+// Checks in the order the reference dispatches: output lens
+// (src/reproject.cpp:408-418), input lens (:378-398), interpolation (:352-367);
+// then the preconditions the reference leaves unchecked.
+int validate(const lrp_image *in, const lrp_image *out, int interpolation, bool need_data) {
+  if (!in || !out) return fail(LRP_ERR_NULL, "null image");
+  if (!lens_in_hot_path(out->lens.type)) return fail(LRP_ERR_OUTPUT_LENS, "Output lens type not supported.");
+  if (!lens_in_hot_path(in->lens.type)) return fail(LRP_ERR_INPUT_LENS, "Input lens type not supported.");
+  if (interpolation != LRP_NEAREST && interpolation != LRP_BILINEAR && interpolation != LRP_BICUBIC)
+    return fail(LRP_ERR_INTERPOLATION, "Interpolation method not supported.");
+  if (in->channels < 1 || in->channels != out->channels)
+    return fail(LRP_ERR_CHANNELS, "in->channels must equal out->channels and be >= 1");
+  if (in->channels > 8 && in->channels != 4) return fail(LRP_ERR_CHANNELS, "more than 8 channels not supported");
+  if (in->width < 1 || in->height < 1 || out->width < 1 || out->height < 1)
+    return fail(LRP_ERR_BAD_DIMS, "image dimensions must be positive");
+  const unsigned long long lim = 1ull << 32;
+  if ((unsigned long long)image_bytes(*in) >= lim || (unsigned long long)image_bytes(*out) >= lim)
+    return fail(LRP_ERR_BAD_DIMS, "images of 4 GiB or more are not supported");
+  if (need_data && (!in->data || !out->data)) return fail(LRP_ERR_NULL, "null image data");
+  return LRP_OK;
+}
+
+lrp::KParams make_params(const lrp_image *in, const lrp_image *out, int num_samples, const float *rotation,
+                         const lrp_post *post) {
+  lrp::KParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.src = in->data;
+  P.dst = out->data;
+  P.in_w = in->width;
+  P.in_h = in->height;
+  P.out_w = out->width;
+  P.out_h = out->height;
+  P.channels = out->channels;
+  P.num_samples = num_samples;
+  P.normalize = 1.0f / (float)(num_samples * num_samples); // src/reproject.cpp:280
+  P.in_lens = pack_lens(in->lens);
+  P.out_lens = pack_lens(out->lens);
+  P.has_rot = rotation != nullptr;
+  if (rotation) std::memcpy(P.rot, rotation, sizeof(P.rot));
+  P.has_post = post != nullptr;
+  if (post) {
+    P.exposure = post->exposure;
+    P.reinhard = post->reinhard;
+  }
+  P.y_offset = 0;
+  return P;
+}
+
+int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int interpolation,
+                      const float *rotation, const lrp_post *post, hipStream_t stream) {
+  if (num_samples <= 0) return LRP_OK; // reference loop body never runs: output untouched
+  const lrp::KParams P = make_params(in, out, num_samples, rotation, post);
+  const int oi = out_lens_index(out->lens.type);
+  const int im = in_lens_mode(in->lens);
+  hipError_t e;
+  if (interpolation == LRP_NEAREST)
+    e = lrp::launch_nearest(P, oi, im, stream);
+  else if (interpolation == LRP_BILINEAR)
+    e = lrp::launch_bilinear(P, oi, im, stream);
+  else
+    e = lrp::launch_bicubic(P, oi, im, stream);
+  if (e != hipSuccess) return hip_fail(e, "reproject kernel launch");
+  return LRP_OK;
+}
+
+// Grow-only device / pinned buffer.
+struct Buffer {
+  void *ptr = nullptr;
+  size_t cap = 0;
+  bool pinned_host = false;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return LRP_OK;
+    release();
+    hipError_t e = pinned_host ? hipHostMalloc(&ptr, bytes, hipHostMallocDefault) : hipMalloc(&ptr, bytes);
+    if (e != hipSuccess) {
+      ptr = nullptr;
+      cap = 0;
+      return hip_fail(e, pinned_host ? "hipHostMalloc" : "hipMalloc");
+    }
+    cap = bytes;
+    return LRP_OK;
+  }
+  void release() {
+    if (ptr) {
+      if (pinned_host)
+        (void)hipHostFree(ptr);
+      else
+        (void)hipFree(ptr);
+    }
+    ptr = nullptr;
+    cap = 0;
+  }
+};
+
+struct Slot {
+  hipStream_t stream = nullptr;
+  Buffer d_in, d_out;
+};
+
+} // namespace
+
+struct lrp_context {
+  int device = 0;
+  std::vector<Slot> slots;
+  size_t next = 0;
+  int first_error = LRP_OK;
+  std::string first_error_text;
+};
+
+extern "C" {
+
+int lrp_abi_version(void) { return LRP_ABI_VERSION; }
+
+int lrp_device_count(void) { return device_count_cached(); }
+
+const char *lrp_strerror(int status) {
+  switch (status) {
+  case LRP_OK: return "ok";
+  case LRP_ERR_OUTPUT_LENS: return "Output lens type not supported.";
+  case LRP_ERR_INPUT_LENS: return "Input lens type not supported.";
+  case LRP_ERR_INTERPOLATION: return "Interpolation method not supported.";
+  case LRP_ERR_CHANNELS: return "channel count mismatch or unsupported";
+  case LRP_ERR_BAD_DIMS: return "bad image dimensions";
+  case LRP_ERR_NULL: return "null pointer";
+  case LRP_ERR_NO_DEVICE: return "no usable HIP device";
+  case LRP_ERR_HIP: return "HIP runtime error";
+  case LRP_ERR_OOM: return "out of memory";
+  case LRP_ERR_BAD_ARG: return "bad argument";
+  default: return "unknown status";
+  }
+}
+
+const char *lrp_last_error(void) { return g_last_error.c_str(); }
+
+int lrp_reproject_device(const lrp_image *in, lrp_image *out, int num_samples, int interpolation,
+                         const float *rotation, const lrp_post *post, int device, void *stream) {
+  int st = validate(in, out, interpolation, true);
+  if (st != LRP_OK) return st;
+  st = select_device(device);
+  if (st != LRP_OK) return st;
+  return enqueue_reproject(in, out, num_samples, interpolation, rotation, post, (hipStream_t)stream);
+}
+
+int lrp_reproject_multi_device(const lrp_image *in, lrp_image *outs, int n_out, int num_samples,
+                               int interpolation, const float *rotations, const lrp_post *post, int device,
+                               void *stream) {
+  if (n_out < 0 || (n_out > 0 && !outs)) return fail(LRP_ERR_BAD_ARG, "bad output array");
+  for (int i = 0; i < n_out; ++i) {
+    int st = validate(in, &outs[i], interpolation, true);
+    if (st != LRP_OK) return st;
+  }
+  int st = select_device(device);
+  if (st != LRP_OK) return st;
+  for (int i = 0; i < n_out; ++i) {
+    st = enqueue_reproject(in, &outs[i], num_samples, interpolation, rotations ? rotations + 9 * i : nullptr, post,
+                           (hipStream_t)stream);
+    if (st != LRP_OK) return st;
+  }
+  return LRP_OK;
+}
+
+int lrp_post_process_device(lrp_image *img, float exposure, float reinhard, int device, void *stream) {
+  if (!img || !img->data) return fail(LRP_ERR_NULL, "null image");
+  if (img->width < 1 || img->height < 1 || img->channels < 1) return fail(LRP_ERR_BAD_DIMS, "bad image dimensions");
+  if ((unsigned long long)image_bytes(*img) >= (1ull << 32)) return fail(LRP_ERR_BAD_DIMS, "image too large");
+  int st = select_device(device);
+  if (st != LRP_OK) return st;
+  hipError_t e = lrp::launch_post_process(img->data, (uint32_t)img->width * (uint32_t)img->height, img->channels,
+                                          exposure, reinhard, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "post_process kernel launch");
+  return LRP_OK;
+}
+
+int lrp_context_create(lrp_context **ctx, int device, int n_streams) {
+  if (!ctx || n_streams < 1 || n_streams > 64) return fail(LRP_ERR_BAD_ARG, "bad context arguments");
+  int st = select_device(device);
+  if (st != LRP_OK) return st;
+  lrp_context *c = new (std::nothrow) lrp_context;
+  if (!c) return fail(LRP_ERR_OOM, "host allocation failed");
+  c->device = device;
+  c->slots.resize((size_t)n_streams);
+  for (auto &s : c->slots) {
+    hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      lrp_context_destroy(c);
+      return hip_fail(e, "hipStreamCreateWithFlags");
+    }
+  }
+  *ctx = c;
+  return LRP_OK;
+}
+
+void lrp_context_destroy(lrp_context *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  for (auto &s : ctx->slots) {
+    if (s.stream) {
+      (void)hipStreamSynchronize(s.stream);
+      (void)hipStreamDestroy(s.stream);
+    }
+    s.d_in.release();
+    s.d_out.release();
+  }
+  delete ctx;
+}
+
+int lrp_context_submit(lrp_context *ctx, const lrp_image *in, lrp_image *out, int num_samples, int interpolation,
+                       const float *rotation, const lrp_post *post) {
+  if (!ctx) return fail(LRP_ERR_NULL, "null context");
+  int st = validate(in, out, interpolation, true);
+  if (st != LRP_OK) return st;
+  st = select_device(ctx->device);
+  if (st != LRP_OK) return st;
+  if (num_samples <= 0) return LRP_OK;
+  Slot &s = ctx->slots[ctx->next];
+  ctx->next = (ctx->next + 1) % ctx->slots.size();
+  // The slot's buffers are reused: its previous image must have drained.
+  LRP_HIP_TRY(hipStreamSynchronize(s.stream));
+  const size_t in_bytes = image_bytes(*in), out_bytes = image_bytes(*out);
+  st = s.d_in.reserve(in_bytes);
+  if (st != LRP_OK) return st;
+  st = s.d_out.reserve(out_bytes);
+  if (st != LRP_OK) return st;
+  LRP_HIP_TRY(hipMemcpyAsync(s.d_in.ptr, in->data, in_bytes, hipMemcpyHostToDevice, s.stream));
+  lrp_image din = *in, dout = *out;
+  din.data = (float *)s.d_in.ptr;
+  dout.data = (float *)s.d_out.ptr;
+  st = enqueue_reproject(&din, &dout, num_samples, interpolation, rotation, post, s.stream);
+  if (st != LRP_OK) return st;
+  LRP_HIP_TRY(hipMemcpyAsync(out->data, s.d_out.ptr, out_bytes, hipMemcpyDeviceToHost, s.stream));
+  return LRP_OK;
+}
+
+int lrp_context_wait(lrp_context *ctx) {
+  if (!ctx) return fail(LRP_ERR_NULL, "null context");
+  int st = select_device(ctx->device);
+  if (st != LRP_OK) return st;
+  int result = LRP_OK;
+  for (auto &s : ctx->slots) {
+    hipError_t e = hipStreamSynchronize(s.stream);
+    if (e != hipSuccess && result == LRP_OK) result = hip_fail(e, "hipStreamSynchronize");
+  }
+  return result;
+}
+
+namespace {
+// The synchronous host-buffer entry points borrow a single-stream context from
+// a per-device pool (one per concurrent caller, reused afterwards), so repeated
+// calls keep their device buffers and concurrent pool threads never share one.
+// Pooled contexts live until process exit.
+std::mutex g_pool_mutex;
+std::vector<std::vector<lrp_context *>> g_pool; // [device] -> idle contexts
+
+int borrow_context(int device, lrp_context **out) {
+  int st = select_device(device);
+  if (st != LRP_OK) return st;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    if (g_pool.size() <= (size_t)device) g_pool.resize((size_t)device + 1);
+    auto &idle = g_pool[(size_t)device];
+    if (!idle.empty()) {
+      *out = idle.back();
+      idle.pop_back();
+      return LRP_OK;
+    }
+  }
+  return lrp_context_create(out, device, 1);
+}
+
+void return_context(lrp_context *c) {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  g_pool[(size_t)c->device].push_back(c);
+}
+} // namespace
+
+int lrp_reproject(const lrp_image *in, lrp_image *out, int num_samples, int interpolation, const float *rotation,
+                  const lrp_post *post, int device) {
+  int st = validate(in, out, interpolation, true);
+  if (st != LRP_OK) return st;
+  lrp_context *c = nullptr;
+  st = borrow_context(device, &c);
+  if (st != LRP_OK) return st;
+  st = lrp_context_submit(c, in, out, num_samples, interpolation, rotation, post);
+  const int st_wait = lrp_context_wait(c);
+  return_context(c);
+  return st != LRP_OK ? st : st_wait;
+}
+
+int lrp_post_process(lrp_image *img, float exposure, float reinhard, int device) {
+  if (!img || !img->data) return fail(LRP_ERR_NULL, "null image");
+  if (img->width < 1 || img->height < 1 || img->channels < 1) return fail(LRP_ERR_BAD_DIMS, "bad image dimensions");
+  if ((unsigned long long)image_bytes(*img) >= (1ull << 32)) return fail(LRP_ERR_BAD_DIMS, "image too large");
+  lrp_context *c = nullptr;
+  int st = borrow_context(device, &c);
+  if (st != LRP_OK) return st;
+  st = [&]() -> int {
+    Slot &s = c->slots[0];
+    const size_t bytes = image_bytes(*img);
+    int r = s.d_out.reserve(bytes);
+    if (r != LRP_OK) return r;
+    LRP_HIP_TRY(hipMemcpyAsync(s.d_out.ptr, img->data, bytes, hipMemcpyHostToDevice, s.stream));
+    lrp_image d = *img;
+    d.data = (float *)s.d_out.ptr;
+    r = lrp_post_process_device(&d, exposure, reinhard, device, s.stream);
+    if (r != LRP_OK) return r;
+    LRP_HIP_TRY(hipMemcpyAsync(img->data, s.d_out.ptr, bytes, hipMemcpyDeviceToHost, s.stream));
+    LRP_HIP_TRY(hipStreamSynchronize(s.stream));
+    return LRP_OK;
+  }();
+  return_context(c);
+  return st;
+}
+
+int lrp_synth_fill_device(float *data, int width, int height, int channels, uint32_t seed, int depth_channel,
+                          int device, void *stream) {
+  if (!data) return fail(LRP_ERR_NULL, "null data");
+  if (width < 1 || height < 1 || channels < 1) return fail(LRP_ERR_BAD_DIMS, "bad image dimensions");
+  const unsigned long long n = (unsigned long long)width * height * channels;
+  if (n >= (1ull << 30)) return fail(LRP_ERR_BAD_DIMS, "image too large");
+  int st = select_device(device);
+  if (st != LRP_OK) return st;
+  hipError_t e = lrp::launch_synth_fill(data, (uint32_t)n, channels, seed, depth_channel, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "synth_fill kernel launch");
+  return LRP_OK;
+}
+
+int lrp_math_eval_device(int func, const float *a, const float *b, float *out, size_t n, int device, void *stream) {
+  if (!a || !out) return fail(LRP_ERR_NULL, "null array");
+  if (func < 0 || func > 9) return fail(LRP_ERR_BAD_ARG, "unknown function id");
+  int st = select_device(device);
+  if (st != LRP_OK) return st;
+  if (n == 0) return LRP_OK;
+  hipError_t e = lrp::launch_math_eval(func, a, b, out, n, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "math_eval kernel launch");
+  return LRP_OK;
+}
+
+} // extern "C"

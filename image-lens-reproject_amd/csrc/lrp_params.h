@@ -1,0 +1,41 @@
+// lrp_params.h — kernel argument block shared by the C-ABI layer and the HIP
+// kernels.  Plain POD passed by value in kernarg (SGPR-resident, wave-uniform).
+#pragma once
+
+#include <stdint.h>
+
+namespace lrp {
+
+// Lens model ids used as template arguments (numbering of include/lrp.h /
+// reference src/config.hpp:7-13).
+enum : int { kRect = 0, kEquidistant = 1, kEquirect = 4 };
+// Input-lens mode: equirectangular sources split into clamped and wrapping
+// (reference LoopHorizontally, src/reproject.cpp:386-394).
+enum : int { kInRect = 0, kInEquidistant = 1, kInEquirect = 2, kInEquirectLoop = 3 };
+
+struct LensP {
+  float p[4];          // union payload of LensInfo (see include/lrp.h)
+  float sensor_width;
+  float sensor_height;
+};
+
+struct KParams {
+  const float *src;
+  float *dst;
+  int32_t in_w, in_h;
+  int32_t out_w, out_h;
+  int32_t channels;
+  int32_t num_samples;
+  float normalize;     // 1.0f / (num_samples * num_samples), src/reproject.cpp:280
+  LensP in_lens;
+  LensP out_lens;
+  float rot[9];        // row-major; valid when has_rot
+  int32_t has_rot;
+  int32_t has_post;    // fused post_process epilogue (src/reproject.cpp:421-437)
+  float exposure;
+  float reinhard;
+  int32_t tiles_x, tiles_y; // output tiling of the launch
+  int32_t y_offset;         // first output row of this launch (row-band launches)
+};
+
+} // namespace lrp

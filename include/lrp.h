@@ -1,0 +1,196 @@
+/*
+ * lrp.h — C ABI of the MI355X-native lens reprojection library (liblrp_hip.so).
+ *
+ * This is the drop-in boundary for the reference's L4 -> L1 call: the worker
+ * lambda in reference src/main.cpp:597-603 calls
+ *     reproject::reproject(&input, &output, num_samples, interpolation, rotation_matrix);
+ *     reproject::post_process(&output, exposure, reinhard);
+ * declared in reference src/reproject.hpp:22-27.  The reference has no FFI layer
+ * of its own; a maintainer binds these entry points from the C++
+ * wrapper in include/lens_reproject.hpp.
+ *
+ * Plain C: pointers, sizes, fixed-width enums.  No torch / HIP types appear in
+ * the signatures (a HIP stream travels as void*).  Every function returns an
+ * lrp_status; nothing exits the process or throws.  The library never falls
+ * back to a CPU path: without a usable gfx950 device every compute entry point
+ * fails with LRP_ERR_NO_DEVICE / LRP_ERR_HIP.
+ *
+ * Thread safety: all entry points may be called concurrently from different
+ * host threads (the reference calls reproject() from -j N pool threads,
+ * src/main.cpp:538-544).  An lrp_context must be used by one thread at a time.
+ */
+#ifndef LRP_H
+#define LRP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRP_ABI_VERSION 1
+
+/* ---- enums: numbering identical to the reference's ------------------------ */
+
+/* reference src/config.hpp:7-13 (enum LensType) */
+typedef enum lrp_lens_type {
+  LRP_RECTILINEAR = 0,
+  LRP_FISHEYE_EQUIDISTANT = 1,
+  LRP_FISHEYE_EQUISOLID = 2,     /* declared by the reference, rejected by reproject() */
+  LRP_FISHEYE_STEREOGRAPHIC = 3, /* declared by the reference, rejected by reproject() */
+  LRP_EQUIRECTANGULAR = 4
+} lrp_lens_type;
+
+/* reference src/reproject.hpp:16-20 (enum Interpolation) */
+typedef enum lrp_interpolation { LRP_NEAREST = 0, LRP_BILINEAR = 1, LRP_BICUBIC = 2 } lrp_interpolation;
+
+/* reference src/reproject.hpp:7 (enum DataLayout); carried, never read by the kernels */
+typedef enum lrp_data_layout { LRP_RGB = 0, LRP_RGBA = 1, LRP_RGBZ = 2, LRP_RGBAZ = 3 } lrp_data_layout;
+
+typedef enum lrp_status {
+  LRP_OK = 0,
+  LRP_ERR_OUTPUT_LENS = 1,   /* reference prints "Output lens type not supported." and exit(1), src/reproject.cpp:415-417 */
+  LRP_ERR_INPUT_LENS = 2,    /* "Input lens type not supported.",  src/reproject.cpp:395-397 */
+  LRP_ERR_INTERPOLATION = 3, /* "Interpolation method not supported.", src/reproject.cpp:364-366 */
+  LRP_ERR_CHANNELS = 4,      /* in->channels != out->channels (unchecked precondition in the reference) or < 1 */
+  LRP_ERR_BAD_DIMS = 5,      /* non-positive size, or an image of 4 GiB or more */
+  LRP_ERR_NULL = 6,          /* NULL image / data pointer */
+  LRP_ERR_NO_DEVICE = 7,     /* no HIP device, or device index out of range */
+  LRP_ERR_HIP = 8,           /* a HIP runtime call failed; see lrp_last_error() */
+  LRP_ERR_OOM = 9,           /* device or pinned-host allocation failed */
+  LRP_ERR_BAD_ARG = 10
+} lrp_status;
+
+/* ---- PODs: layout identical to the reference's ----------------------------- */
+
+/* reference src/config.hpp:15-37 (struct LensInfo): sizeof 28; type @0, union @4,
+ * sensor_width @20, sensor_height @24.  Millimetres and radians. */
+typedef struct lrp_lens {
+  int32_t type; /* lrp_lens_type */
+  union {
+    struct { float focal_length; } rectilinear;
+    struct { float fov; } fisheye_equidistant;
+    struct { float focal_length; float fov; } fisheye_equisolid;
+    struct { float latitude_min, latitude_max, longitude_min, longitude_max; } equirectangular;
+    float raw[4];
+  } u;
+  float sensor_width;
+  float sensor_height;
+} lrp_lens;
+
+/* reference src/reproject.hpp:9-14 (struct Image): sizeof 56; lens @0, width @28,
+ * height @32, channels @36, data @40, data_layout @48.  Interleaved row-major
+ * float32, data[(y*width + x)*channels + c], no row padding. */
+typedef struct lrp_image {
+  lrp_lens lens;
+  int32_t width, height, channels;
+  float *data;
+  int32_t data_layout; /* lrp_data_layout */
+} lrp_image;
+
+/* Optional fused epilogue == reference post_process(img, exposure, reinhard)
+ * (src/reproject.cpp:421-437) applied to the freshly written output.  The
+ * reference CLI runs it when exposure != 1 || reinhard != 1 (src/main.cpp:601). */
+typedef struct lrp_post {
+  float exposure;
+  float reinhard;
+} lrp_post;
+
+/* ---- library / device ------------------------------------------------------ */
+
+int lrp_abi_version(void);
+/* Number of usable HIP devices (0 when there is none; never negative). */
+int lrp_device_count(void);
+/* Static text for a status code. */
+const char *lrp_strerror(int status);
+/* Detail of the calling thread's last failure (HIP error string etc.), "" if none. */
+const char *lrp_last_error(void);
+
+/* ---- one image, host buffers (the reference's calling convention) ---------- */
+
+/* Drop-in for reproject::reproject (src/reproject.cpp:405-419) with in->data and
+ * out->data in host memory (pageable or pinned).  Uploads the source, runs the
+ * kernel on `device`, downloads the result; returns when out->data is complete.
+ * rotation: 9 floats row-major or NULL (= no rotation, src/reproject.cpp:303).
+ * post: NULL, or the fused post_process epilogue.
+ * num_samples <= 0 leaves out->data untouched, as the reference loop does. */
+int lrp_reproject(const lrp_image *in, lrp_image *out, int num_samples, int interpolation,
+                  const float *rotation, const lrp_post *post, int device);
+
+/* Drop-in for reproject::post_process (src/reproject.cpp:421-437), host buffer. */
+int lrp_post_process(lrp_image *img, float exposure, float reinhard, int device);
+
+/* ---- one image, device-resident buffers ------------------------------------ */
+
+/* Same operation with in->data / out->data being device pointers on `device`.
+ * Asynchronous: enqueues on `stream` (a hipStream_t, NULL = default stream) and
+ * returns; the caller synchronises.  No allocation, no host sync: capturable
+ * into a hipGraph. */
+int lrp_reproject_device(const lrp_image *in, lrp_image *out, int num_samples, int interpolation,
+                         const float *rotation, const lrp_post *post, int device, void *stream);
+
+int lrp_post_process_device(lrp_image *img, float exposure, float reinhard, int device, void *stream);
+
+/* One resident source, n_out target lenses/rotations (cubemap faces etc.):
+ * outs[i] is rendered with rotations + 9*i (or no rotation when rotations is
+ * NULL).  Equivalent to n_out reference calls sharing `in`. */
+int lrp_reproject_multi_device(const lrp_image *in, lrp_image *outs, int n_out, int num_samples,
+                               int interpolation, const float *rotations, const lrp_post *post,
+                               int device, void *stream);
+
+/* ---- batches of independent images (the reference's --input-dir path) ------ */
+
+/* A context owns `n_streams` HIP streams on one device, each with a device
+ * source/destination buffer pair and pinned staging, sized for the largest
+ * image submitted so far.  Images are independent (src/main.cpp:540-622: one
+ * file per pool thread); the context round-robins them over its streams so that
+ * H2D of image i+1, the kernel of image i and D2H of image i-1 overlap. */
+typedef struct lrp_context lrp_context;
+
+int lrp_context_create(lrp_context **ctx, int device, int n_streams);
+void lrp_context_destroy(lrp_context *ctx);
+/* Enqueue one image (host buffers).  Returns once the work is queued; in->data
+ * must stay valid and out->data must not be read until lrp_context_wait. */
+int lrp_context_submit(lrp_context *ctx, const lrp_image *in, lrp_image *out, int num_samples,
+                       int interpolation, const float *rotation, const lrp_post *post);
+/* Wait for everything submitted so far; returns the first error seen. */
+int lrp_context_wait(lrp_context *ctx);
+
+/* ---- synthetic frames (bench / tests) -------------------------------------- */
+
+/* Fill a device buffer with the counter-based synthetic frame of SURVEY.md §8d
+ * (identical bits to oracle lrpo_synth_fill on the host).  depth_channel = -1
+ * for colour-only frames. */
+int lrp_synth_fill_device(float *data, int width, int height, int channels, uint32_t seed,
+                          int depth_channel, int device, void *stream);
+
+/* Evaluate the device math routines on device arrays (lets tests prove the
+ * device build of the math matches the host libm): func 0 sinf, 1 cosf,
+ * 2 sincosf.sin, 3 sincosf.cos, 4 atanf, 5 asinf, 6 atan2f(a, b), 7 a / b,
+ * 8 sqrtf(a), 9 (float)int(a) with the x86 cvttss2si convention.
+ * `b` may be NULL for unary functions. */
+int lrp_math_eval_device(int func, const float *a, const float *b, float *out, size_t n, int device,
+                         void *stream);
+
+/* ---- caller-side producers of hot-path inputs (host, no device needed) ------ */
+
+/* computeRotationMatrix (reference src/main.cpp:98-142): R = R_y(pan) * R_x(pitch)
+ * * R_z(roll), row-major, angles in radians, float sin/cos. */
+void lrp_rotation_matrix(float pan, float pitch, float roll, float *out9);
+
+/* Lens constructors with the reference CLI's conventions (src/main.cpp:15-95):
+ * rectilinear: sensor_height = res_y / res_x * sensor_width (:27);
+ * equidistant: sensor 36 x 36 mm (:53-54);
+ * equirectangular: sensor 0 (:93); lrp_lens_equirectangular_full = "full"
+ * (-pi..pi, -pi/2..pi/2 narrowed to float, :62-66). */
+void lrp_lens_rectilinear(lrp_lens *lens, float focal_length, float sensor_width, float res_x, float res_y);
+void lrp_lens_equidistant(lrp_lens *lens, float fov);
+void lrp_lens_equirectangular(lrp_lens *lens, float longitude_min, float longitude_max, float latitude_min,
+                              float latitude_max);
+void lrp_lens_equirectangular_full(lrp_lens *lens);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRP_H */

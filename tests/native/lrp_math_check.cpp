@@ -1,0 +1,174 @@
+// Test-only harness: compares the product's math header (host build of
+// image-lens-reproject_amd/csrc/lrp_math.h) against the live host libm, the
+// library the reference's std::sin/std::cos/std::atan/std::atan2/std::asin
+// calls resolve to (reference src/reproject.cpp:182-263).
+//
+// Built by __graft_entry__.build() into tests/native/_build/; loaded with
+// ctypes by tests/test_math_vs_libm.py.
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <atomic>
+#include <thread>
+#include <vector>
+
+#include "lrp_math.h"
+
+namespace {
+
+inline bool same(float a, float b) {
+  uint32_t ua, ub;
+  memcpy(&ua, &a, 4);
+  memcpy(&ub, &b, 4);
+  if (ua == ub) return true;
+  return (a != a) && (b != b); // any NaN matches any NaN
+}
+
+enum Func { F_SIN = 0, F_COS = 1, F_SINCOS_S = 2, F_SINCOS_C = 3, F_ATAN = 4, F_ASIN = 5 };
+
+inline float own(int f, float x) {
+  switch (f) {
+  case F_SIN: return lrp::sinf_(x);
+  case F_COS: return lrp::cosf_(x);
+  case F_SINCOS_S: {
+    float s, c;
+    lrp::sincosf_(x, s, c);
+    return s;
+  }
+  case F_SINCOS_C: {
+    float s, c;
+    lrp::sincosf_(x, s, c);
+    return c;
+  }
+  case F_ATAN: return lrp::atanf_(x);
+  default: return lrp::asinf_(x);
+  }
+}
+
+inline float ref(int f, float x) {
+  switch (f) {
+  case F_SIN: return sinf(x);
+  case F_COS: return cosf(x);
+  case F_SINCOS_S: {
+    float s, c;
+    sincosf(x, &s, &c);
+    return s;
+  }
+  case F_SINCOS_C: {
+    float s, c;
+    sincosf(x, &s, &c);
+    return c;
+  }
+  case F_ATAN: return atanf(x);
+  default: return asinf(x);
+  }
+}
+
+inline uint64_t splitmix(uint64_t &s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+} // namespace
+
+extern "C" {
+
+// Sweep bit patterns [begin, begin+count) with stride `stride` of a unary
+// function; returns the number of mismatches and the first offending pattern.
+uint64_t lrp_check_unary(int func, uint32_t begin, uint64_t count, uint32_t stride, int threads,
+                         uint32_t *first_bad) {
+  std::atomic<uint64_t> bad{0};
+  std::atomic<uint64_t> first{~0ull};
+  if (threads < 1) threads = 1;
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) {
+    pool.emplace_back([&, t]() {
+      uint64_t local = 0;
+      for (uint64_t i = (uint64_t)t; i < count; i += (uint64_t)threads) {
+        uint32_t u = begin + (uint32_t)(i * stride);
+        float x;
+        memcpy(&x, &u, 4);
+        if (!same(own(func, x), ref(func, x))) {
+          ++local;
+          uint64_t cur = first.load();
+          while ((uint64_t)u < cur && !first.compare_exchange_weak(cur, (uint64_t)u)) {
+          }
+        }
+      }
+      bad += local;
+    });
+  }
+  for (auto &th : pool) th.join();
+  if (first_bad) *first_bad = (uint32_t)first.load();
+  return bad.load();
+}
+
+// atan2f: `count` pseudo-random pairs.  mode 0: both operands uniform over all
+// bit patterns; mode 1: uniform finite magnitudes in a lens-like range
+// (|v| in [2^-20, 2^20)) with random signs; mode 2: exponent-difference probe
+// (pairs whose exponents differ by 55..66, the k>60 / k<-60 branches).
+uint64_t lrp_check_atan2(uint64_t seed, uint64_t count, int mode, int threads, uint32_t *bad_y,
+                         uint32_t *bad_x) {
+  std::atomic<uint64_t> bad{0};
+  std::atomic<int> have{0};
+  if (threads < 1) threads = 1;
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) {
+    pool.emplace_back([&, t]() {
+      uint64_t s = seed * 0x100000001B3ull + (uint64_t)t * 0x9E3779B97F4A7C15ull;
+      uint64_t local = 0;
+      for (uint64_t i = (uint64_t)t; i < count; i += (uint64_t)threads) {
+        uint64_t r = splitmix(s);
+        uint32_t uy = (uint32_t)r, ux = (uint32_t)(r >> 32);
+        if (mode == 1) {
+          auto squash = [](uint32_t u) {
+            uint32_t e = 107 + ((u >> 23) & 0xff) % 40; // exponent 2^-20 .. 2^19
+            return (u & 0x807fffffu) | (e << 23);
+          };
+          uy = squash(uy);
+          ux = squash(ux);
+        } else if (mode == 2) {
+          uint32_t ey = 30 + ((uy >> 23) & 0xff) % 160;
+          uint32_t diff = 55 + (uint32_t)(splitmix(s) % 12);
+          uint32_t ex = (splitmix(s) & 1) ? ey + diff : ey - diff;
+          if ((int32_t)ex < 1) ex = 1;
+          if (ex > 254) ex = 254;
+          uy = (uy & 0x807fffffu) | (ey << 23);
+          ux = (ux & 0x807fffffu) | (ex << 23);
+        }
+        float y, x;
+        memcpy(&y, &uy, 4);
+        memcpy(&x, &ux, 4);
+        if (!same(lrp::atan2f_(y, x), atan2f(y, x))) {
+          ++local;
+          if (have.exchange(1) == 0) {
+            if (bad_y) *bad_y = uy;
+            if (bad_x) *bad_x = ux;
+          }
+        }
+      }
+      bad += local;
+    });
+  }
+  for (auto &th : pool) th.join();
+  return bad.load();
+}
+
+// Element-wise evaluation (for targeted special-value tests from Python).
+void lrp_eval_unary(int func, const float *in, float *out_own, float *out_ref, uint64_t n) {
+  for (uint64_t i = 0; i < n; ++i) {
+    out_own[i] = own(func, in[i]);
+    out_ref[i] = ref(func, in[i]);
+  }
+}
+void lrp_eval_atan2(const float *y, const float *x, float *out_own, float *out_ref, uint64_t n) {
+  for (uint64_t i = 0; i < n; ++i) {
+    out_own[i] = lrp::atan2f_(y[i], x[i]);
+    out_ref[i] = atan2f(y[i], x[i]);
+  }
+}
+
+} // extern "C"
