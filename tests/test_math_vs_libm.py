@@ -1,0 +1,54 @@
+"""CPU: the host build of lrp_math.h against the live libm of this machine, the
+library the reference's std::sin / std::cos / std::atan / std::atan2 / std::asin
+resolve to (reference src/reproject.cpp:182-263).  Exhaustive over all 2^32
+binary32 inputs for the unary functions; structured + random pairs for atan2f.
+Bit-exact (any NaN equals any NaN)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tests", "native", "_build", "liblrp_math_check.so")
+THREADS = min(32, os.cpu_count() or 1)
+
+
+@pytest.fixture(scope="module")
+def chk():
+    L = ctypes.CDLL(SO)
+    L.lrp_check_unary.restype = ctypes.c_uint64
+    L.lrp_check_unary.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
+                                  ctypes.POINTER(ctypes.c_uint32)]
+    L.lrp_check_atan2.restype = ctypes.c_uint64
+    L.lrp_check_atan2.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                  ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    L.lrp_eval_atan2.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_uint64]
+    return L
+
+
+@pytest.mark.parametrize("func,name", [(0, "sinf"), (1, "cosf"), (2, "sincosf.sin"), (3, "sincosf.cos"),
+                                       (4, "atanf"), (5, "asinf")])
+def test_unary_exhaustive(chk, func, name):
+    first = ctypes.c_uint32(0)
+    bad = chk.lrp_check_unary(func, 0, 1 << 32, 1, THREADS, ctypes.byref(first))
+    assert bad == 0, f"{name}: {bad} of 2^32 inputs differ from libm, first bit pattern 0x{first.value:08x}"
+
+
+@pytest.mark.parametrize("mode,count", [(0, 1 << 27), (1, 1 << 28), (2, 1 << 26)])
+def test_atan2_random_pairs(chk, mode, count):
+    by, bx = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    bad = chk.lrp_check_atan2(0xC0FFEE + mode, count, mode, THREADS, ctypes.byref(by), ctypes.byref(bx))
+    assert bad == 0, f"atan2f mode {mode}: {bad} mismatches, first y=0x{by.value:08x} x=0x{bx.value:08x}"
+
+
+def test_atan2_special_grid(chk):
+    """Every pair from a grid of special values (signed zeros, infinities, NaN,
+    denormals, the x == 1 shortcut, huge exponent gaps)."""
+    vals = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e-38, 3e38, -3e38, 0.5, 2.0, 1e-20,
+                     1e20, -1e-20, -1e20, 3.14159274, 0.4375, 2.4375], dtype=np.float32)
+    y, x = [a.reshape(-1).copy() for a in np.meshgrid(vals, vals)]
+    own, ref = np.empty_like(y), np.empty_like(y)
+    chk.lrp_eval_atan2(y.ctypes.data, x.ctypes.data, own.ctypes.data, ref.ctypes.data, y.size)
+    same = (own.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(own) & np.isnan(ref))
+    assert same.all(), f"atan2f special grid: y={y[~same][:4]} x={x[~same][:4]}"
