@@ -10,7 +10,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off
        -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -fno-gpu-flush-denormals-to-zero
        -Wall -Wno-unused-function -I"$here" -I"$here/../../include")
-srcs=(lrp_kernels_nn.hip lrp_kernels_bl.hip lrp_kernels_bc.hip lrp_aux_kernels.hip lrp_capi.cpp lrp_host_util.cpp)
+srcs=(lrp_kernels_nn.hip lrp_kernels_bl.hip lrp_kernels_bc.hip lrp_tile_nn.hip lrp_tile_bl.hip lrp_tile_bc.hip lrp_tile_win.hip lrp_tables.hip lrp_aux_kernels.hip lrp_capi.cpp lrp_host_util.cpp)
 pids=()
 for s in "${srcs[@]}"; do
   o="$obj/${s%.*}.o"
@@ -21,6 +21,7 @@ for s in "${srcs[@]}"; do
   fi
 done
 for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/liblrp_hip.so" "$obj"/lrp_kernels_nn.o "$obj"/lrp_kernels_bl.o \
-  "$obj"/lrp_kernels_bc.o "$obj"/lrp_aux_kernels.o "$obj"/lrp_capi.o "$obj"/lrp_host_util.o
+objs=()
+for s in "${srcs[@]}"; do objs+=("$obj/${s%.*}.o"); done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/liblrp_hip.so" "${objs[@]}"
 echo "built $out/liblrp_hip.so"

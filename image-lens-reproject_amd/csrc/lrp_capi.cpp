@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -14,11 +15,16 @@
 
 #include "../../include/lrp.h"
 #include "lrp_params.h"
+#include "lrp_tables.h"
 
 namespace lrp {
 hipError_t launch_nearest(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
 hipError_t launch_bilinear(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
 hipError_t launch_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
+hipError_t launch_tile_nearest(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
+hipError_t launch_tile_bilinear(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
+hipError_t launch_tile_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
+hipError_t launch_win_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
 hipError_t launch_post_process(float *data, uint32_t n_pixels, int channels, float exposure, float reinhard,
                                hipStream_t stream);
 hipError_t launch_synth_fill(float *data, uint32_t n_elems, int channels, uint32_t seed, int depth_channel,
@@ -137,17 +143,61 @@ lrp::KParams make_params(const lrp_image *in, const lrp_image *out, int num_samp
     P.reinhard = post->reinhard;
   }
   P.y_offset = 0;
+  // lens-only constants of the tile kernel, same binary32 operations as the
+  // reference performs per pixel (src/reproject.cpp:178,196,265-266)
+  P.in_focal = in->lens.sensor_width / in->lens.u.fisheye_equidistant.fov;
+  P.out_focal = out->lens.sensor_width / out->lens.u.fisheye_equidistant.fov;
+  P.in_lon_span = in->lens.u.equirectangular.longitude_max - in->lens.u.equirectangular.longitude_min;
+  P.in_lat_span = in->lens.u.equirectangular.latitude_max - in->lens.u.equirectangular.latitude_min;
   return P;
 }
 
+// Kernel selection.  The tile kernel (lrp_kernel_v2.h) serves RGBA images whose
+// tap indices fit its 16-bit packing; everything else — and everything when
+// LRP_KERNEL=pixel is set in the environment (A/B checks) — takes the
+// one-pixel-per-lane kernel (lrp_kernel_impl.h).  Both are HIP; there is no CPU path.
+// 0 = pixel kernel, 1 = tile kernel everywhere, 2 (default) = tile kernel with the
+// LDS-window kernel for bicubic.
+int kernel_choice() {
+  static const int choice = [] {
+    const char *v = std::getenv("LRP_KERNEL");
+    if (v && std::strcmp(v, "pixel") == 0) return 0;
+    if (v && std::strcmp(v, "tile") == 0) return 1;
+    return 2;
+  }();
+  return choice;
+}
+
 int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int interpolation,
-                      const float *rotation, const lrp_post *post, hipStream_t stream) {
+                      const float *rotation, const lrp_post *post, int device, hipStream_t stream) {
   if (num_samples <= 0) return LRP_OK; // reference loop body never runs: output untouched
-  const lrp::KParams P = make_params(in, out, num_samples, rotation, post);
+  lrp::KParams P = make_params(in, out, num_samples, rotation, post);
   const int oi = out_lens_index(out->lens.type);
   const int im = in_lens_mode(in->lens);
   hipError_t e;
-  if (interpolation == LRP_NEAREST)
+  bool tile = kernel_choice() != 0 && out->channels == 4 && in->width <= 65535 && in->height <= 32767 &&
+              (long long)out->width * num_samples < (1ll << 30) && (long long)out->height * num_samples < (1ll << 30);
+  if (tile && out->lens.type != LRP_FISHEYE_EQUIDISTANT) {
+    // separable output-lens terms (cached per device / lens / size / num_samples)
+    e = lrp::get_output_tables(device, out->lens.type == LRP_RECTILINEAR ? lrp::kRect : lrp::kEquirect, P.out_lens,
+                               out->width, out->height, num_samples, &P.col_tab, &P.row_tab);
+    if (e == hipErrorOutOfMemory) {
+      (void)hipGetLastError();
+      tile = false; // cache full or no memory for the tables: per-pixel kernel
+    } else if (e != hipSuccess) {
+      return hip_fail(e, "output-lens table build");
+    }
+  }
+  if (tile) {
+    if (interpolation == LRP_NEAREST)
+      e = lrp::launch_tile_nearest(P, oi, im, stream);
+    else if (interpolation == LRP_BILINEAR)
+      e = lrp::launch_tile_bilinear(P, oi, im, stream);
+    else if (kernel_choice() == 2 && num_samples == 1)
+      e = lrp::launch_win_bicubic(P, oi, im, stream);
+    else
+      e = lrp::launch_tile_bicubic(P, oi, im, stream);
+  } else if (interpolation == LRP_NEAREST)
     e = lrp::launch_nearest(P, oi, im, stream);
   else if (interpolation == LRP_BILINEAR)
     e = lrp::launch_bilinear(P, oi, im, stream);
@@ -232,7 +282,7 @@ int lrp_reproject_device(const lrp_image *in, lrp_image *out, int num_samples, i
   if (st != LRP_OK) return st;
   st = select_device(device);
   if (st != LRP_OK) return st;
-  return enqueue_reproject(in, out, num_samples, interpolation, rotation, post, (hipStream_t)stream);
+  return enqueue_reproject(in, out, num_samples, interpolation, rotation, post, device, (hipStream_t)stream);
 }
 
 int lrp_reproject_multi_device(const lrp_image *in, lrp_image *outs, int n_out, int num_samples,
@@ -247,7 +297,7 @@ int lrp_reproject_multi_device(const lrp_image *in, lrp_image *outs, int n_out, 
   if (st != LRP_OK) return st;
   for (int i = 0; i < n_out; ++i) {
     st = enqueue_reproject(in, &outs[i], num_samples, interpolation, rotations ? rotations + 9 * i : nullptr, post,
-                           (hipStream_t)stream);
+                           device, (hipStream_t)stream);
     if (st != LRP_OK) return st;
   }
   return LRP_OK;
@@ -319,7 +369,7 @@ int lrp_context_submit(lrp_context *ctx, const lrp_image *in, lrp_image *out, in
   lrp_image din = *in, dout = *out;
   din.data = (float *)s.d_in.ptr;
   dout.data = (float *)s.d_out.ptr;
-  st = enqueue_reproject(&din, &dout, num_samples, interpolation, rotation, post, s.stream);
+  st = enqueue_reproject(&din, &dout, num_samples, interpolation, rotation, post, ctx->device, s.stream);
   if (st != LRP_OK) return st;
   LRP_HIP_TRY(hipMemcpyAsync(out->data, s.d_out.ptr, out_bytes, hipMemcpyDeviceToHost, s.stream));
   return LRP_OK;

@@ -19,7 +19,6 @@ namespace lrp {
 constexpr int kTileW = 32;
 constexpr int kTileH = 8;
 constexpr int kThreads = kTileW * kTileH; // 256 = 4 wavefronts
-constexpr int kXcds = 8;
 
 template <int OutLens, int InMode, int Interp, int CH>
 __global__ __launch_bounds__(kThreads) void reproject_kernel(const KParams P) {

@@ -1,0 +1,639 @@
+// lrp_kernel_v2.h — the tile kernel: the hot path as it runs on gfx950.
+//
+// Work decomposition
+//   * A 256-thread workgroup (4 wavefronts) owns a 64 x 16 tile of output pixels.
+//     Lane l of every wavefront owns output column tile_x*64 + l; wavefront w owns
+//     the four contiguous rows 4w .. 4w+3, so each of its stores is one contiguous
+//     1 KiB run (64 lanes x float4) and every per-row quantity is wave-uniform
+//     (SGPR / scalar loads).
+//   * Tiles are numbered so that the workgroups the dispatcher deals to one XCD
+//     (blockIdx % 8 equal) walk a contiguous band of the output: neighbouring
+//     tiles read neighbouring source rows, which then hit in that XCD's 4 MiB L2.
+//
+// Instruction diet (the reference loop is VALU-bound on this chip, not HBM-bound:
+// an IEEE divide costs ~46 issue cycles per wavefront, a sqrt ~53)
+//   * separable output-lens terms come from per-column / per-row tables
+//     (lrp_tables.hip) instead of 4 divides or 3 double-precision polynomials
+//     per pixel;
+//   * lens-only constants (sensor_width / fov, angular spans) come from the host;
+//   * x / -z, y / -z is skipped when -z == 1 for the whole wavefront (division by
+//     one is the identity in IEEE arithmetic) — the no-rotation / identity case.
+//   Every remaining operation is the reference's, in the reference's order.
+//
+// Bicubic taps through LDS
+//   The 16 taps of neighbouring pixels overlap almost completely, and 16 float4
+//   gathers per pixel saturate the texture-address path long before HBM.  Each
+//   wavefront reduces the tap-index bounding box of its 256 pixels with DPP
+//   butterflies, the four partial boxes meet in LDS, and the workgroup copies the
+//   window (coalesced row segments, float4 per lane) into LDS once.  A pixel
+//   whose taps are 4 consecutive columns x 4 consecutive rows — everything except
+//   image borders and the +-pi seam — then needs ONE address: its 16 taps are
+//   ds_read_b128 at compile-time offsets from it.  Windows larger than the LDS
+//   budget (poles, seam, strong minification) and non-consecutive taps fall back,
+//   per workgroup resp. per wavefront, to explicit per-tap addressing.
+#pragma once
+
+#include "lrp_device.h"
+
+#ifndef LRP_ABLATE
+#define LRP_ABLATE 0 // 1..4: timing-only experiment builds (tools/ablate.sh); never shipped
+#endif
+#ifndef LRP_TILE_MINWAVES
+#define LRP_TILE_MINWAVES 1 // __launch_bounds__ waves per SIMD of the tile kernel
+#endif
+#ifndef LRP_WIN_MINWAVES
+#define LRP_WIN_MINWAVES 1 // __launch_bounds__ waves per SIMD of the window kernel
+#endif
+#ifndef LRP_TILE_ROWS
+#define LRP_TILE_ROWS 4
+#endif
+
+namespace lrp {
+
+constexpr int kT2W = 64;         // tile width: one output column per lane
+constexpr int kT2Rows = LRP_TILE_ROWS; // output rows per wavefront
+constexpr int kT2Waves = 4;      // wavefronts per workgroup
+constexpr int kT2H = kT2Rows * kT2Waves;
+constexpr int kT2Threads = 64 * kT2Waves;
+constexpr int kWinTexels = 2560; // staged source window capacity: 2560 float4 = 40 KiB -> 4 workgroups / CU
+
+// ---- wavefront-wide integer min / max (all 64 lanes active) ------------------
+template <int Ctrl> __device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, Ctrl, 0xF, 0xF, false);
+}
+template <bool Max> __device__ __forceinline__ int pick(int a, int b) {
+  if constexpr (Max)
+    return a > b ? a : b;
+  else
+    return a < b ? a : b;
+}
+template <bool Max> __device__ __forceinline__ int wave_extreme(int v) {
+  v = pick<Max>(v, dpp_i32<0xB1>(v));  // quad_perm [1,0,3,2]
+  v = pick<Max>(v, dpp_i32<0x4E>(v));  // quad_perm [2,3,0,1]
+  v = pick<Max>(v, dpp_i32<0x141>(v)); // row_half_mirror
+  v = pick<Max>(v, dpp_i32<0x140>(v)); // row_mirror: every lane of a 16-lane row holds the row's extreme
+  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return pick<Max>(pick<Max>(a, b), pick<Max>(c, d));
+}
+
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == ~0ull; }
+
+// ---- ray -> source coordinates with hoisted constants --------------------------
+template <int InMode>
+__device__ __forceinline__ void ray_to_source_v2(const KParams &P, float x, float y, float z, float &cx, float &cy) {
+  const LensP &L = P.in_lens;
+  const float img_w = (float)P.in_w, img_h = (float)P.in_h;
+  if constexpr (InMode == kInRect || InMode == kInEquidistant) {
+    // x /= -z; y /= -z  (src/reproject.cpp:163-164,191-192).  v / 1.0f == v.
+    const float nz = -z;
+    if (!wave_all(nz == 1.0f)) {
+      x = x / nz;
+      y = y / nz;
+    }
+  }
+  if constexpr (InMode == kInRect) {
+    const float focal = L.p[0];
+    cx = x * img_w / L.sensor_width * focal; // :165
+    cy = y * img_h / L.sensor_height * focal;
+  } else if constexpr (InMode == kInEquidistant) {
+    const float r = lrp_sqrtf(x * x + y * y); // :193
+    const float theta = atanf_(r);            // :194
+    const float r_mm = P.in_focal * theta;    // :196-198
+    const float r_px = r_mm / L.sensor_width * img_w;
+    cx = x / r * r_px; // :202-203
+    cy = y / r * r_px;
+  } else {
+    const float lat_min = L.p[0], lon_min = L.p[2];
+    const float theta = -atan2f_(-x, -z);                            // :262
+    const float phi = asinf_(y / lrp_sqrtf(x * x + y * y + z * z)); // :263
+    cx = ((theta - lon_min) / P.in_lon_span - 0.5f) * img_w;         // :268
+    cy = ((phi - lat_min) / P.in_lat_span - 0.5f) * img_h;           // :269
+  }
+}
+
+// equidistant_to_vec (src/reproject.cpp:171-186) with the lens constant hoisted.
+__device__ __forceinline__ void equidistant_ray_v2(const KParams &P, float cx, float cy, float &vx, float &vy,
+                                                   float &vz) {
+  const float r_px = lrp_sqrtf(cx * cx + cy * cy);
+  const float r_mm = r_px / (float)P.out_w * P.out_lens.sensor_width;
+  const float theta = r_mm / P.out_focal;
+  float sn, cs;
+  sincosf_(theta, sn, cs);
+  const float s = sn / r_px;
+  vx = s * cx;
+  vy = s * cy;
+  vz = cs;
+}
+
+// The reference's tap indices (src/reproject.cpp:114-127).
+template <bool Loop>
+__device__ __forceinline__ void bicubic_indices(float sx, float sy, int w, int h, int xs[4], int ys[4]) {
+  xs[0] = column<Loop>(trunc_x86(sx - 1.0f), w);
+  xs[1] = column<Loop>(trunc_x86(sx), w);
+  xs[2] = column<Loop>(trunc_x86(sx + 1.0f), w);
+  xs[3] = column<Loop>(trunc_x86(sx + 2.0f), w);
+  ys[0] = clamp_index(trunc_x86(sy - 1.0f), h - 1);
+  ys[1] = clamp_index(trunc_x86(sy), h - 1);
+  ys[2] = clamp_index(trunc_x86(sy + 1.0f), h - 1);
+  ys[3] = clamp_index(trunc_x86(sy + 2.0f), h - 1);
+}
+
+// ---- bicubic on channel pairs ---------------------------------------------------
+// An RGBA texel is two register pairs (r,g) and (b,a); every Catmull-Rom step is
+// one packed instruction per pair (v_pk_mul_f32 / v_pk_add_f32 round each half
+// exactly like the scalar instruction), with the weights broadcast.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct Rgba {
+  f2 lo, hi;
+};
+__device__ __forceinline__ Rgba as_rgba(const float4 v) { return Rgba{f2{v.x, v.y}, f2{v.z, v.w}}; }
+
+// cubicInterpolate (src/reproject.cpp:92-98), same association order as catmull_rom().
+__device__ __forceinline__ f2 catmull_rom2(const f2 a, const f2 b, const f2 c, const f2 d, float t, float half_t) {
+  const f2 inner = ((3.0f * (b - c)) + d) - a;
+  const f2 mid = ((((2.0f * a) - (5.0f * b)) + (4.0f * c)) - d) + t * inner;
+  const f2 outer = (c - a) + t * mid;
+  return b + half_t * outer;
+}
+__device__ __forceinline__ Rgba cubic4(const Rgba a, const Rgba b, const Rgba c, const Rgba d, float t, float half_t) {
+  return Rgba{catmull_rom2(a.lo, b.lo, c.lo, d.lo, t, half_t), catmull_rom2(a.hi, b.hi, c.hi, d.hi, t, half_t)};
+}
+
+// ---- source texels through a buffer descriptor ------------------------------------
+// buffer_load_dwordx4 takes a 32-bit VGPR byte offset, an SGPR byte offset and a
+// 12-bit immediate: the 16 taps of an interior bicubic pixel are ONE VGPR offset
+// (first tap), four SGPR row offsets (0, W*16, 2W*16, 3W*16 — computed once per
+// kernel) and the immediates 0/16/32/48.  No per-tap address arithmetic at all.
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Rgba texel_at(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+  const u4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
+  return Rgba{f2{u2f(q.x), u2f(q.y)}, f2{u2f(q.z), u2f(q.w)}};
+}
+
+// bicubicInterpolate (src/reproject.cpp:100-107): vertical cubic per tap column,
+// then the horizontal one.  Taps: byte offset v[i] (column part, VGPR) + r[j]
+// (row part; SGPR in the interior path).
+template <bool ScalarRows>
+__device__ __forceinline__ Rgba bicubic_taps(__amdgpu_buffer_rsrc_t rsrc, uint32_t v0, uint32_t v1, uint32_t v2,
+                                             uint32_t v3, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, float fx,
+                                             float fy) {
+  // ScalarRows: r[j] are wave-uniform and ride in the instruction's SGPR offset;
+  // otherwise they are per-lane and are added into the VGPR offset.
+  auto tap = [&](uint32_t v, uint32_t r) {
+    if constexpr (ScalarRows)
+      return texel_at(rsrc, v, r);
+    else
+      return texel_at(rsrc, v + r, 0u);
+  };
+  const float hfx = 0.5f * fx, hfy = 0.5f * fy;
+  const Rgba k0 = cubic4(tap(v0, r0), tap(v0, r1), tap(v0, r2), tap(v0, r3), fy, hfy);
+  const Rgba k1 = cubic4(tap(v1, r0), tap(v1, r1), tap(v1, r2), tap(v1, r3), fy, hfy);
+  const Rgba k2 = cubic4(tap(v2, r0), tap(v2, r1), tap(v2, r2), tap(v2, r3), fy, hfy);
+  const Rgba k3 = cubic4(tap(v3, r0), tap(v3, r1), tap(v3, r2), tap(v3, r3), fy, hfy);
+  return cubic4(k0, k1, k2, k3, fx, hfx);
+}
+
+// Interior test shared by the bilinear and bicubic fast paths: with
+// lo <= s < hi (hi = extent - reach) no tap index is clamped or wrapped, and with
+// (s + reach) - s == reach the float additions s + 1.0f .. s + reach are exact, so
+// int(s + k) == int(s) + k for every tap (s - 1.0f is exact for s >= 1).  NaN fails.
+__device__ __forceinline__ int interior(float s, float lo, float hi, float reach) {
+  return (int)(s >= lo) & (int)(s < hi) & (int)(((s + reach) - s) == reach);
+}
+
+// ---- output pixel -> source coordinates (src/reproject.cpp:287-324) ----------------
+// Terms of the output lens that depend on the column and the horizontal
+// sub-sample only.
+struct ColTerms {
+  float a, b; // rectilinear: vx | equirectangular: vx, vz | equidistant: scx
+};
+template <int OutLens> __device__ __forceinline__ ColTerms column_terms(const KParams &P, int xe, int ssx) {
+  const int ns = P.num_samples;
+  ColTerms c{0.0f, 0.0f};
+  if constexpr (OutLens == kRect) {
+    c.a = P.col_tab[xe * ns + ssx];
+  } else if constexpr (OutLens == kEquirect) {
+    c.a = P.col_tab[xe * ns + ssx];
+    c.b = P.col_tab[P.out_w * ns + xe * ns + ssx];
+  } else {
+    const float cx = ((float)xe + 0.5f) - (float)P.out_w * 0.5f; // :287
+    c.a = cx + ((float)ssx + 1.0f) / ((float)ns + 1.0f) - 0.5f;  // :295
+  }
+  return c;
+}
+
+// One sub-sample of output pixel (column terms `col`, row ye) -> top-left-origin
+// source texel coordinates.  All 64 lanes must be active (wave-wide vote inside).
+template <int OutLens, int InMode>
+__device__ __forceinline__ void pixel_source(const KParams &P, const ColTerms col, int ye, int ssy, float &sx,
+                                             float &sy) {
+  const int ns = P.num_samples;
+  float vx, vy, vz;
+  if constexpr (OutLens == kRect) {
+    vx = col.a;
+    vy = P.row_tab[ye * ns + ssy];
+    vz = -1.0f;
+  } else if constexpr (OutLens == kEquirect) {
+    vx = col.a;
+    vz = col.b;
+    vy = P.row_tab[ye * ns + ssy];
+  } else {
+    const float cy = ((float)ye + 0.5f) - (float)P.out_h * 0.5f;               // :288
+    const float scy = cy + ((float)ssy + 1.0f) / ((float)ns + 1.0f) - 0.5f;    // :298
+    equidistant_ray_v2(P, col.a, scy, vx, vy, vz);
+  }
+  if (P.has_rot) { // :303-311
+    const float nx = P.rot[0] * vx + P.rot[1] * vy + P.rot[2] * vz;
+    const float ny = P.rot[3] * vx + P.rot[4] * vy + P.rot[5] * vz;
+    const float nz = P.rot[6] * vx + P.rot[7] * vy + P.rot[8] * vz;
+    vx = nx;
+    vy = ny;
+    vz = nz;
+  }
+  float px, py;
+  ray_to_source_v2<InMode>(P, vx, vy, vz, px, py);
+  sx = (px - 0.5f) + (float)P.in_w * 0.5f; // :323-324
+  sy = (py - 0.5f) + (float)P.in_h * 0.5f;
+}
+
+// ---- one sample, taps straight from global memory -------------------------------
+struct SrcView {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t row_bytes;
+  float x_hi, y_hi; // interior bounds of the fast paths: extent - reach
+};
+template <int Interp> __device__ __forceinline__ SrcView source_view(const KParams &P) {
+  SrcView v;
+  v.row_bytes = (uint32_t)P.in_w * 16u;
+  v.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.src), 0, (int)(v.row_bytes * (uint32_t)P.in_h),
+                                             0x00020000);
+  v.x_hi = (float)(P.in_w - (Interp == 2 ? 2 : 1));
+  v.y_hi = (float)(P.in_h - (Interp == 2 ? 2 : 1));
+  return v;
+}
+
+// sample_nearest / sample_bilinear / sample_bicubic (src/reproject.cpp:39-148).
+// All 64 lanes must be active (wave-wide vote).
+template <int Interp, bool Loop>
+__device__ __forceinline__ Rgba sample_direct(const KParams &P, const SrcView &src, float sx, float sy) {
+  const int in_w = P.in_w, in_h = P.in_h;
+  const uint32_t row_bytes = src.row_bytes;
+  const __amdgpu_buffer_rsrc_t rsrc = src.rsrc;
+  const float x_hi = src.x_hi, y_hi = src.y_hi;
+  Rgba s;
+  if constexpr (Interp == 2) {
+    if (wave_all((interior(sx, 1.0f, x_hi, 2.0f) & interior(sy, 1.0f, y_hi, 2.0f)) != 0)) {
+      // every lane: 4 consecutive columns x 4 consecutive rows, nothing clamped
+      // (src/reproject.cpp:114-131 reduce to int(s) - 1 .. int(s) + 2, f = s - int(s))
+      const float tx_ = __builtin_truncf(sx), ty_ = __builtin_truncf(sy);
+      const float fx = sx - tx_, fy = sy - ty_;
+      const uint32_t v0 = __umul24((uint32_t)((int)ty_ - 1), row_bytes) + (uint32_t)((int)tx_ - 1) * 16u;
+      s = bicubic_taps<true>(rsrc, v0, v0 + 16u, v0 + 32u, v0 + 48u, 0u, row_bytes, 2u * row_bytes,
+                                 3u * row_bytes, fx, fy);
+    } else {
+      int xs[4], ys[4];
+      bicubic_indices<Loop>(sx, sy, in_w, in_h, xs, ys);
+      const float fx = unit_clamp(sx - (float)xs[1]); // :130-131
+      const float fy = unit_clamp(sy - (float)ys[1]);
+      s = bicubic_taps<false>(rsrc, (uint32_t)xs[0] * 16u, (uint32_t)xs[1] * 16u, (uint32_t)xs[2] * 16u,
+                                 (uint32_t)xs[3] * 16u, (uint32_t)ys[0] * row_bytes, (uint32_t)ys[1] * row_bytes,
+                                 (uint32_t)ys[2] * row_bytes, (uint32_t)ys[3] * row_bytes, fx, fy);
+    }
+  } else if constexpr (Interp == 1) {
+    if (wave_all((interior(sx, 0.0f, x_hi, 1.0f) & interior(sy, 0.0f, y_hi, 1.0f)) != 0)) {
+      // src/reproject.cpp:60-88 with lx = int(sx), ux = lx + 1, fx = sx - lx
+      const float tx_ = __builtin_truncf(sx), ty_ = __builtin_truncf(sy);
+      const float fx = sx - tx_, fy = sy - ty_;
+      const float cfx = 1.0f - fx, cfy = 1.0f - fy;
+      const uint32_t v0 = __umul24((uint32_t)(int)ty_, row_bytes) + (uint32_t)(int)tx_ * 16u;
+      const Rgba ll = texel_at(rsrc, v0, 0u), lu = texel_at(rsrc, v0 + 16u, 0u);
+      const Rgba ul = texel_at(rsrc, v0, row_bytes), uu = texel_at(rsrc, v0 + 16u, row_bytes);
+      const f2 lo_l = fx * lu.lo + cfx * ll.lo, lo_h = fx * lu.hi + cfx * ll.hi; // :83-84
+      const f2 hi_l = fx * uu.lo + cfx * ul.lo, hi_h = fx * uu.hi + cfx * ul.hi;
+      s = Rgba{fy * hi_l + cfy * lo_l, fy * hi_h + cfy * lo_h}; // :87
+    } else {
+      const Texel<4> t = sample_bilinear<4, Loop>(P, sx, sy);
+      s = Rgba{f2{t.v[0], t.v[1]}, f2{t.v[2], t.v[3]}};
+    }
+  } else {
+    // sample_nearest (src/reproject.cpp:39-53)
+    const int lx = column<Loop>(trunc_x86(sx + 0.5f), in_w);
+    const int ly = clamp_index(trunc_x86(sy + 0.5f), in_h - 1);
+    s = texel_at(rsrc, __umul24((uint32_t)ly, row_bytes) + (uint32_t)lx * 16u, 0u);
+  }
+  return s;
+}
+
+// ---- the tile kernel (RGBA float) ------------------------------------------------
+template <int OutLens, int InMode, int Interp>
+__global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_kernel(const KParams P) {
+  constexpr bool Loop = (InMode == kInEquirectLoop);
+
+  const int n_tiles = P.tiles_x * P.tiles_y;
+  const int chunk = (n_tiles + kXcds - 1) / kXcds;
+  const int tile = (int)(blockIdx.x % kXcds) * chunk + (int)(blockIdx.x / kXcds);
+  if (tile >= n_tiles) return; // whole workgroup
+  const int ty = tile / P.tiles_x;
+  const int tx = tile - ty * P.tiles_x;
+  const int lane = (int)(threadIdx.x & 63u);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int x = tx * kT2W + lane;
+  const int y_first = P.y_offset + ty * kT2H + wave * kT2Rows; // wave-uniform
+  // Lanes / rows beyond the image recompute the last valid pixel and never store
+  // (all 64 lanes stay active for the wave-wide votes).
+  const int xe = x < P.out_w ? x : P.out_w - 1;
+  const int ns = P.num_samples;
+  const SrcView src = source_view<Interp>(P);
+
+  Rgba acc[kT2Rows];
+#pragma unroll
+  for (int k = 0; k < kT2Rows; ++k) acc[k] = Rgba{f2{0.0f, 0.0f}, f2{0.0f, 0.0f}};
+
+  for (int ssx = 0; ssx < ns; ++ssx) {
+    const ColTerms col = column_terms<OutLens>(P, xe, ssx);
+    for (int ssy = 0; ssy < ns; ++ssy) {
+#pragma unroll
+      for (int k = 0; k < kT2Rows; ++k) {
+        const int yk = y_first + k;
+        const int ye = yk < P.out_h ? yk : P.out_h - 1; // wave-uniform
+        float sx, sy;
+        pixel_source<OutLens, InMode>(P, col, ye, ssy, sx, sy);
+
+        const Rgba s = sample_direct<Interp, Loop>(P, src, sx, sy);
+        acc[k].lo += s.lo; // :334-336
+        acc[k].hi += s.hi;
+      }
+    }
+  }
+
+  // src/reproject.cpp:338-341, then the optional fused post_process (:421-437)
+  if (x < P.out_w) {
+#pragma unroll
+    for (int k = 0; k < kT2Rows; ++k) {
+      const int yk = y_first + k;
+      if (yk < P.out_h) {
+        float4 o = make_float4(acc[k].lo.x * P.normalize, acc[k].lo.y * P.normalize, acc[k].hi.x * P.normalize,
+                               acc[k].hi.y * P.normalize);
+        if (P.has_post) {
+          o.x = tonemap(o.x, P.exposure, P.reinhard);
+          o.y = tonemap(o.y, P.exposure, P.reinhard);
+          o.z = tonemap(o.z, P.exposure, P.reinhard);
+        }
+        reinterpret_cast<float4 *>(P.dst)[(uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x] = o;
+      }
+    }
+  }
+}
+
+// ---- the bicubic window kernel (RGBA float) -----------------------------------------
+//
+// 16 float4 gathers per pixel keep the texture-address path of a CU busy for
+// ~256 cycles per wavefront, as long as the 180 packed cubic instructions keep its
+// SIMD busy — the two do not overlap well.  The taps of neighbouring pixels overlap
+// almost completely, so each wavefront stages the source window of its own 16 x 16
+// output block in LDS once and reads the taps from there (ds_read_b128, 4 LDS
+// cycles each):
+//   * block = 16 x 16 output pixels per wavefront, 4 passes of 16 columns x 4 rows
+//     (square blocks keep the window small under any rotation of the mapping);
+//   * all 256 pixels interior (no clamped / wrapped tap; the common case) ->
+//     window = [min int(sx) - 1, max int(sx) + 2] x [min int(sy) - 1, max int(sy) + 2],
+//     reduced with DPP butterflies, no LDS, no barrier;
+//   * the window rows are fetched with global_load_lds_dwordx4 (LDS-DMA: per-lane
+//     global address, wave-uniform LDS row base + lane * 16; no VGPR round trip),
+//     lanes beyond the window width masked off;
+//   * s_waitcnt vmcnt(0) orders the wavefront's own ds_reads behind its DMA — the
+//     window is private to the wavefront, so there is no workgroup barrier at all;
+//   * a pixel's 16 taps are then ONE LDS address + 3 row increments and the
+//     immediates 0/16/32/48.
+// A block with a border / seam / NaN pixel, or a window larger than the per-wave
+// LDS budget (strong minification), takes sample_direct() per pass instead.
+#if LRP_ABLATE == 5 // diagnostic build: per-phase wave-cycle sums (tools/ablate.sh 5; kbench prints them)
+__device__ unsigned long long g_lrp_stamps[8];
+#define LRP_STAMP(var)                                                                              \
+  unsigned long long var;                                                                           \
+  __builtin_amdgcn_sched_barrier(0);                                                                \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                       \
+  __builtin_amdgcn_sched_barrier(0)
+#define LRP_ACC(i, a, b) st_sum[i] += (b) - (a)
+#else
+#define LRP_STAMP(var)
+#define LRP_ACC(i, a, b)
+#endif
+
+constexpr int kWinCap = 384; // float4 texels per window buffer: 2 buffers x 6 KiB per wavefront -> 13 wavefronts / CU
+constexpr int kBlk = 16;     // output block edge per wavefront
+
+// Source coordinates and window of one 16 x 16 block (4 pixels per lane).
+struct WinBlock {
+  float sx[4], sy[4];
+  int x_lo, y_lo, bw, bh, pitch; // window origin, size and row pitch in texels (wave-uniform)
+  bool staged;                   // taps come from the LDS window (wave-uniform)
+};
+
+// Software pipeline of one wavefront over its strip of `blocks_per_wave` blocks
+// (top to bottom), two LDS window buffers:
+//     A(0); DMA(0)
+//     for g:  A(g+1)                      | DMA(g) in flight under the coordinate math
+//             s_waitcnt vmcnt(0)          | window g has landed
+//             DMA(g+1)                    | in flight under ...
+//             taps + cubics + store of g  | ... the interpolation of block g
+// so the only exposed memory latency is the first window of a strip.
+template <int OutLens, int InMode>
+__global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubic_win_kernel(const KParams P) {
+  constexpr bool Loop = (InMode == kInEquirectLoop);
+  __shared__ float4 s_win[kT2Waves][2][kWinCap];
+
+  const int n_tiles = P.tiles_x * P.tiles_y;
+  const int chunk = (n_tiles + kXcds - 1) / kXcds;
+  const int tile = (int)(blockIdx.x % kXcds) * chunk + (int)(blockIdx.x / kXcds);
+  if (tile >= n_tiles) return; // whole workgroup
+  const int ty = tile / P.tiles_x;
+  const int tx = tile - ty * P.tiles_x;
+  const int lane = (int)(threadIdx.x & 63u);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int G = P.blocks_per_wave;
+  // workgroup tile = 64 x 16G: four strips of G blocks side by side, one per wavefront
+  const int x = tx * (kBlk * kT2Waves) + wave * kBlk + (lane & 15);
+  const int y_lane = P.y_offset + ty * (kBlk * G) + (lane >> 4); // + 16 * g + 4 * pass
+  const int xe = x < P.out_w ? x : P.out_w - 1;
+  const int in_w = P.in_w;
+  const SrcView src = source_view<2>(P);
+  const float4 *__restrict__ src4 = reinterpret_cast<const float4 *>(P.src);
+  float4 *const win0 = s_win[wave][0];
+  const ColTerms col = column_terms<OutLens>(P, xe, 0);
+
+  // phase A of block g: coordinates, interior vote, window box, DMA issue
+  auto coords = [&](int g, WinBlock &b) {
+    int ok = 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yk = y_lane + 16 * g + 4 * k;
+      const int ye = yk < P.out_h ? yk : P.out_h - 1;
+      pixel_source<OutLens, InMode>(P, col, ye, 0, b.sx[k], b.sy[k]);
+      ok &= interior(b.sx[k], 1.0f, src.x_hi, 2.0f) & interior(b.sy[k], 1.0f, src.y_hi, 2.0f);
+    }
+    b.staged = false;
+    b.x_lo = b.y_lo = b.bw = b.bh = b.pitch = 0;
+    if (wave_all(ok != 0)) {
+      // every tap index of the block is int(s) - 1 .. int(s) + 2, unclamped
+      int ix[4], iy[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ix[k] = (int)b.sx[k];
+        iy[k] = (int)b.sy[k];
+      }
+      b.x_lo = wave_extreme<false>(min(min(ix[0], ix[1]), min(ix[2], ix[3]))) - 1;
+      b.y_lo = wave_extreme<false>(min(min(iy[0], iy[1]), min(iy[2], iy[3]))) - 1;
+      const int x_hi = wave_extreme<true>(max(max(ix[0], ix[1]), max(ix[2], ix[3]))) + 2;
+      const int y_hi = wave_extreme<true>(max(max(iy[0], iy[1]), max(iy[2], iy[3]))) + 2;
+      b.bw = x_hi - b.x_lo + 1;
+      b.bh = y_hi - b.y_lo + 1;
+      b.pitch = b.bw | 1; // odd: consecutive window rows start an odd number of 16 B slots apart
+      b.staged = b.bw <= 64 && b.pitch * b.bh <= kWinCap;
+    }
+  };
+  auto issue = [&](int g, const WinBlock &b) {
+    if (b.staged) {
+      // LDS-DMA, one window row per instruction, lanes beyond the width masked off
+      float4 *const win = win0 + (g & 1) * kWinCap;
+      const float4 *gp = src4 + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane));
+      if (lane < b.bw) {
+        for (int r = 0; r < b.bh; ++r)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + (size_t)r * in_w),
+                                           (__attribute__((address_space(3))) void *)(win + r * b.pitch), 16, 0, 0);
+      }
+    }
+  };
+
+#if LRP_ABLATE == 5
+  unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  WinBlock cur, nxt;
+  LRP_STAMP(t_a);
+  coords(0, cur);
+  LRP_STAMP(t_b);
+  issue(0, cur);
+  LRP_STAMP(t_c);
+  LRP_ACC(0, t_a, t_b);
+  LRP_ACC(1, t_b, t_c);
+#pragma unroll 1
+  for (int g = 0; g < G; ++g) {
+    LRP_STAMP(t0);
+    if (g + 1 < G) coords(g + 1, nxt);
+    LRP_STAMP(t1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // window g has landed (also retires block g-1's stores)
+    LRP_STAMP(t2);
+    if (g + 1 < G) issue(g + 1, nxt);
+    LRP_STAMP(t3);
+    LRP_ACC(0, t0, t1);
+    LRP_ACC(2, t1, t2);
+    LRP_ACC(1, t2, t3);
+    const float4 *const win = win0 + (g & 1) * kWinCap;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      Rgba s;
+      if (cur.staged) {
+        const float tx_ = __builtin_truncf(cur.sx[k]), ty_ = __builtin_truncf(cur.sy[k]);
+        const float fx = cur.sx[k] - tx_, fy = cur.sy[k] - ty_;
+        const float4 *t = win + (((int)ty_ - 1 - cur.y_lo) * cur.pitch + ((int)tx_ - 1 - cur.x_lo));
+        const float hfx = 0.5f * fx, hfy = 0.5f * fy;
+        const float4 *t1 = t + cur.pitch, *t2 = t1 + cur.pitch, *t3 = t2 + cur.pitch;
+        const Rgba k0 = cubic4(as_rgba(t[0]), as_rgba(t1[0]), as_rgba(t2[0]), as_rgba(t3[0]), fy, hfy);
+        const Rgba k1 = cubic4(as_rgba(t[1]), as_rgba(t1[1]), as_rgba(t2[1]), as_rgba(t3[1]), fy, hfy);
+        const Rgba k2 = cubic4(as_rgba(t[2]), as_rgba(t1[2]), as_rgba(t2[2]), as_rgba(t3[2]), fy, hfy);
+        const Rgba k3 = cubic4(as_rgba(t[3]), as_rgba(t1[3]), as_rgba(t2[3]), as_rgba(t3[3]), fy, hfy);
+        s = cubic4(k0, k1, k2, k3, fx, hfx);
+      } else {
+        s = sample_direct<2, Loop>(P, src, cur.sx[k], cur.sy[k]);
+      }
+      // num_samples == 1: (0.0f + s) * normalize (src/reproject.cpp:334-341)
+      const f2 zero = f2{0.0f, 0.0f};
+      const f2 lo = (zero + s.lo) * P.normalize, hi = (zero + s.hi) * P.normalize;
+      const int yk = y_lane + 16 * g + 4 * k;
+      if (x < P.out_w && yk < P.out_h) {
+        float4 o = make_float4(lo.x, lo.y, hi.x, hi.y);
+        if (P.has_post) {
+          o.x = tonemap(o.x, P.exposure, P.reinhard);
+          o.y = tonemap(o.y, P.exposure, P.reinhard);
+          o.z = tonemap(o.z, P.exposure, P.reinhard);
+        }
+        reinterpret_cast<float4 *>(P.dst)[(uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x] = o;
+      }
+    }
+    cur = nxt;
+    LRP_STAMP(t4);
+    LRP_ACC(3, t3, t4);
+  }
+#if LRP_ABLATE == 5
+  LRP_STAMP(t_end);
+  LRP_ACC(4, t_a, t_end);
+  if (lane == 0) {
+    for (int i = 0; i < 5; ++i) atomicAdd(&g_lrp_stamps[i], st_sum[i]);
+    atomicAdd(&g_lrp_stamps[7], 1ull);
+  }
+#endif
+}
+
+using TileKernelFn = void (*)(const KParams);
+
+template <int Interp> struct TileKernelTable {
+  static TileKernelFn get(int out_idx, int in_mode) {
+    static const TileKernelFn table[3][4] = {
+        {reproject_tile_kernel<kRect, kInRect, Interp>, reproject_tile_kernel<kRect, kInEquidistant, Interp>,
+         reproject_tile_kernel<kRect, kInEquirect, Interp>, reproject_tile_kernel<kRect, kInEquirectLoop, Interp>},
+        {reproject_tile_kernel<kEquidistant, kInRect, Interp>, reproject_tile_kernel<kEquidistant, kInEquidistant, Interp>,
+         reproject_tile_kernel<kEquidistant, kInEquirect, Interp>,
+         reproject_tile_kernel<kEquidistant, kInEquirectLoop, Interp>},
+        {reproject_tile_kernel<kEquirect, kInRect, Interp>, reproject_tile_kernel<kEquirect, kInEquidistant, Interp>,
+         reproject_tile_kernel<kEquirect, kInEquirect, Interp>,
+         reproject_tile_kernel<kEquirect, kInEquirectLoop, Interp>}};
+    return table[out_idx][in_mode];
+  }
+};
+
+template <int Interp> hipError_t launch_tile_interp(KParams P, int out_idx, int in_mode, hipStream_t stream) {
+  P.tiles_x = (P.out_w + kT2W - 1) / kT2W;
+  const int rows = P.out_h - P.y_offset;
+  P.tiles_y = (rows + kT2H - 1) / kT2H;
+  const int n_tiles = P.tiles_x * P.tiles_y;
+  if (n_tiles <= 0) return hipSuccess;
+  const int chunk = (n_tiles + kXcds - 1) / kXcds;
+  hipLaunchKernelGGL(TileKernelTable<Interp>::get(out_idx, in_mode), dim3((unsigned)(chunk * kXcds)), dim3(kT2Threads), 0,
+                     stream, P);
+  return hipGetLastError();
+}
+
+struct WinKernelTable {
+  static TileKernelFn get(int out_idx, int in_mode) {
+    static const TileKernelFn table[3][4] = {
+        {reproject_bicubic_win_kernel<kRect, kInRect>, reproject_bicubic_win_kernel<kRect, kInEquidistant>,
+         reproject_bicubic_win_kernel<kRect, kInEquirect>, reproject_bicubic_win_kernel<kRect, kInEquirectLoop>},
+        {reproject_bicubic_win_kernel<kEquidistant, kInRect>, reproject_bicubic_win_kernel<kEquidistant, kInEquidistant>,
+         reproject_bicubic_win_kernel<kEquidistant, kInEquirect>,
+         reproject_bicubic_win_kernel<kEquidistant, kInEquirectLoop>},
+        {reproject_bicubic_win_kernel<kEquirect, kInRect>, reproject_bicubic_win_kernel<kEquirect, kInEquidistant>,
+         reproject_bicubic_win_kernel<kEquirect, kInEquirect>, reproject_bicubic_win_kernel<kEquirect, kInEquirectLoop>}};
+    return table[out_idx][in_mode];
+  }
+};
+
+// num_samples must be 1 (the pipeline keeps no accumulator across sub-samples).
+inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, hipStream_t stream) {
+  P.tiles_x = (P.out_w + kBlk * kT2Waves - 1) / (kBlk * kT2Waves);
+  const int rows = P.out_h - P.y_offset;
+  // strips of 4 blocks when that still leaves >= 8 workgroups per CU, else shorter
+  const int row_blocks = (rows + kBlk - 1) / kBlk;
+  int G = 4;
+  while (G > 1 && (long long)P.tiles_x * ((row_blocks + G - 1) / G) < 2048) G >>= 1;
+  P.blocks_per_wave = G;
+  P.tiles_y = (row_blocks + G - 1) / G;
+  const int n_tiles = P.tiles_x * P.tiles_y;
+  if (n_tiles <= 0) return hipSuccess;
+  const int chunk = (n_tiles + kXcds - 1) / kXcds;
+  hipLaunchKernelGGL(WinKernelTable::get(out_idx, in_mode), dim3((unsigned)(chunk * kXcds)), dim3(kT2Threads), 0, stream,
+                     P);
+  return hipGetLastError();
+}
+
+} // namespace lrp

@@ -218,28 +218,37 @@ LRP_HD float atanf_(float x) {
     }
     direct = true;
   } else {
+    // The four argument reductions differ only in numerator and denominator:
+    // select those, then divide once (one IEEE divide per call instead of one
+    // per range; the quotient is the same operation on the same operands).
     const float ax = u2f(ix);
+    float num, den;
     if (ix < 0x3f980000u) {   // |x| < 1.1875
       if (ix < 0x3f300000u) { // 7/16 <= |x| < 11/16
-        x = ((ax + ax) - 1.0f) / (ax + 2.0f);
+        num = (ax + ax) - 1.0f;
+        den = ax + 2.0f;
         hi = atanhi0;
         lo = atanlo0;
       } else { // 11/16 <= |x| < 19/16
-        x = (ax - 1.0f) / (ax + 1.0f);
+        num = ax - 1.0f;
+        den = ax + 1.0f;
         hi = atanhi1;
         lo = atanlo1;
       }
     } else {
       if (ix < 0x401c0000u) { // |x| < 2.4375
-        x = (ax - 1.5f) / (ax * 1.5f + 1.0f);
+        num = ax - 1.5f;
+        den = ax * 1.5f + 1.0f;
         hi = atanhi2;
         lo = atanlo2;
       } else { // 2.4375 <= |x| < 2^25
-        x = -1.0f / ax;
+        num = -1.0f;
+        den = ax;
         hi = atanhi3;
         lo = atanlo3;
       }
     }
+    x = num / den;
   }
   const float z = x * x;
   const float w = z * z;

@@ -12,6 +12,7 @@ enum : int { kRect = 0, kEquidistant = 1, kEquirect = 4 };
 // Input-lens mode: equirectangular sources split into clamped and wrapping
 // (reference LoopHorizontally, src/reproject.cpp:386-394).
 enum : int { kInRect = 0, kInEquidistant = 1, kInEquirect = 2, kInEquirectLoop = 3 };
+constexpr int kXcds = 8; // XCDs (private L2s) of an MI355X; blockIdx % 8 labels the blocks that share one
 
 struct LensP {
   float p[4];          // union payload of LensInfo (see include/lrp.h)
@@ -36,6 +37,17 @@ struct KParams {
   float reinhard;
   int32_t tiles_x, tiles_y; // output tiling of the launch
   int32_t y_offset;         // first output row of this launch (row-band launches)
+  // ---- tile kernel (lrp_kernel_v2.h) only ----------------------------------
+  // Separable output-lens terms, one entry per (column, sub-sample) and per
+  // (row, sub-sample), built by lrp_tables.hip with the same operations the
+  // per-pixel code would execute; null for the equidistant target (not separable).
+  const float *col_tab; // [2][out_w * num_samples]
+  const float *row_tab; // [out_h * num_samples]
+  // Lens constants that depend on the lens only, evaluated once on the host
+  // with the same IEEE binary32 operations (src/reproject.cpp:178,196,251-252,265-266).
+  float in_focal, out_focal;        // equidistant: sensor_width / fov
+  float in_lon_span, in_lat_span;   // equirectangular source
+  int32_t blocks_per_wave;          // window kernel: 16 x 16 blocks per wavefront strip
 };
 
 } // namespace lrp

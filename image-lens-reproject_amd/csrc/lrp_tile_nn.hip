@@ -1,0 +1,8 @@
+// lrp_tile_nn.hip — nearest instantiations of the tile kernel (lrp_kernel_v2.h).
+#include "lrp_kernel_v2.h"
+
+namespace lrp {
+hipError_t launch_tile_nearest(const KParams &P, int out_idx, int in_mode, hipStream_t stream) {
+  return launch_tile_interp<0>(P, out_idx, in_mode, stream);
+}
+} // namespace lrp

@@ -1,0 +1,191 @@
+// kbench.cpp — native kernel bench over the C ABI (include/lrp.h); no Python,
+// no torch.  Times lrp_reproject_device on device-resident synthetic frames with
+// HIP events on the launch stream, prints per-workload kernel time, Gpix/s and
+// the algorithmic-bytes roofline fraction, plus an FNV-1a checksum of the output
+// so two kernel variants (LRP_KERNEL=v1|v2) can be compared bit for bit at full
+// size.
+//
+// Build (tools/build_kbench.sh):
+//   hipcc -O2 -std=c++17 tools/kbench.cpp -Iinclude -L<pkg>/lib -llrp_hip -Wl,-rpath,<pkg>/lib -o tools/kbench
+// Usage: kbench [--size N] [--reps R] [--distinct D] [--channels C] [--ns S] [--sum] [workload ...]
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lrp.h"
+
+#define HIP_OK(x)                                                                                  \
+  do {                                                                                             \
+    hipError_t e_ = (x);                                                                           \
+    if (e_ != hipSuccess) {                                                                        \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__);       \
+      exit(2);                                                                                     \
+    }                                                                                              \
+  } while (0)
+#define LRP_OKAY(x)                                                                                \
+  do {                                                                                             \
+    int s_ = (x);                                                                                  \
+    if (s_ != LRP_OK) {                                                                            \
+      fprintf(stderr, "lrp error %d (%s): %s at %s:%d\n", s_, lrp_strerror(s_), lrp_last_error(), __FILE__, __LINE__); \
+      exit(3);                                                                                     \
+    }                                                                                              \
+  } while (0)
+
+struct Workload {
+  const char *name;
+  const char *in_lens, *out_lens; // "rect" | "eqd" | "eqr" | "eqrp"
+  int interp;
+  int has_rot;
+  float rot_deg[3];
+};
+
+static const Workload kWorkloads[] = {
+    {"eqd_rect_bc", "eqd", "rect", 2, 0, {0, 0, 0}},       // BASELINE configs[1] (equidistant stands in for equisolid)
+    {"eqd_rect_bc_id", "eqd", "rect", 2, 1, {0, 0, 0}},    // same with the CLI's always-present identity matrix
+    {"eqr_rect_bc", "eqr", "rect", 2, 1, {0, 0, 0}},       // north_star roofline case
+    {"eqr_rect_bl", "eqr", "rect", 1, 1, {0, 0, 0}},
+    {"eqr_rect_nn", "eqr", "rect", 0, 1, {0, 0, 0}},       // configs[0] shape
+    {"eqr_eqd_bl_rot", "eqr", "eqd", 1, 1, {30, -15, 5}},  // configs[2]
+    {"rect_eqr_bc", "rect", "eqr", 2, 1, {0, 0, 0}},       // configs[3] shape (without post)
+    {"eqr_rect_bc_rot", "eqr", "rect", 2, 1, {90, 0, 0}},  // configs[4] face
+    {"rect_rect_bc", "rect", "rect", 2, 1, {10, 5, 0}},
+    {"eqd_eqd_bc", "eqd", "eqd", 2, 1, {10, 5, 0}},
+    {"eqr_eqr_bc_rot", "eqr", "eqr", 2, 1, {30, -15, 5}},
+    {"eqd_rect_bl", "eqd", "rect", 1, 0, {0, 0, 0}},
+    {"eqd_rect_nn", "eqd", "rect", 0, 0, {0, 0, 0}},
+};
+
+static void make_lens(lrp_lens *L, const char *kind, int w, int h) {
+  if (!strcmp(kind, "rect"))
+    lrp_lens_rectilinear(L, 18.0f, 36.0f, (float)w, (float)h);
+  else if (!strcmp(kind, "eqd"))
+    lrp_lens_equidistant(L, 3.14159265f);
+  else if (!strcmp(kind, "eqrp"))
+    lrp_lens_equirectangular(L, -1.0f, 1.5f, -0.6f, 0.7f);
+  else
+    lrp_lens_equirectangular_full(L);
+}
+
+static uint64_t fnv1a(const void *p, size_t n) {
+  const uint64_t *q = (const uint64_t *)p;
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n / 8; ++i) {
+    h ^= q[i];
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
+int main(int argc, char **argv) {
+  int size = 4096, reps = 20, distinct = 4, channels = 4, ns = 1, out_size = 0;
+  bool sum = false, post = false;
+  std::vector<std::string> names;
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    auto next = [&]() { return (i + 1 < argc) ? atoi(argv[++i]) : 0; };
+    if (a == "--size") size = next();
+    else if (a == "--out-size") out_size = next();
+    else if (a == "--reps") reps = next();
+    else if (a == "--distinct") distinct = next();
+    else if (a == "--channels") channels = next();
+    else if (a == "--ns") ns = next();
+    else if (a == "--sum") sum = true;
+    else if (a == "--post") post = true;
+    else names.push_back(a);
+  }
+  if (!out_size) out_size = size;
+  if (names.empty())
+    for (const auto &w : kWorkloads) names.push_back(w.name);
+  if (lrp_device_count() < 1) {
+    fprintf(stderr, "no HIP device\n");
+    return 1;
+  }
+  HIP_OK(hipSetDevice(0));
+  hipStream_t stream;
+  HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  const size_t in_elems = (size_t)size * size * channels, out_elems = (size_t)out_size * out_size * channels;
+  std::vector<float *> src(distinct), dst(distinct);
+  for (int i = 0; i < distinct; ++i) {
+    HIP_OK(hipMalloc(&src[i], in_elems * 4));
+    HIP_OK(hipMalloc(&dst[i], out_elems * 4));
+    LRP_OKAY(lrp_synth_fill_device(src[i], size, size, channels, 0x5EED0000u + i, channels == 5 ? 4 : -1, 0, stream));
+  }
+  HIP_OK(hipStreamSynchronize(stream));
+  std::vector<float> host;
+  if (sum) host.resize(out_elems);
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0));
+  HIP_OK(hipEventCreate(&e1));
+  const char *kv = getenv("LRP_KERNEL");
+  printf("# size %d -> %d, C=%d, ns=%d, reps=%d, distinct=%d, LRP_KERNEL=%s\n", size, out_size, channels, ns, reps, distinct,
+         kv ? kv : "(default)");
+  for (const auto &nm : names) {
+    const Workload *W = nullptr;
+    for (const auto &w : kWorkloads)
+      if (nm == w.name) W = &w;
+    if (!W) {
+      fprintf(stderr, "unknown workload %s\n", nm.c_str());
+      continue;
+    }
+    lrp_image in{}, out{};
+    make_lens(&in.lens, W->in_lens, size, size);
+    make_lens(&out.lens, W->out_lens, out_size, out_size);
+    in.width = in.height = size;
+    out.width = out.height = out_size;
+    in.channels = out.channels = channels;
+    float rot[9];
+    const float d2r = 3.14159265358979f / 180.0f;
+    lrp_rotation_matrix(W->rot_deg[0] * d2r, W->rot_deg[1] * d2r, W->rot_deg[2] * d2r, rot);
+    lrp_post pp{2.0f, 4.0f};
+    auto launch = [&](int i) {
+      in.data = src[i % distinct];
+      out.data = dst[i % distinct];
+      LRP_OKAY(lrp_reproject_device(&in, &out, ns, W->interp, W->has_rot ? rot : nullptr, post ? &pp : nullptr, 0, stream));
+    };
+    for (int i = 0; i < 3; ++i) launch(i);
+    HIP_OK(hipStreamSynchronize(stream));
+    float best = 1e30f, total = 0;
+    for (int i = 0; i < reps; ++i) {
+      HIP_OK(hipEventRecord(e0, stream));
+      launch(i);
+      HIP_OK(hipEventRecord(e1, stream));
+      HIP_OK(hipEventSynchronize(e1));
+      float ms;
+      HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+      total += ms;
+      if (ms < best) best = ms;
+    }
+    const double avg_s = total / reps * 1e-3;
+    const double bytes = (double)(in_elems + out_elems) * 4;
+    uint64_t h = 0;
+    if (sum) {
+      launch(0);
+      HIP_OK(hipStreamSynchronize(stream));
+      HIP_OK(hipMemcpy(host.data(), dst[0], out_elems * 4, hipMemcpyDeviceToHost));
+      h = fnv1a(host.data(), out_elems * 4);
+    }
+    printf("%-18s avg %8.1f us  min %8.1f us  %8.2f Gpix/s  %7.1f GB/s algorithmic  frac %.3f", W->name, avg_s * 1e6,
+           best * 1e3, (double)out_size * out_size / avg_s / 1e9, bytes / avg_s / 1e9, bytes / avg_s / 8e12);
+    if (sum) printf("  fnv %016llx", (unsigned long long)h);
+    printf("\n");
+    // diagnostic builds (tools/ablate.sh 5) export per-phase wave-cycle sums
+    typedef int (*stamps_fn)(unsigned long long *, int);
+    if (stamps_fn fn = (stamps_fn)dlsym(RTLD_DEFAULT, "lrp_debug_read_stamps")) {
+      unsigned long long st[8];
+      HIP_OK(hipDeviceSynchronize());
+      if (fn(st, 1) == 0 && st[7] > 0) {
+        printf("    stamps per wave (cycles): coords %.0f  dma-issue %.0f  dma-wait %.0f  taps+cubic+store %.0f  total %.0f  (waves %llu)\n",
+               (double)st[0] / st[7], (double)st[1] / st[7], (double)st[2] / st[7], (double)st[3] / st[7],
+               (double)st[4] / st[7], st[7]);
+      }
+    }
+    fflush(stdout);
+  }
+  return 0;
+}
