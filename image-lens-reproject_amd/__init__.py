@@ -196,6 +196,15 @@ def device_count():
     return _native.load().lrp_device_count()
 
 
+PIXEL_KERNEL, TILE_KERNEL, WINDOW_KERNEL = 0, 1, 2
+
+
+def debug_kernel(choice=-1):
+    """lrp_debug_kernel: select the HIP kernel family (0 pixel, 1 tile, 2 tile + LDS-window
+    bicubic; all produce the same bits); returns the previous choice.  -1 only queries."""
+    return _native.load().lrp_debug_kernel(int(choice))
+
+
 def reproject(in_image, out_image, num_samples, interpolation, rotation_matrix=None, post=None, device=None,
               stream=None):
     """reproject::reproject (src/reproject.cpp:405-419).  `post=(exposure, reinhard)`

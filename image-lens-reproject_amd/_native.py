@@ -48,6 +48,8 @@ _FLOATP = ctypes.c_void_p  # float* passed as raw address (host or device)
 SYMBOLS = {
     "lrp_abi_version": (ctypes.c_int, []),
     "lrp_device_count": (ctypes.c_int, []),
+    "lrp_debug_kernel": (ctypes.c_int, [ctypes.c_int]),
+    "lrp_release_cached_tables": (None, []),
     "lrp_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "lrp_last_error": (ctypes.c_char_p, []),
     "lrp_reproject": (

@@ -4,6 +4,7 @@
 // lrp_kernels_*.hip / lrp_aux_kernels.hip translation units.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -157,16 +158,15 @@ lrp::KParams make_params(const lrp_image *in, const lrp_image *out, int num_samp
 // LRP_KERNEL=pixel is set in the environment (A/B checks) — takes the
 // one-pixel-per-lane kernel (lrp_kernel_impl.h).  Both are HIP; there is no CPU path.
 // 0 = pixel kernel, 1 = tile kernel everywhere, 2 (default) = tile kernel with the
-// LDS-window kernel for bicubic.
-int kernel_choice() {
-  static const int choice = [] {
-    const char *v = std::getenv("LRP_KERNEL");
-    if (v && std::strcmp(v, "pixel") == 0) return 0;
-    if (v && std::strcmp(v, "tile") == 0) return 1;
-    return 2;
-  }();
-  return choice;
-}
+// LDS-window kernel for bicubic.  Initialised from LRP_KERNEL=pixel|tile, changed
+// at run time by lrp_debug_kernel().
+std::atomic<int> g_kernel_choice{[] {
+  const char *v = std::getenv("LRP_KERNEL");
+  if (v && std::strcmp(v, "pixel") == 0) return 0;
+  if (v && std::strcmp(v, "tile") == 0) return 1;
+  return 2;
+}()};
+int kernel_choice() { return g_kernel_choice.load(std::memory_order_relaxed); }
 
 int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int interpolation,
                       const float *rotation, const lrp_post *post, int device, hipStream_t stream) {
@@ -254,6 +254,13 @@ struct lrp_context {
 extern "C" {
 
 int lrp_abi_version(void) { return LRP_ABI_VERSION; }
+
+int lrp_debug_kernel(int choice) {
+  if (choice < 0 || choice > 2) return kernel_choice();
+  return g_kernel_choice.exchange(choice, std::memory_order_relaxed);
+}
+
+void lrp_release_cached_tables(void) { lrp::release_output_tables(); }
 
 int lrp_device_count(void) { return device_count_cached(); }
 

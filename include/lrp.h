@@ -107,6 +107,17 @@ const char *lrp_strerror(int status);
 /* Detail of the calling thread's last failure (HIP error string etc.), "" if none. */
 const char *lrp_last_error(void);
 
+/* Three HIP kernel families compute the same bits: 0 = one pixel per lane
+ * (any channel count), 1 = tile kernel (RGBA), 2 = tile kernel + LDS-window
+ * bicubic (default; the library picks the pixel kernel by itself where the others
+ * do not apply).  Testing / A-B knob: sets the family for subsequent calls of all
+ * threads and returns the previous one; an out-of-range value only queries.
+ * The environment variable LRP_KERNEL=pixel|tile sets the initial value. */
+int lrp_debug_kernel(int choice);
+/* Frees the cached per-output-lens tables of every device (after synchronising
+ * them).  Optional: the cache is bounded and reused across calls. */
+void lrp_release_cached_tables(void);
+
 /* ---- one image, host buffers (the reference's calling convention) ---------- */
 
 /* Drop-in for reproject::reproject (src/reproject.cpp:405-419) with in->data and
@@ -125,8 +136,11 @@ int lrp_post_process(lrp_image *img, float exposure, float reinhard, int device)
 
 /* Same operation with in->data / out->data being device pointers on `device`.
  * Asynchronous: enqueues on `stream` (a hipStream_t, NULL = default stream) and
- * returns; the caller synchronises.  No allocation, no host sync: capturable
- * into a hipGraph. */
+ * returns; the caller synchronises.  The first call with a new (output lens,
+ * output size, num_samples) builds that lens's per-column / per-row tables
+ * (one small allocation + a synchronous 2-microsecond kernel, cached afterwards);
+ * every later call neither allocates nor synchronises and is capturable into a
+ * hipGraph. */
 int lrp_reproject_device(const lrp_image *in, lrp_image *out, int num_samples, int interpolation,
                          const float *rotation, const lrp_post *post, int device, void *stream);
 

@@ -149,3 +149,25 @@ def synth_frame(width, height, channels, seed, depth_channel=-1):
     a = np.empty((height, width, channels), dtype=np.float32)
     lib().lrpo_synth_fill(a.ctypes.data, width, height, channels, seed & 0xFFFFFFFF, depth_channel)
     return a
+
+
+def reproject_rows(in_lens, src, out_lens, out_w, out_h, num_samples, interpolation, rotation, rows):
+    """Oracle output rows `rows` of the (out_h, out_w) image: {y: (out_w, C) array}.
+    Rows are independent in the reference loop (src/reproject.cpp:284), so this is
+    the full-size oracle on a bounded sample."""
+    L = lib()
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    h, w, c = src.shape
+    res = {}
+    keep, rp = _rot(rotation)
+    cin = _image(in_lens, w, h, c, src)
+    for y in rows:
+        # a one-row buffer placed so that row y of the virtual image lands in it
+        row = np.full((1, out_w, c), np.float32(-12345.0), dtype=np.float32)
+        cout = _image(out_lens, out_w, out_h, c, None)
+        cout.data = row.ctypes.data - y * out_w * c * 4
+        rc = L.lrpo_reproject_rows(ctypes.byref(cin), ctypes.byref(cout), num_samples, int(interpolation), rp, y, y + 1)
+        if rc != 0:
+            raise OracleError(rc)
+        res[y] = row[0]
+    return res
