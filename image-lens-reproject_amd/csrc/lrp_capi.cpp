@@ -175,7 +175,8 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
   const int oi = out_lens_index(out->lens.type);
   const int im = in_lens_mode(in->lens);
   hipError_t e;
-  bool tile = kernel_choice() != 0 && out->channels == 4 && in->width <= 65535 && in->height <= 32767 &&
+  const bool tile_channels = out->channels >= 3 && out->channels <= 5;
+  bool tile = kernel_choice() != 0 && tile_channels && in->width <= 65535 && in->height <= 32767 &&
               (long long)out->width * num_samples < (1ll << 30) && (long long)out->height * num_samples < (1ll << 30);
   if (tile && out->lens.type != LRP_FISHEYE_EQUIDISTANT) {
     // separable output-lens terms (cached per device / lens / size / num_samples)
@@ -193,7 +194,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
       e = lrp::launch_tile_nearest(P, oi, im, stream);
     else if (interpolation == LRP_BILINEAR)
       e = lrp::launch_tile_bilinear(P, oi, im, stream);
-    else if (kernel_choice() == 2 && num_samples == 1)
+    else if (kernel_choice() == 2 && num_samples == 1 && out->channels == 4)
       e = lrp::launch_win_bicubic(P, oi, im, stream);
     else
       e = lrp::launch_tile_bicubic(P, oi, im, stream);

@@ -42,7 +42,7 @@
 #define LRP_TILE_MINWAVES 1 // __launch_bounds__ waves per SIMD of the tile kernel
 #endif
 #ifndef LRP_WIN_MINWAVES
-#define LRP_WIN_MINWAVES 1 // __launch_bounds__ waves per SIMD of the window kernel
+#define LRP_WIN_MINWAVES 4 // __launch_bounds__ waves per SIMD of the window kernel (<= 128 VGPRs)
 #endif
 #ifndef LRP_TILE_ROWS
 #define LRP_TILE_ROWS 4
@@ -139,15 +139,26 @@ __device__ __forceinline__ void bicubic_indices(float sx, float sy, int w, int h
   ys[3] = clamp_index(trunc_x86(sy + 2.0f), h - 1);
 }
 
-// ---- bicubic on channel pairs ---------------------------------------------------
-// An RGBA texel is two register pairs (r,g) and (b,a); every Catmull-Rom step is
-// one packed instruction per pair (v_pk_mul_f32 / v_pk_add_f32 round each half
-// exactly like the scalar instruction), with the weights broadcast.
+// ---- texels as channel pairs -------------------------------------------------------
+// A texel of CH = 3, 4 or 5 channels is held as register pairs (c0,c1), (c2,c3)
+// plus a single (c2 for RGB, c4 for RGBAZ); every interpolation step is one packed
+// instruction per pair (v_pk_mul_f32 / v_pk_add_f32 round each half exactly like
+// the scalar instruction) plus a scalar one for the odd channel, weights broadcast.
 typedef float f2 __attribute__((ext_vector_type(2)));
-struct Rgba {
-  f2 lo, hi;
+template <int CH> struct Px {
+  f2 lo; // channels 0, 1
+  f2 hi; // channels 2, 3 (CH >= 4)
+  float e; // channel 2 (CH == 3) or 4 (CH == 5)
 };
-__device__ __forceinline__ Rgba as_rgba(const float4 v) { return Rgba{f2{v.x, v.y}, f2{v.z, v.w}}; }
+using Rgba = Px<4>;
+__device__ __forceinline__ Rgba as_rgba(const float4 v) { return Rgba{f2{v.x, v.y}, f2{v.z, v.w}, 0.0f}; }
+
+template <int CH> __device__ __forceinline__ Px<CH> px_zero() { return Px<CH>{f2{0.0f, 0.0f}, f2{0.0f, 0.0f}, 0.0f}; }
+template <int CH> __device__ __forceinline__ void px_add(Px<CH> &a, const Px<CH> &b) {
+  a.lo += b.lo;
+  if constexpr (CH >= 4) a.hi += b.hi;
+  if constexpr (CH & 1) a.e += b.e;
+}
 
 // cubicInterpolate (src/reproject.cpp:92-98), same association order as catmull_rom().
 __device__ __forceinline__ f2 catmull_rom2(const f2 a, const f2 b, const f2 c, const f2 d, float t, float half_t) {
@@ -156,42 +167,61 @@ __device__ __forceinline__ f2 catmull_rom2(const f2 a, const f2 b, const f2 c, c
   const f2 outer = (c - a) + t * mid;
   return b + half_t * outer;
 }
+template <int CH>
+__device__ __forceinline__ Px<CH> cubic_px(const Px<CH> &a, const Px<CH> &b, const Px<CH> &c, const Px<CH> &d, float t,
+                                           float half_t) {
+  Px<CH> r = px_zero<CH>();
+  r.lo = catmull_rom2(a.lo, b.lo, c.lo, d.lo, t, half_t);
+  if constexpr (CH >= 4) r.hi = catmull_rom2(a.hi, b.hi, c.hi, d.hi, t, half_t);
+  if constexpr (CH & 1) r.e = catmull_rom(a.e, b.e, c.e, d.e, t, half_t);
+  return r;
+}
 __device__ __forceinline__ Rgba cubic4(const Rgba a, const Rgba b, const Rgba c, const Rgba d, float t, float half_t) {
-  return Rgba{catmull_rom2(a.lo, b.lo, c.lo, d.lo, t, half_t), catmull_rom2(a.hi, b.hi, c.hi, d.hi, t, half_t)};
+  return cubic_px<4>(a, b, c, d, t, half_t);
 }
 
 // ---- source texels through a buffer descriptor ------------------------------------
-// buffer_load_dwordx4 takes a 32-bit VGPR byte offset, an SGPR byte offset and a
-// 12-bit immediate: the 16 taps of an interior bicubic pixel are ONE VGPR offset
-// (first tap), four SGPR row offsets (0, W*16, 2W*16, 3W*16 — computed once per
-// kernel) and the immediates 0/16/32/48.  No per-tap address arithmetic at all.
+// buffer_load takes a 32-bit VGPR byte offset, an SGPR byte offset and a 12-bit
+// immediate: the 16 taps of an interior bicubic pixel are ONE VGPR offset (first
+// tap), four SGPR row offsets (0, pitch, 2 pitch, 3 pitch — computed once per
+// kernel) and the immediates 0, T, 2T, 3T (T = texel bytes).  No per-tap address
+// arithmetic at all.  RGB texels are one dwordx3, RGBAZ a dwordx4 + a dword.
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ Rgba texel_at(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
-  const u4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
-  return Rgba{f2{u2f(q.x), u2f(q.y)}, f2{u2f(q.z), u2f(q.w)}};
+typedef unsigned int u3 __attribute__((ext_vector_type(3)));
+template <int CH>
+__device__ __forceinline__ Px<CH> texel_at(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+  if constexpr (CH == 3) {
+    const u3 q = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)voff, (int)soff, 0);
+    return Px<3>{f2{u2f(q.x), u2f(q.y)}, f2{0.0f, 0.0f}, u2f(q.z)};
+  } else {
+    const u4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
+    float e = 0.0f;
+    if constexpr (CH == 5) e = u2f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(voff + 16u), (int)soff, 0));
+    return Px<CH>{f2{u2f(q.x), u2f(q.y)}, f2{u2f(q.z), u2f(q.w)}, e};
+  }
 }
 
 // bicubicInterpolate (src/reproject.cpp:100-107): vertical cubic per tap column,
 // then the horizontal one.  Taps: byte offset v[i] (column part, VGPR) + r[j]
 // (row part; SGPR in the interior path).
-template <bool ScalarRows>
-__device__ __forceinline__ Rgba bicubic_taps(__amdgpu_buffer_rsrc_t rsrc, uint32_t v0, uint32_t v1, uint32_t v2,
-                                             uint32_t v3, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, float fx,
-                                             float fy) {
+template <int CH, bool ScalarRows>
+__device__ __forceinline__ Px<CH> bicubic_taps(__amdgpu_buffer_rsrc_t rsrc, uint32_t v0, uint32_t v1, uint32_t v2,
+                                               uint32_t v3, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, float fx,
+                                               float fy) {
   // ScalarRows: r[j] are wave-uniform and ride in the instruction's SGPR offset;
   // otherwise they are per-lane and are added into the VGPR offset.
   auto tap = [&](uint32_t v, uint32_t r) {
     if constexpr (ScalarRows)
-      return texel_at(rsrc, v, r);
+      return texel_at<CH>(rsrc, v, r);
     else
-      return texel_at(rsrc, v + r, 0u);
+      return texel_at<CH>(rsrc, v + r, 0u);
   };
   const float hfx = 0.5f * fx, hfy = 0.5f * fy;
-  const Rgba k0 = cubic4(tap(v0, r0), tap(v0, r1), tap(v0, r2), tap(v0, r3), fy, hfy);
-  const Rgba k1 = cubic4(tap(v1, r0), tap(v1, r1), tap(v1, r2), tap(v1, r3), fy, hfy);
-  const Rgba k2 = cubic4(tap(v2, r0), tap(v2, r1), tap(v2, r2), tap(v2, r3), fy, hfy);
-  const Rgba k3 = cubic4(tap(v3, r0), tap(v3, r1), tap(v3, r2), tap(v3, r3), fy, hfy);
-  return cubic4(k0, k1, k2, k3, fx, hfx);
+  const Px<CH> k0 = cubic_px<CH>(tap(v0, r0), tap(v0, r1), tap(v0, r2), tap(v0, r3), fy, hfy);
+  const Px<CH> k1 = cubic_px<CH>(tap(v1, r0), tap(v1, r1), tap(v1, r2), tap(v1, r3), fy, hfy);
+  const Px<CH> k2 = cubic_px<CH>(tap(v2, r0), tap(v2, r1), tap(v2, r2), tap(v2, r3), fy, hfy);
+  const Px<CH> k3 = cubic_px<CH>(tap(v3, r0), tap(v3, r1), tap(v3, r2), tap(v3, r3), fy, hfy);
+  return cubic_px<CH>(k0, k1, k2, k3, fx, hfx);
 }
 
 // Interior test shared by the bilinear and bicubic fast paths: with
@@ -263,9 +293,9 @@ struct SrcView {
   uint32_t row_bytes;
   float x_hi, y_hi; // interior bounds of the fast paths: extent - reach
 };
-template <int Interp> __device__ __forceinline__ SrcView source_view(const KParams &P) {
+template <int Interp, int CH> __device__ __forceinline__ SrcView source_view(const KParams &P) {
   SrcView v;
-  v.row_bytes = (uint32_t)P.in_w * 16u;
+  v.row_bytes = (uint32_t)P.in_w * (4u * CH);
   v.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.src), 0, (int)(v.row_bytes * (uint32_t)P.in_h),
                                              0x00020000);
   v.x_hi = (float)(P.in_w - (Interp == 2 ? 2 : 1));
@@ -275,58 +305,125 @@ template <int Interp> __device__ __forceinline__ SrcView source_view(const KPara
 
 // sample_nearest / sample_bilinear / sample_bicubic (src/reproject.cpp:39-148).
 // All 64 lanes must be active (wave-wide vote).
-template <int Interp, bool Loop>
-__device__ __forceinline__ Rgba sample_direct(const KParams &P, const SrcView &src, float sx, float sy) {
+template <int Interp, bool Loop, int CH>
+__device__ __forceinline__ Px<CH> sample_direct(const KParams &P, const SrcView &src, float sx, float sy) {
+  constexpr uint32_t T = 4u * CH; // texel bytes
   const int in_w = P.in_w, in_h = P.in_h;
   const uint32_t row_bytes = src.row_bytes;
   const __amdgpu_buffer_rsrc_t rsrc = src.rsrc;
   const float x_hi = src.x_hi, y_hi = src.y_hi;
-  Rgba s;
+  Px<CH> s;
   if constexpr (Interp == 2) {
     if (wave_all((interior(sx, 1.0f, x_hi, 2.0f) & interior(sy, 1.0f, y_hi, 2.0f)) != 0)) {
       // every lane: 4 consecutive columns x 4 consecutive rows, nothing clamped
       // (src/reproject.cpp:114-131 reduce to int(s) - 1 .. int(s) + 2, f = s - int(s))
       const float tx_ = __builtin_truncf(sx), ty_ = __builtin_truncf(sy);
       const float fx = sx - tx_, fy = sy - ty_;
-      const uint32_t v0 = __umul24((uint32_t)((int)ty_ - 1), row_bytes) + (uint32_t)((int)tx_ - 1) * 16u;
-      s = bicubic_taps<true>(rsrc, v0, v0 + 16u, v0 + 32u, v0 + 48u, 0u, row_bytes, 2u * row_bytes,
+      const uint32_t v0 = __umul24((uint32_t)((int)ty_ - 1), row_bytes) + (uint32_t)((int)tx_ - 1) * T;
+      s = bicubic_taps<CH, true>(rsrc, v0, v0 + T, v0 + 2u * T, v0 + 3u * T, 0u, row_bytes, 2u * row_bytes,
                                  3u * row_bytes, fx, fy);
     } else {
       int xs[4], ys[4];
       bicubic_indices<Loop>(sx, sy, in_w, in_h, xs, ys);
       const float fx = unit_clamp(sx - (float)xs[1]); // :130-131
       const float fy = unit_clamp(sy - (float)ys[1]);
-      s = bicubic_taps<false>(rsrc, (uint32_t)xs[0] * 16u, (uint32_t)xs[1] * 16u, (uint32_t)xs[2] * 16u,
-                                 (uint32_t)xs[3] * 16u, (uint32_t)ys[0] * row_bytes, (uint32_t)ys[1] * row_bytes,
-                                 (uint32_t)ys[2] * row_bytes, (uint32_t)ys[3] * row_bytes, fx, fy);
+      const float hfx = 0.5f * fx, hfy = 0.5f * fy;
+      // Out-of-view pixels clamp all four tap columns (or rows) to one border index:
+      // the four vertical cubics then have identical inputs, hence identical results,
+      // and are evaluated once (4 or 1 loads instead of 16 scattered border gathers;
+      // this is most of a rectilinear -> equirectangular frame).  Wave-uniform votes.
+      const bool one_col = wave_all((xs[0] == xs[1]) & (xs[1] == xs[2]) & (xs[2] == xs[3]));
+      const bool one_row = wave_all(ys[0] == ys[3]); // rows are clamped, never wrapped: monotone
+      const uint32_t c0 = (uint32_t)xs[0] * T, r0 = (uint32_t)ys[0] * row_bytes;
+      if (one_col && one_row) {
+        const Px<CH> t = texel_at<CH>(rsrc, c0 + r0, 0u);
+        const Px<CH> k = cubic_px<CH>(t, t, t, t, fy, hfy);
+        s = cubic_px<CH>(k, k, k, k, fx, hfx);
+      } else if (one_col) {
+        const Px<CH> k = cubic_px<CH>(texel_at<CH>(rsrc, c0 + r0, 0u), texel_at<CH>(rsrc, c0 + (uint32_t)ys[1] * row_bytes, 0u),
+                                      texel_at<CH>(rsrc, c0 + (uint32_t)ys[2] * row_bytes, 0u),
+                                      texel_at<CH>(rsrc, c0 + (uint32_t)ys[3] * row_bytes, 0u), fy, hfy);
+        s = cubic_px<CH>(k, k, k, k, fx, hfx);
+      } else if (one_row) {
+        const Px<CH> t0 = texel_at<CH>(rsrc, c0 + r0, 0u), t1 = texel_at<CH>(rsrc, (uint32_t)xs[1] * T + r0, 0u);
+        const Px<CH> t2 = texel_at<CH>(rsrc, (uint32_t)xs[2] * T + r0, 0u), t3 = texel_at<CH>(rsrc, (uint32_t)xs[3] * T + r0, 0u);
+        s = cubic_px<CH>(cubic_px<CH>(t0, t0, t0, t0, fy, hfy), cubic_px<CH>(t1, t1, t1, t1, fy, hfy),
+                         cubic_px<CH>(t2, t2, t2, t2, fy, hfy), cubic_px<CH>(t3, t3, t3, t3, fy, hfy), fx, hfx);
+      } else {
+        s = bicubic_taps<CH, false>(rsrc, c0, (uint32_t)xs[1] * T, (uint32_t)xs[2] * T, (uint32_t)xs[3] * T, r0,
+                                    (uint32_t)ys[1] * row_bytes, (uint32_t)ys[2] * row_bytes,
+                                    (uint32_t)ys[3] * row_bytes, fx, fy);
+      }
     }
   } else if constexpr (Interp == 1) {
+    // sample_bilinear (src/reproject.cpp:55-90); the interior vote reduces the
+    // indices to lx = int(sx), ux = lx + 1, fx = sx - lx
+    uint32_t o_ll, o_lu, o_ul, o_uu;
+    float fx, fy;
     if (wave_all((interior(sx, 0.0f, x_hi, 1.0f) & interior(sy, 0.0f, y_hi, 1.0f)) != 0)) {
-      // src/reproject.cpp:60-88 with lx = int(sx), ux = lx + 1, fx = sx - lx
       const float tx_ = __builtin_truncf(sx), ty_ = __builtin_truncf(sy);
-      const float fx = sx - tx_, fy = sy - ty_;
-      const float cfx = 1.0f - fx, cfy = 1.0f - fy;
-      const uint32_t v0 = __umul24((uint32_t)(int)ty_, row_bytes) + (uint32_t)(int)tx_ * 16u;
-      const Rgba ll = texel_at(rsrc, v0, 0u), lu = texel_at(rsrc, v0 + 16u, 0u);
-      const Rgba ul = texel_at(rsrc, v0, row_bytes), uu = texel_at(rsrc, v0 + 16u, row_bytes);
-      const f2 lo_l = fx * lu.lo + cfx * ll.lo, lo_h = fx * lu.hi + cfx * ll.hi; // :83-84
-      const f2 hi_l = fx * uu.lo + cfx * ul.lo, hi_h = fx * uu.hi + cfx * ul.hi;
-      s = Rgba{fy * hi_l + cfy * lo_l, fy * hi_h + cfy * lo_h}; // :87
+      fx = sx - tx_;
+      fy = sy - ty_;
+      o_ll = __umul24((uint32_t)(int)ty_, row_bytes) + (uint32_t)(int)tx_ * T;
+      o_lu = o_ll + T;
+      o_ul = o_ll + row_bytes;
+      o_uu = o_ul + T;
     } else {
-      const Texel<4> t = sample_bilinear<4, Loop>(P, sx, sy);
-      s = Rgba{f2{t.v[0], t.v[1]}, f2{t.v[2], t.v[3]}};
+      const int lx = column<Loop>(trunc_x86(sx), in_w), ux = column<Loop>(trunc_x86(sx + 1.0f), in_w);
+      const int ly = clamp_index(trunc_x86(sy), in_h - 1), uy = clamp_index(trunc_x86(sy + 1.0f), in_h - 1);
+      fx = unit_clamp(sx - (float)lx); // :70-71
+      fy = unit_clamp(sy - (float)ly);
+      const uint32_t rl = (uint32_t)ly * row_bytes, ru = (uint32_t)uy * row_bytes;
+      o_ll = rl + (uint32_t)lx * T;
+      o_lu = rl + (uint32_t)ux * T;
+      o_ul = ru + (uint32_t)lx * T;
+      o_uu = ru + (uint32_t)ux * T;
     }
+    const float cfx = 1.0f - fx, cfy = 1.0f - fy;
+    const Px<CH> ll = texel_at<CH>(rsrc, o_ll, 0u), lu = texel_at<CH>(rsrc, o_lu, 0u);
+    const Px<CH> ul = texel_at<CH>(rsrc, o_ul, 0u), uu = texel_at<CH>(rsrc, o_uu, 0u);
+    s = px_zero<CH>();
+    // l = fx*lu + cfx*ll; u = fx*uu + cfx*ul; r = fy*u + cfy*l  (:83-88)
+    s.lo = fy * (fx * uu.lo + cfx * ul.lo) + cfy * (fx * lu.lo + cfx * ll.lo);
+    if constexpr (CH >= 4) s.hi = fy * (fx * uu.hi + cfx * ul.hi) + cfy * (fx * lu.hi + cfx * ll.hi);
+    if constexpr (CH & 1) s.e = fy * (fx * uu.e + cfx * ul.e) + cfy * (fx * lu.e + cfx * ll.e);
   } else {
     // sample_nearest (src/reproject.cpp:39-53)
     const int lx = column<Loop>(trunc_x86(sx + 0.5f), in_w);
     const int ly = clamp_index(trunc_x86(sy + 0.5f), in_h - 1);
-    s = texel_at(rsrc, __umul24((uint32_t)ly, row_bytes) + (uint32_t)lx * 16u, 0u);
+    s = texel_at<CH>(rsrc, __umul24((uint32_t)ly, row_bytes) + (uint32_t)lx * T, 0u);
   }
   return s;
 }
 
-// ---- the tile kernel (RGBA float) ------------------------------------------------
-template <int OutLens, int InMode, int Interp>
+// src/reproject.cpp:338-341 + optional fused post_process (:421-437), one pixel.
+template <int CH>
+__device__ __forceinline__ void store_px(const KParams &P, uint32_t pixel_index, Px<CH> a) {
+  const float n = P.normalize;
+  float c[5] = {a.lo.x * n, a.lo.y * n, (CH == 3 ? a.e : a.hi.x) * n, a.hi.y * n, a.e * n};
+  if (P.has_post) {
+    c[0] = tonemap(c[0], P.exposure, P.reinhard);
+    c[1] = tonemap(c[1], P.exposure, P.reinhard);
+    c[2] = tonemap(c[2], P.exposure, P.reinhard);
+  }
+  float *d = P.dst + (size_t)pixel_index * CH;
+  if constexpr (CH == 4) {
+    *reinterpret_cast<float4 *>(d) = make_float4(c[0], c[1], c[2], c[3]);
+  } else if constexpr (CH == 3) {
+    d[0] = c[0];
+    d[1] = c[1];
+    d[2] = c[2];
+  } else {
+    d[0] = c[0];
+    d[1] = c[1];
+    d[2] = c[2];
+    d[3] = c[3];
+    d[4] = c[4];
+  }
+}
+
+// ---- the tile kernel (RGB / RGBA / RGBAZ float) ----------------------------------
+template <int OutLens, int InMode, int Interp, int CH>
 __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_kernel(const KParams P) {
   constexpr bool Loop = (InMode == kInEquirectLoop);
 
@@ -344,11 +441,11 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
   // (all 64 lanes stay active for the wave-wide votes).
   const int xe = x < P.out_w ? x : P.out_w - 1;
   const int ns = P.num_samples;
-  const SrcView src = source_view<Interp>(P);
+  const SrcView src = source_view<Interp, CH>(P);
 
-  Rgba acc[kT2Rows];
+  Px<CH> acc[kT2Rows];
 #pragma unroll
-  for (int k = 0; k < kT2Rows; ++k) acc[k] = Rgba{f2{0.0f, 0.0f}, f2{0.0f, 0.0f}};
+  for (int k = 0; k < kT2Rows; ++k) acc[k] = px_zero<CH>();
 
   for (int ssx = 0; ssx < ns; ++ssx) {
     const ColTerms col = column_terms<OutLens>(P, xe, ssx);
@@ -359,29 +456,17 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
         const int ye = yk < P.out_h ? yk : P.out_h - 1; // wave-uniform
         float sx, sy;
         pixel_source<OutLens, InMode>(P, col, ye, ssy, sx, sy);
-
-        const Rgba s = sample_direct<Interp, Loop>(P, src, sx, sy);
-        acc[k].lo += s.lo; // :334-336
-        acc[k].hi += s.hi;
+        const Px<CH> s = sample_direct<Interp, Loop, CH>(P, src, sx, sy);
+        px_add<CH>(acc[k], s); // :334-336
       }
     }
   }
 
-  // src/reproject.cpp:338-341, then the optional fused post_process (:421-437)
   if (x < P.out_w) {
 #pragma unroll
     for (int k = 0; k < kT2Rows; ++k) {
       const int yk = y_first + k;
-      if (yk < P.out_h) {
-        float4 o = make_float4(acc[k].lo.x * P.normalize, acc[k].lo.y * P.normalize, acc[k].hi.x * P.normalize,
-                               acc[k].hi.y * P.normalize);
-        if (P.has_post) {
-          o.x = tonemap(o.x, P.exposure, P.reinhard);
-          o.y = tonemap(o.y, P.exposure, P.reinhard);
-          o.z = tonemap(o.z, P.exposure, P.reinhard);
-        }
-        reinterpret_cast<float4 *>(P.dst)[(uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x] = o;
-      }
+      if (yk < P.out_h) store_px<CH>(P, (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x, acc[k]);
     }
   }
 }
@@ -415,13 +500,23 @@ __device__ unsigned long long g_lrp_stamps[8];
   __builtin_amdgcn_sched_barrier(0);                                                                \
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                       \
   __builtin_amdgcn_sched_barrier(0)
-#define LRP_ACC(i, a, b) st_sum[i] += (b) - (a)
+#define LRP_ACC(i, a, b) st_sum##i += (b) - (a)
 #else
 #define LRP_STAMP(var)
 #define LRP_ACC(i, a, b)
 #endif
 
-constexpr int kWinCap = 384; // float4 texels per window buffer: 2 buffers x 6 KiB per wavefront -> 13 wavefronts / CU
+#ifndef LRP_WIN_CAP
+#define LRP_WIN_CAP 640
+#endif
+#ifndef LRP_WIN_STRIP
+#define LRP_WIN_STRIP 4
+#endif
+#ifndef LRP_WIN_BUFFERS
+#define LRP_WIN_BUFFERS 1
+#endif
+constexpr int kWinBuffers = LRP_WIN_BUFFERS; // 2: DMA of block g+1 under the cubics of block g; 1: under its own coordinates only
+constexpr int kWinCap = LRP_WIN_CAP; // float4 texels per window buffer: 10 KiB per wavefront, 40 KiB per workgroup -> 4 workgroups / CU
 constexpr int kBlk = 16;     // output block edge per wavefront
 
 // Source coordinates and window of one 16 x 16 block (4 pixels per lane).
@@ -431,18 +526,19 @@ struct WinBlock {
   bool staged;                   // taps come from the LDS window (wave-uniform)
 };
 
-// Software pipeline of one wavefront over its strip of `blocks_per_wave` blocks
-// (top to bottom), two LDS window buffers:
+// One wavefront walks its strip of `blocks_per_wave` blocks top to bottom:
 //     A(0); DMA(0)
 //     for g:  A(g+1)                      | DMA(g) in flight under the coordinate math
 //             s_waitcnt vmcnt(0)          | window g has landed
-//             DMA(g+1)                    | in flight under ...
-//             taps + cubics + store of g  | ... the interpolation of block g
-// so the only exposed memory latency is the first window of a strip.
+//             taps + cubics + store of g
+//             DMA(g+1)                    | every tap of block g has been read
+// (kWinBuffers == 2 issues DMA(g+1) before the cubics of block g instead; measured
+// equal, and one 10 KiB buffer per wavefront admits 1:1 and rotated mappings at
+// 4 wavefronts per SIMD, which is worth 5-25 %.)
 template <int OutLens, int InMode>
 __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubic_win_kernel(const KParams P) {
   constexpr bool Loop = (InMode == kInEquirectLoop);
-  __shared__ float4 s_win[kT2Waves][2][kWinCap];
+  __shared__ float4 s_win[kT2Waves][kWinBuffers][kWinCap];
 
   const int n_tiles = P.tiles_x * P.tiles_y;
   const int chunk = (n_tiles + kXcds - 1) / kXcds;
@@ -458,7 +554,7 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
   const int y_lane = P.y_offset + ty * (kBlk * G) + (lane >> 4); // + 16 * g + 4 * pass
   const int xe = x < P.out_w ? x : P.out_w - 1;
   const int in_w = P.in_w;
-  const SrcView src = source_view<2>(P);
+  const SrcView src = source_view<2, 4>(P);
   const float4 *__restrict__ src4 = reinterpret_cast<const float4 *>(P.src);
   float4 *const win0 = s_win[wave][0];
   const ColTerms col = column_terms<OutLens>(P, xe, 0);
@@ -496,7 +592,7 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
   auto issue = [&](int g, const WinBlock &b) {
     if (b.staged) {
       // LDS-DMA, one window row per instruction, lanes beyond the width masked off
-      float4 *const win = win0 + (g & 1) * kWinCap;
+      float4 *const win = win0 + (g & (kWinBuffers - 1)) * kWinCap;
       const float4 *gp = src4 + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane));
       if (lane < b.bw) {
         for (int r = 0; r < b.bh; ++r)
@@ -507,7 +603,7 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
   };
 
 #if LRP_ABLATE == 5
-  unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_sum0 = 0, st_sum1 = 0, st_sum2 = 0, st_sum3 = 0, st_sum4 = 0;
 #endif
   WinBlock cur, nxt;
   LRP_STAMP(t_a);
@@ -524,12 +620,12 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
     LRP_STAMP(t1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // window g has landed (also retires block g-1's stores)
     LRP_STAMP(t2);
-    if (g + 1 < G) issue(g + 1, nxt);
+    if (kWinBuffers == 2 && g + 1 < G) issue(g + 1, nxt);
     LRP_STAMP(t3);
     LRP_ACC(0, t0, t1);
     LRP_ACC(2, t1, t2);
     LRP_ACC(1, t2, t3);
-    const float4 *const win = win0 + (g & 1) * kWinCap;
+    const float4 *const win = win0 + (g & (kWinBuffers - 1)) * kWinCap;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       Rgba s;
@@ -545,22 +641,15 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
         const Rgba k3 = cubic4(as_rgba(t[3]), as_rgba(t1[3]), as_rgba(t2[3]), as_rgba(t3[3]), fy, hfy);
         s = cubic4(k0, k1, k2, k3, fx, hfx);
       } else {
-        s = sample_direct<2, Loop>(P, src, cur.sx[k], cur.sy[k]);
+        s = sample_direct<2, Loop, 4>(P, src, cur.sx[k], cur.sy[k]);
       }
       // num_samples == 1: (0.0f + s) * normalize (src/reproject.cpp:334-341)
-      const f2 zero = f2{0.0f, 0.0f};
-      const f2 lo = (zero + s.lo) * P.normalize, hi = (zero + s.hi) * P.normalize;
+      Rgba a = px_zero<4>();
+      px_add<4>(a, s);
       const int yk = y_lane + 16 * g + 4 * k;
-      if (x < P.out_w && yk < P.out_h) {
-        float4 o = make_float4(lo.x, lo.y, hi.x, hi.y);
-        if (P.has_post) {
-          o.x = tonemap(o.x, P.exposure, P.reinhard);
-          o.y = tonemap(o.y, P.exposure, P.reinhard);
-          o.z = tonemap(o.z, P.exposure, P.reinhard);
-        }
-        reinterpret_cast<float4 *>(P.dst)[(uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x] = o;
-      }
+      if (x < P.out_w && yk < P.out_h) store_px<4>(P, (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x, a);
     }
+    if (kWinBuffers == 1 && g + 1 < G) issue(g + 1, nxt); // the window is free again: every tap of block g has been read
     cur = nxt;
     LRP_STAMP(t4);
     LRP_ACC(3, t3, t4);
@@ -569,7 +658,11 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
   LRP_STAMP(t_end);
   LRP_ACC(4, t_a, t_end);
   if (lane == 0) {
-    for (int i = 0; i < 5; ++i) atomicAdd(&g_lrp_stamps[i], st_sum[i]);
+    atomicAdd(&g_lrp_stamps[0], st_sum0);
+    atomicAdd(&g_lrp_stamps[1], st_sum1);
+    atomicAdd(&g_lrp_stamps[2], st_sum2);
+    atomicAdd(&g_lrp_stamps[3], st_sum3);
+    atomicAdd(&g_lrp_stamps[4], st_sum4);
     atomicAdd(&g_lrp_stamps[7], 1ull);
   }
 #endif
@@ -577,21 +670,23 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
 
 using TileKernelFn = void (*)(const KParams);
 
-template <int Interp> struct TileKernelTable {
+template <int Interp, int CH> struct TileKernelTable {
   static TileKernelFn get(int out_idx, int in_mode) {
     static const TileKernelFn table[3][4] = {
-        {reproject_tile_kernel<kRect, kInRect, Interp>, reproject_tile_kernel<kRect, kInEquidistant, Interp>,
-         reproject_tile_kernel<kRect, kInEquirect, Interp>, reproject_tile_kernel<kRect, kInEquirectLoop, Interp>},
-        {reproject_tile_kernel<kEquidistant, kInRect, Interp>, reproject_tile_kernel<kEquidistant, kInEquidistant, Interp>,
-         reproject_tile_kernel<kEquidistant, kInEquirect, Interp>,
-         reproject_tile_kernel<kEquidistant, kInEquirectLoop, Interp>},
-        {reproject_tile_kernel<kEquirect, kInRect, Interp>, reproject_tile_kernel<kEquirect, kInEquidistant, Interp>,
-         reproject_tile_kernel<kEquirect, kInEquirect, Interp>,
-         reproject_tile_kernel<kEquirect, kInEquirectLoop, Interp>}};
+        {reproject_tile_kernel<kRect, kInRect, Interp, CH>, reproject_tile_kernel<kRect, kInEquidistant, Interp, CH>,
+         reproject_tile_kernel<kRect, kInEquirect, Interp, CH>, reproject_tile_kernel<kRect, kInEquirectLoop, Interp, CH>},
+        {reproject_tile_kernel<kEquidistant, kInRect, Interp, CH>,
+         reproject_tile_kernel<kEquidistant, kInEquidistant, Interp, CH>,
+         reproject_tile_kernel<kEquidistant, kInEquirect, Interp, CH>,
+         reproject_tile_kernel<kEquidistant, kInEquirectLoop, Interp, CH>},
+        {reproject_tile_kernel<kEquirect, kInRect, Interp, CH>, reproject_tile_kernel<kEquirect, kInEquidistant, Interp, CH>,
+         reproject_tile_kernel<kEquirect, kInEquirect, Interp, CH>,
+         reproject_tile_kernel<kEquirect, kInEquirectLoop, Interp, CH>}};
     return table[out_idx][in_mode];
   }
 };
 
+// P.channels must be 3, 4 or 5.
 template <int Interp> hipError_t launch_tile_interp(KParams P, int out_idx, int in_mode, hipStream_t stream) {
   P.tiles_x = (P.out_w + kT2W - 1) / kT2W;
   const int rows = P.out_h - P.y_offset;
@@ -599,8 +694,10 @@ template <int Interp> hipError_t launch_tile_interp(KParams P, int out_idx, int 
   const int n_tiles = P.tiles_x * P.tiles_y;
   if (n_tiles <= 0) return hipSuccess;
   const int chunk = (n_tiles + kXcds - 1) / kXcds;
-  hipLaunchKernelGGL(TileKernelTable<Interp>::get(out_idx, in_mode), dim3((unsigned)(chunk * kXcds)), dim3(kT2Threads), 0,
-                     stream, P);
+  const TileKernelFn fn = P.channels == 4   ? TileKernelTable<Interp, 4>::get(out_idx, in_mode)
+                          : P.channels == 3 ? TileKernelTable<Interp, 3>::get(out_idx, in_mode)
+                                            : TileKernelTable<Interp, 5>::get(out_idx, in_mode);
+  hipLaunchKernelGGL(fn, dim3((unsigned)(chunk * kXcds)), dim3(kT2Threads), 0, stream, P);
   return hipGetLastError();
 }
 
@@ -624,7 +721,7 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
   const int rows = P.out_h - P.y_offset;
   // strips of 4 blocks when that still leaves >= 8 workgroups per CU, else shorter
   const int row_blocks = (rows + kBlk - 1) / kBlk;
-  int G = 4;
+  int G = LRP_WIN_STRIP;
   while (G > 1 && (long long)P.tiles_x * ((row_blocks + G - 1) / G) < 2048) G >>= 1;
   P.blocks_per_wave = G;
   P.tiles_y = (row_blocks + G - 1) / G;

@@ -117,6 +117,9 @@ def test_config4_rect_to_equirect_bicubic_tonemapped(lrp, oracle, torch_cuda, ch
     lrp.post_process(lrp.Image(lout, n, n, channels, plain), *post)
     torch.cuda.synchronize()
     assert same_bytes(torch, fused, plain), "fused and stand-alone post_process differ"
+    # the tile kernel (RGBAZ / RGBZ variants) against the one-pixel-per-lane kernel, whole frame
+    pixel = render(lrp, torch, lin, d_in, lout, n, n, 1, BICUBIC, rot, post=post, kernel=0)
+    assert same_bytes(torch, fused, pixel), "tile and pixel kernels differ"
 
 
 def test_config5_8k_rgb_to_six_cubemap_faces(lrp, oracle, torch_cuda):
@@ -135,6 +138,11 @@ def test_config5_8k_rgb_to_six_cubemap_faces(lrp, oracle, torch_cuda):
     torch.cuda.synchronize()
     for d, t, r in zip(degs, outs, rots):
         check_rows(oracle, lin, src_host, lout, face, face, 1, BICUBIC, r, t, f"face {d}", n=4)
+    # RGB tile kernel against the one-pixel-per-lane kernel, whole faces
+    for interp in (NEAREST, BILINEAR, BICUBIC):
+        a = render(lrp, torch, lin, d_in, lout, face, face, 1, interp, rots[4], kernel=2)
+        b = render(lrp, torch, lin, d_in, lout, face, face, 1, interp, rots[4], kernel=0)
+        assert same_bytes(torch, a, b), f"RGB interp={interp}: tile and pixel kernels differ"
 
 
 def test_supersampled_downscale_4k_to_1k(lrp, oracle, torch_cuda):

@@ -59,6 +59,8 @@ static const Workload kWorkloads[] = {
     {"eqr_eqr_bc_rot", "eqr", "eqr", 2, 1, {30, -15, 5}},
     {"eqd_rect_bl", "eqd", "rect", 1, 0, {0, 0, 0}},
     {"eqd_rect_nn", "eqd", "rect", 0, 0, {0, 0, 0}},
+    {"rect_eqr_nn", "rect", "eqr", 0, 1, {0, 0, 0}},
+    {"rect_eqr_bl", "rect", "eqr", 1, 1, {0, 0, 0}},
 };
 
 static void make_lens(lrp_lens *L, const char *kind, int w, int h) {
