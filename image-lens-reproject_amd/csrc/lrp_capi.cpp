@@ -237,19 +237,25 @@ struct Buffer {
   }
 };
 
+// One image in flight: device source + destination and the events that hand it
+// from the upload stream to the compute stream to the download stream.
 struct Slot {
-  hipStream_t stream = nullptr;
   Buffer d_in, d_out;
+  hipEvent_t uploaded = nullptr, computed = nullptr, downloaded = nullptr;
+  bool used = false;
 };
 
 } // namespace
 
+// Three-stage pipeline: H2D on `up`, kernels on `run`, D2H on `down`, so that the
+// upload of image i+1, the kernel of image i and the download of image i-1 use
+// both PCIe directions and the GPU at the same time (a stream per image does not:
+// its own H2D -> kernel -> D2H chain keeps one DMA direction idle).
 struct lrp_context {
   int device = 0;
+  hipStream_t up = nullptr, run = nullptr, down = nullptr;
   std::vector<Slot> slots;
   size_t next = 0;
-  int first_error = LRP_OK;
-  std::string first_error_text;
 };
 
 extern "C" {
@@ -331,12 +337,17 @@ int lrp_context_create(lrp_context **ctx, int device, int n_streams) {
   if (!c) return fail(LRP_ERR_OOM, "host allocation failed");
   c->device = device;
   c->slots.resize((size_t)n_streams);
+  hipError_t e = hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->run, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->down, hipStreamNonBlocking);
   for (auto &s : c->slots) {
-    hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-      lrp_context_destroy(c);
-      return hip_fail(e, "hipStreamCreateWithFlags");
-    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.computed, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.downloaded, hipEventDisableTiming);
+  }
+  if (e != hipSuccess) {
+    lrp_context_destroy(c);
+    return hip_fail(e, "stream / event creation");
   }
   *ctx = c;
   return LRP_OK;
@@ -345,11 +356,14 @@ int lrp_context_create(lrp_context **ctx, int device, int n_streams) {
 void lrp_context_destroy(lrp_context *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  for (auto &s : ctx->slots) {
-    if (s.stream) {
-      (void)hipStreamSynchronize(s.stream);
-      (void)hipStreamDestroy(s.stream);
+  for (hipStream_t st : {ctx->up, ctx->run, ctx->down})
+    if (st) {
+      (void)hipStreamSynchronize(st);
+      (void)hipStreamDestroy(st);
     }
+  for (auto &s : ctx->slots) {
+    for (hipEvent_t ev : {s.uploaded, s.computed, s.downloaded})
+      if (ev) (void)hipEventDestroy(ev);
     s.d_in.release();
     s.d_out.release();
   }
@@ -366,20 +380,33 @@ int lrp_context_submit(lrp_context *ctx, const lrp_image *in, lrp_image *out, in
   if (num_samples <= 0) return LRP_OK;
   Slot &s = ctx->slots[ctx->next];
   ctx->next = (ctx->next + 1) % ctx->slots.size();
-  // The slot's buffers are reused: its previous image must have drained.
-  LRP_HIP_TRY(hipStreamSynchronize(s.stream));
   const size_t in_bytes = image_bytes(*in), out_bytes = image_bytes(*out);
-  st = s.d_in.reserve(in_bytes);
-  if (st != LRP_OK) return st;
-  st = s.d_out.reserve(out_bytes);
-  if (st != LRP_OK) return st;
-  LRP_HIP_TRY(hipMemcpyAsync(s.d_in.ptr, in->data, in_bytes, hipMemcpyHostToDevice, s.stream));
+  if (in_bytes > s.d_in.cap || out_bytes > s.d_out.cap) {
+    // growing a buffer frees the old one: the slot's previous image must have drained
+    if (s.used) LRP_HIP_TRY(hipEventSynchronize(s.downloaded));
+    st = s.d_in.reserve(in_bytes);
+    if (st != LRP_OK) return st;
+    st = s.d_out.reserve(out_bytes);
+    if (st != LRP_OK) return st;
+  }
+  // upload: the slot's source buffer is free once its previous kernel has run
+  if (s.used) LRP_HIP_TRY(hipStreamWaitEvent(ctx->up, s.computed, 0));
+  LRP_HIP_TRY(hipMemcpyAsync(s.d_in.ptr, in->data, in_bytes, hipMemcpyHostToDevice, ctx->up));
+  LRP_HIP_TRY(hipEventRecord(s.uploaded, ctx->up));
+  // kernel: after the upload, and after the previous download has read the destination buffer
+  LRP_HIP_TRY(hipStreamWaitEvent(ctx->run, s.uploaded, 0));
+  if (s.used) LRP_HIP_TRY(hipStreamWaitEvent(ctx->run, s.downloaded, 0));
   lrp_image din = *in, dout = *out;
   din.data = (float *)s.d_in.ptr;
   dout.data = (float *)s.d_out.ptr;
-  st = enqueue_reproject(&din, &dout, num_samples, interpolation, rotation, post, ctx->device, s.stream);
+  st = enqueue_reproject(&din, &dout, num_samples, interpolation, rotation, post, ctx->device, ctx->run);
   if (st != LRP_OK) return st;
-  LRP_HIP_TRY(hipMemcpyAsync(out->data, s.d_out.ptr, out_bytes, hipMemcpyDeviceToHost, s.stream));
+  LRP_HIP_TRY(hipEventRecord(s.computed, ctx->run));
+  // download
+  LRP_HIP_TRY(hipStreamWaitEvent(ctx->down, s.computed, 0));
+  LRP_HIP_TRY(hipMemcpyAsync(out->data, s.d_out.ptr, out_bytes, hipMemcpyDeviceToHost, ctx->down));
+  LRP_HIP_TRY(hipEventRecord(s.downloaded, ctx->down));
+  s.used = true;
   return LRP_OK;
 }
 
@@ -388,8 +415,8 @@ int lrp_context_wait(lrp_context *ctx) {
   int st = select_device(ctx->device);
   if (st != LRP_OK) return st;
   int result = LRP_OK;
-  for (auto &s : ctx->slots) {
-    hipError_t e = hipStreamSynchronize(s.stream);
+  for (hipStream_t stream : {ctx->up, ctx->run, ctx->down}) {
+    hipError_t e = hipStreamSynchronize(stream);
     if (e != hipSuccess && result == LRP_OK) result = hip_fail(e, "hipStreamSynchronize");
   }
   return result;
@@ -450,13 +477,13 @@ int lrp_post_process(lrp_image *img, float exposure, float reinhard, int device)
     const size_t bytes = image_bytes(*img);
     int r = s.d_out.reserve(bytes);
     if (r != LRP_OK) return r;
-    LRP_HIP_TRY(hipMemcpyAsync(s.d_out.ptr, img->data, bytes, hipMemcpyHostToDevice, s.stream));
+    LRP_HIP_TRY(hipMemcpyAsync(s.d_out.ptr, img->data, bytes, hipMemcpyHostToDevice, c->run));
     lrp_image d = *img;
     d.data = (float *)s.d_out.ptr;
-    r = lrp_post_process_device(&d, exposure, reinhard, device, s.stream);
+    r = lrp_post_process_device(&d, exposure, reinhard, device, c->run);
     if (r != LRP_OK) return r;
-    LRP_HIP_TRY(hipMemcpyAsync(img->data, s.d_out.ptr, bytes, hipMemcpyDeviceToHost, s.stream));
-    LRP_HIP_TRY(hipStreamSynchronize(s.stream));
+    LRP_HIP_TRY(hipMemcpyAsync(img->data, s.d_out.ptr, bytes, hipMemcpyDeviceToHost, c->run));
+    LRP_HIP_TRY(hipStreamSynchronize(c->run));
     return LRP_OK;
   }();
   return_context(c);

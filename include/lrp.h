@@ -155,11 +155,13 @@ int lrp_reproject_multi_device(const lrp_image *in, lrp_image *outs, int n_out, 
 
 /* ---- batches of independent images (the reference's --input-dir path) ------ */
 
-/* A context owns `n_streams` HIP streams on one device, each with a device
- * source/destination buffer pair and pinned staging, sized for the largest
- * image submitted so far.  Images are independent (src/main.cpp:540-622: one
- * file per pool thread); the context round-robins them over its streams so that
- * H2D of image i+1, the kernel of image i and D2H of image i-1 overlap. */
+/* A context owns a three-stage pipeline on one device — an upload stream, a
+ * compute stream and a download stream, chained by events — and `n_streams`
+ * image slots (device source + destination buffers, sized for the largest image
+ * submitted so far).  Images are independent (src/main.cpp:540-622: one file per
+ * pool thread); with n_streams >= 2 the H2D copy of image i+1, the kernel of
+ * image i and the D2H copy of image i-1 run at the same time on both PCIe
+ * directions (pinned host buffers make the copies asynchronous). */
 typedef struct lrp_context lrp_context;
 
 int lrp_context_create(lrp_context **ctx, int device, int n_streams);
