@@ -181,15 +181,17 @@ __device__ __forceinline__ Texel<CH> load_texel(const float *__restrict__ src, u
 }
 
 template <int CH> __device__ __forceinline__ void store_texel(float *__restrict__ dst, uint32_t elem_off, const Texel<CH> &t, int ch) {
+  // non-temporal: the output is written once and never read back by the kernel
   if constexpr (CH == 4) {
-    *reinterpret_cast<float4 *>(dst + elem_off) = make_float4(t.v[0], t.v[1], t.v[2], t.v[3]);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(v4f{t.v[0], t.v[1], t.v[2], t.v[3]}, reinterpret_cast<v4f *>(dst + elem_off));
   } else if constexpr (CH == 0) {
 #pragma unroll
     for (int c = 0; c < kMaxDynChannels; ++c)
-      if (c < ch) dst[elem_off + c] = t.v[c];
+      if (c < ch) __builtin_nontemporal_store(t.v[c], dst + elem_off + c);
   } else {
 #pragma unroll
-    for (int c = 0; c < CH; ++c) dst[elem_off + c] = t.v[c];
+    for (int c = 0; c < CH; ++c) __builtin_nontemporal_store(t.v[c], dst + elem_off + c);
   }
 }
 

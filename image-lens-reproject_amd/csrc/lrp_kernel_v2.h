@@ -281,10 +281,16 @@ __device__ __forceinline__ void pixel_source(const KParams &P, const ColTerms co
     vy = ny;
     vz = nz;
   }
+#if defined(LRP_TRIVIAL_COORDS) // timing experiment: trivial coordinates (memory path only)
+  sx = vx * 1000.0f + (float)P.in_w * 0.5f;
+  sy = vy * 1000.0f + (float)P.in_h * 0.5f;
+  (void)vz;
+#else
   float px, py;
   ray_to_source_v2<InMode>(P, vx, vy, vz, px, py);
   sx = (px - 0.5f) + (float)P.in_w * 0.5f; // :323-324
   sy = (py - 0.5f) + (float)P.in_h * 0.5f;
+#endif
 }
 
 // ---- one sample, taps straight from global memory -------------------------------
@@ -406,19 +412,23 @@ __device__ __forceinline__ void store_px(const KParams &P, uint32_t pixel_index,
     c[1] = tonemap(c[1], P.exposure, P.reinhard);
     c[2] = tonemap(c[2], P.exposure, P.reinhard);
   }
+  // Non-temporal stores: the output is written once and never read by this kernel;
+  // keeping it out of the L2 leaves the cache to the source texels (measured on a 4K
+  // frame: nearest 88 -> 63 us, bilinear 117 -> 95 us, bicubic 223 -> 214 us).
   float *d = P.dst + (size_t)pixel_index * CH;
+  typedef float v4f __attribute__((ext_vector_type(4)));
   if constexpr (CH == 4) {
-    *reinterpret_cast<float4 *>(d) = make_float4(c[0], c[1], c[2], c[3]);
+    __builtin_nontemporal_store(v4f{c[0], c[1], c[2], c[3]}, reinterpret_cast<v4f *>(d));
   } else if constexpr (CH == 3) {
-    d[0] = c[0];
-    d[1] = c[1];
-    d[2] = c[2];
+    __builtin_nontemporal_store(c[0], d);
+    __builtin_nontemporal_store(c[1], d + 1);
+    __builtin_nontemporal_store(c[2], d + 2);
   } else {
-    d[0] = c[0];
-    d[1] = c[1];
-    d[2] = c[2];
-    d[3] = c[3];
-    d[4] = c[4];
+    __builtin_nontemporal_store(c[0], d);
+    __builtin_nontemporal_store(c[1], d + 1);
+    __builtin_nontemporal_store(c[2], d + 2);
+    __builtin_nontemporal_store(c[3], d + 3);
+    __builtin_nontemporal_store(c[4], d + 4);
   }
 }
 
@@ -635,11 +645,34 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
         const float4 *t = win + (((int)ty_ - 1 - cur.y_lo) * cur.pitch + ((int)tx_ - 1 - cur.x_lo));
         const float hfx = 0.5f * fx, hfy = 0.5f * fy;
         const float4 *t1 = t + cur.pitch, *t2 = t1 + cur.pitch, *t3 = t2 + cur.pitch;
+#if LRP_ABLATE == 1 // timing experiment: taps loaded, no cubic arithmetic
+        Rgba z = as_rgba(t[0]);
+        for (int i = 0; i < 4; ++i) {
+          z.lo += as_rgba(t[i]).lo + as_rgba(t1[i]).lo + as_rgba(t2[i]).lo + as_rgba(t3[i]).lo;
+          z.hi += as_rgba(t[i]).hi + as_rgba(t1[i]).hi + as_rgba(t2[i]).hi + as_rgba(t3[i]).hi;
+        }
+        s = z;
+        (void)hfx;
+        (void)hfy;
+#elif LRP_ABLATE == 2 // timing experiment: cubic arithmetic on register data, one tap loaded
+        const Rgba q = as_rgba(t[0]);
+        (void)t1; (void)t2; (void)t3;
+        const Rgba q1{q.lo + fx, q.hi + fy, 0.0f}, q2{q.lo * fx, q.hi * fy, 0.0f}, q3{q.lo - fx, q.hi - fy, 0.0f};
+        const Rgba k0 = cubic4(q, q1, q2, q3, fy, hfy);
+        const Rgba k1 = cubic4(q1, q2, q3, q, fy, hfy);
+        const Rgba k2 = cubic4(q2, q3, q, q1, fy, hfy);
+        const Rgba k3 = cubic4(q3, q, q1, q2, fy, hfy);
+        s = cubic4(k0, k1, k2, k3, fx, hfx);
+#elif LRP_ABLATE == 7 // timing experiment: neither taps nor arithmetic
+        s = Rgba{f2{fx, fy}, f2{hfx, hfy}, 0.0f};
+        (void)t1; (void)t2; (void)t3;
+#else
         const Rgba k0 = cubic4(as_rgba(t[0]), as_rgba(t1[0]), as_rgba(t2[0]), as_rgba(t3[0]), fy, hfy);
         const Rgba k1 = cubic4(as_rgba(t[1]), as_rgba(t1[1]), as_rgba(t2[1]), as_rgba(t3[1]), fy, hfy);
         const Rgba k2 = cubic4(as_rgba(t[2]), as_rgba(t1[2]), as_rgba(t2[2]), as_rgba(t3[2]), fy, hfy);
         const Rgba k3 = cubic4(as_rgba(t[3]), as_rgba(t1[3]), as_rgba(t2[3]), as_rgba(t3[3]), fy, hfy);
         s = cubic4(k0, k1, k2, k3, fx, hfx);
+#endif
       } else {
         s = sample_direct<2, Loop, 4>(P, src, cur.sx[k], cur.sy[k]);
       }
@@ -647,7 +680,11 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
       Rgba a = px_zero<4>();
       px_add<4>(a, s);
       const int yk = y_lane + 16 * g + 4 * k;
+#if defined(LRP_NO_STORE) // timing experiment: almost no output traffic
+      if (x < P.out_w && yk < P.out_h && a.lo.x == 12345.678f) store_px<4>(P, (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x, a);
+#else
       if (x < P.out_w && yk < P.out_h) store_px<4>(P, (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x, a);
+#endif
     }
     if (kWinBuffers == 1 && g + 1 < G) issue(g + 1, nxt); // the window is free again: every tap of block g has been read
     cur = nxt;
