@@ -147,6 +147,9 @@ def main():
                     help="HIP streams the frames of a step round-robin over (one frame fills the chip; >1 only "
                          "overlaps kernel tails and makes per-kernel durations in a profile overlap)")
     ap.add_argument("--workload", default="fisheye_to_rect_bicubic", choices=sorted(WORKLOADS))
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the barrier / max-time reduction for --gpus > 1 (nccl = RCCL; "
+                         "gloo lets two ranks share one GPU in a smoke test of the multi-rank path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -159,14 +162,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend="gloo")
+    dev = torch.device("cuda", dev_index)
 
     wl = WORKLOADS[args.workload]
     size, c = wl["size"], wl["channels"]
@@ -207,7 +214,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -40,8 +40,8 @@ if cal:
                    "WRITE_SIZE_bytes_raw": write.get(k), "read_factor": read_factor, "write_factor": write_factor}
 names = {"reproject_bicubic_win_kernel<0, 1>": "fisheye_to_rect_bicubic",
          "reproject_bicubic_win_kernel<0, 3>": "equirect_to_rect_bicubic",
-         "reproject_tile_kernel<1, 3, 1>": "equirect_to_fisheye_bilinear",
-         "reproject_tile_kernel<0, 3, 0>": "equirect_to_rect_nearest"}
+         "reproject_tile_kernel<1, 3, 1, 4>": "equirect_to_fisheye_bilinear",
+         "reproject_tile_kernel<0, 3, 0, 4>": "equirect_to_rect_nearest"}
 result = {"_calibration": calibration,
           "_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/traffic_probe.py; KiB -> "
                      "bytes; reads scaled by the factor measured on the calibration kernel (guide: 2.0 for 16 B/lane "
