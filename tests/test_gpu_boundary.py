@@ -1,0 +1,109 @@
+"""-m gpu: behaviour of the drop-in boundary beyond numerics — concurrent callers
+(the reference calls reproject() from -j N pool threads, src/main.cpp:538-544),
+hipGraph capture of the device-resident entry point, the table cache, the kernel
+family knob."""
+import threading
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def test_concurrent_host_callers_like_the_reference_thread_pool(lrp, oracle, torch_cuda):
+    """8 host threads, each rendering its own images through the synchronous host-buffer
+    entry point (the reference's calling convention), different lenses per thread."""
+    in_w, in_h, out_w, out_h = 160, 96, 128, 80
+    names = ["rect", "eqd180", "eqr_full", "eqr_part"]
+    jobs = []
+    for t in range(8):
+        lin = cases.lenses(lrp, in_w, in_h)[names[t % 4]]
+        lout = cases.lenses(lrp, out_w, out_h)[names[(t + 1) % 3]]
+        rot = cases.rotation(lrp, (10.0 * t, -5.0 * t, 3.0 * t))
+        src = cases.hash_noise(in_h, in_w, 4, seed=100 + t)
+        want = oracle.reproject(lin, src, lout, out_w, out_h, 1, t % 3, rot)
+        jobs.append((lin, lout, rot, src, want, t % 3))
+    errors = []
+
+    def worker(job):
+        lin, lout, rot, src, want, interp = job
+        try:
+            for _ in range(5):
+                out = np.full((out_h, out_w, 4), np.float32(-1.0), dtype=np.float32)
+                lrp.reproject(lrp.Image(lin, in_w, in_h, 4, src), lrp.Image(lout, out_w, out_h, 4, out), 1, interp, rot)
+                cases.assert_same_bits(out, want, "threaded host call")
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[0]
+
+
+def test_device_entry_point_is_capturable_into_a_graph(lrp, oracle, torch_cuda):
+    """After one warm-up call (which builds the output-lens tables) lrp_reproject_device
+    neither allocates nor synchronises: it can be captured into a hipGraph and replayed."""
+    torch = torch_cuda
+    in_w, in_h, out_w, out_h = 256, 128, 192, 112
+    lin = cases.lenses(lrp, in_w, in_h)["eqr_full"]
+    lout = cases.lenses(lrp, out_w, out_h)["rect"]
+    rot = cases.rotation(lrp, (30.0, -15.0, 5.0))
+    src = cases.hash_noise(in_h, in_w, 4, seed=7)
+    d_in = torch.from_numpy(src).cuda()
+    d_out = torch.zeros((out_h, out_w, 4), dtype=torch.float32, device="cuda")
+    im_in, im_out = lrp.Image(lin, in_w, in_h, 4, d_in), lrp.Image(lout, out_w, out_h, 4, d_out)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for interp in (0, 1, 2):
+            lrp.reproject(im_in, im_out, 1, interp, rot)  # warm-up: tables cached
+    side.synchronize()
+    for interp in (0, 1, 2):
+        want = oracle.reproject(lin, src, lout, out_w, out_h, 1, interp, rot)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            lrp.reproject(im_in, im_out, 1, interp, rot)
+        d_out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        cases.assert_same_bits(d_out.cpu().numpy(), want, f"graph replay interp={interp}")
+        # new source contents, same graph
+        src2 = cases.hash_noise(in_h, in_w, 4, seed=8 + interp)
+        d_in.copy_(torch.from_numpy(src2))
+        g.replay()
+        torch.cuda.synchronize()
+        cases.assert_same_bits(d_out.cpu().numpy(), oracle.reproject(lin, src2, lout, out_w, out_h, 1, interp, rot),
+                               f"graph replay 2 interp={interp}")
+        d_in.copy_(torch.from_numpy(src))
+
+
+def test_table_cache_release_and_rebuild(lrp, oracle, torch_cuda):
+    torch = torch_cuda
+    in_w, in_h, out_w, out_h = 90, 60, 70, 50
+    lin = cases.lenses(lrp, in_w, in_h)["eqd180"]
+    src = cases.hash_noise(in_h, in_w, 4, seed=3)
+    d_in = torch.from_numpy(src).cuda()
+    for round_ in range(2):
+        for out_name in ("rect", "rect_tele", "eqr_full", "eqr_part"):
+            lout = cases.lenses(lrp, out_w, out_h)[out_name]
+            for ns in (1, 2):
+                d_out = torch.empty((out_h, out_w, 4), dtype=torch.float32, device="cuda")
+                lrp.reproject(lrp.Image(lin, in_w, in_h, 4, d_in), lrp.Image(lout, out_w, out_h, 4, d_out), ns, 1, None)
+                torch.cuda.synchronize()
+                cases.assert_same_bits(d_out.cpu().numpy(), oracle.reproject(lin, src, lout, out_w, out_h, ns, 1, None),
+                                       f"{out_name} ns={ns} round {round_}")
+        lrp._native.load().lrp_release_cached_tables()
+
+
+def test_kernel_family_knob(lrp, torch_cuda):
+    prev = lrp.debug_kernel(-1)
+    assert prev in (0, 1, 2)
+    assert lrp.debug_kernel(0) == prev
+    assert lrp.debug_kernel(-1) == 0
+    assert lrp.debug_kernel(7) == 0  # out of range: query only
+    lrp.debug_kernel(prev)
+    assert lrp.debug_kernel(-1) == prev
