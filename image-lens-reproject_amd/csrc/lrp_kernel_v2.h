@@ -255,19 +255,19 @@ template <int OutLens> __device__ __forceinline__ ColTerms column_terms(const KP
 
 // One sub-sample of output pixel (column terms `col`, row ye) -> top-left-origin
 // source texel coordinates.  All 64 lanes must be active (wave-wide vote inside).
-template <int OutLens, int InMode>
+template <int OutLens, int InMode, bool OneSample = false>
 __device__ __forceinline__ void pixel_source(const KParams &P, const ColTerms col, int ye, int ssy, float &sx,
                                              float &sy) {
-  const int ns = P.num_samples;
+  const int ns = OneSample ? 1 : P.num_samples; // OneSample: the caller guarantees num_samples == 1 (ssy == 0)
   float vx, vy, vz;
   if constexpr (OutLens == kRect) {
     vx = col.a;
-    vy = P.row_tab[ye * ns + ssy];
+    vy = P.row_tab[OneSample ? ye : ye * ns + ssy];
     vz = -1.0f;
   } else if constexpr (OutLens == kEquirect) {
     vx = col.a;
     vz = col.b;
-    vy = P.row_tab[ye * ns + ssy];
+    vy = P.row_tab[OneSample ? ye : ye * ns + ssy];
   } else {
     const float cy = ((float)ye + 0.5f) - (float)P.out_h * 0.5f;               // :288
     const float scy = cy + ((float)ssy + 1.0f) / ((float)ns + 1.0f) - 0.5f;    // :298
@@ -417,17 +417,14 @@ __device__ __forceinline__ void store_px(const KParams &P, uint32_t pixel_index,
   // frame: nearest 88 -> 63 us, bilinear 117 -> 95 us, bicubic 223 -> 214 us).
   float *d = P.dst + (size_t)pixel_index * CH;
   typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
+  typedef float v3f_a4 __attribute__((ext_vector_type(3), aligned(4)));
   if constexpr (CH == 4) {
     __builtin_nontemporal_store(v4f{c[0], c[1], c[2], c[3]}, reinterpret_cast<v4f *>(d));
-  } else if constexpr (CH == 3) {
-    __builtin_nontemporal_store(c[0], d);
-    __builtin_nontemporal_store(c[1], d + 1);
-    __builtin_nontemporal_store(c[2], d + 2);
-  } else {
-    __builtin_nontemporal_store(c[0], d);
-    __builtin_nontemporal_store(c[1], d + 1);
-    __builtin_nontemporal_store(c[2], d + 2);
-    __builtin_nontemporal_store(c[3], d + 3);
+  } else if constexpr (CH == 3) { // one dwordx3 per lane: a wavefront's row is 768 contiguous bytes
+    __builtin_nontemporal_store(v3f_a4{c[0], c[1], c[2]}, reinterpret_cast<v3f_a4 *>(d));
+  } else { // dwordx4 + dword (4-byte aligned): 1280 contiguous bytes per wavefront row
+    __builtin_nontemporal_store(v4f_a4{c[0], c[1], c[2], c[3]}, reinterpret_cast<v4f_a4 *>(d));
     __builtin_nontemporal_store(c[4], d + 4);
   }
 }
@@ -569,34 +566,47 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
   float4 *const win0 = s_win[wave][0];
   const ColTerms col = column_terms<OutLens>(P, xe, 0);
 
-  // phase A of block g: coordinates, interior vote, window box, DMA issue
+  // phase A of block g: coordinates, interior vote, window box
   auto coords = [&](int g, WinBlock &b) {
-    int ok = 1;
+    // Per pixel only the exactness half of interior() (it also fails for NaN / inf);
+    // the range half is voted once per block on the wave-wide extremes.  For finite
+    // floats the raw bits order like signed integers as long as the minimum is >= 0,
+    // and a negative coordinate makes the signed minimum negative, so v_min_i32 /
+    // v_max_i32 on the bits give the extremes (no canonicalising float min / max).
+    int exact = 1;
+    int lo_x = 0x7fffffff, lo_y = 0x7fffffff, hi_x = (int)0x80000000, hi_y = (int)0x80000000;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int yk = y_lane + 16 * g + 4 * k;
       const int ye = yk < P.out_h ? yk : P.out_h - 1;
-      pixel_source<OutLens, InMode>(P, col, ye, 0, b.sx[k], b.sy[k]);
-      ok &= interior(b.sx[k], 1.0f, src.x_hi, 2.0f) & interior(b.sy[k], 1.0f, src.y_hi, 2.0f);
+      pixel_source<OutLens, InMode, true>(P, col, ye, 0, b.sx[k], b.sy[k]);
+      exact &= (int)(((b.sx[k] + 2.0f) - b.sx[k]) == 2.0f) & (int)(((b.sy[k] + 2.0f) - b.sy[k]) == 2.0f);
+      const int bx = (int)f2u(b.sx[k]), by = (int)f2u(b.sy[k]);
+      lo_x = min(lo_x, bx);
+      hi_x = max(hi_x, bx);
+      lo_y = min(lo_y, by);
+      hi_y = max(hi_y, by);
     }
     b.staged = false;
     b.x_lo = b.y_lo = b.bw = b.bh = b.pitch = 0;
-    if (wave_all(ok != 0)) {
-      // every tap index of the block is int(s) - 1 .. int(s) + 2, unclamped
-      int ix[4], iy[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        ix[k] = (int)b.sx[k];
-        iy[k] = (int)b.sy[k];
+    if (wave_all(exact != 0)) {
+      const int w_lo_x = wave_extreme<false>(lo_x), w_hi_x = wave_extreme<true>(hi_x);
+      const int w_lo_y = wave_extreme<false>(lo_y), w_hi_y = wave_extreme<true>(hi_y);
+      const int one = (int)f2u(1.0f);
+      // 1 <= s < extent - 2 for every pixel: every tap index is int(s) - 1 .. int(s) + 2, unclamped
+      if (w_lo_x >= one && w_lo_y >= one && w_hi_x < (int)f2u(src.x_hi) && w_hi_y < (int)f2u(src.y_hi)) {
+        // float -> int of the four wave-uniform extremes (VALU has the converter)
+        const int x_first = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_lo_x));
+        const int y_first = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_lo_y));
+        const int x_last = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_hi_x));
+        const int y_last = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_hi_y));
+        b.x_lo = x_first - 1;
+        b.y_lo = y_first - 1;
+        b.bw = x_last + 2 - b.x_lo + 1;
+        b.bh = y_last + 2 - b.y_lo + 1;
+        b.pitch = b.bw | 1; // odd: consecutive window rows start an odd number of 16 B slots apart
+        b.staged = b.bw <= 64 && b.pitch * b.bh <= kWinCap;
       }
-      b.x_lo = wave_extreme<false>(min(min(ix[0], ix[1]), min(ix[2], ix[3]))) - 1;
-      b.y_lo = wave_extreme<false>(min(min(iy[0], iy[1]), min(iy[2], iy[3]))) - 1;
-      const int x_hi = wave_extreme<true>(max(max(ix[0], ix[1]), max(ix[2], ix[3]))) + 2;
-      const int y_hi = wave_extreme<true>(max(max(iy[0], iy[1]), max(iy[2], iy[3]))) + 2;
-      b.bw = x_hi - b.x_lo + 1;
-      b.bh = y_hi - b.y_lo + 1;
-      b.pitch = b.bw | 1; // odd: consecutive window rows start an odd number of 16 B slots apart
-      b.staged = b.bw <= 64 && b.pitch * b.bh <= kWinCap;
     }
   };
   auto issue = [&](int g, const WinBlock &b) {
@@ -642,7 +652,8 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
       if (cur.staged) {
         const float tx_ = __builtin_truncf(cur.sx[k]), ty_ = __builtin_truncf(cur.sy[k]);
         const float fx = cur.sx[k] - tx_, fy = cur.sy[k] - ty_;
-        const float4 *t = win + (((int)ty_ - 1 - cur.y_lo) * cur.pitch + ((int)tx_ - 1 - cur.x_lo));
+        const float4 *t = win + (__umul24((uint32_t)((int)ty_ - 1 - cur.y_lo), (uint32_t)cur.pitch) +
+                                 (uint32_t)((int)tx_ - 1 - cur.x_lo));
         const float hfx = 0.5f * fx, hfy = 0.5f * fy;
         const float4 *t1 = t + cur.pitch, *t2 = t1 + cur.pitch, *t3 = t2 + cur.pitch;
 #if LRP_ABLATE == 1 // timing experiment: taps loaded, no cubic arithmetic
