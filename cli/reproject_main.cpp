@@ -4,8 +4,6 @@
 //
 // Same flags, defaults, validation messages and stdout progress lines; the differences
 // are listed in `--help`:
-//   * config-file mode (--input-cfg / --output-cfg, Blender JSON, row f4) is not built:
-//     use --no-configs W,H with the --i-* input-lens flags;
 //   * codecs (cli/lrp_image_io.cpp): PNG through libpng, scanline OpenEXR with NO / ZIPS /
 //     ZIP compression; JPEG input is not read;
 //   * the pixel work runs on the GPU: --device N picks the first GPU, --gpus G spreads the
@@ -26,8 +24,13 @@
 #include <thread>
 #include <vector>
 
+#include <fstream>
+#include <sstream>
+
 #include "lrp.h"
+#include "lrp_config.h"
 #include "lrp_image_io.h"
+#include "lrp_json.h"
 
 namespace fs = std::filesystem;
 
@@ -43,8 +46,8 @@ struct Option {
 };
 
 const Option kOptions[] = {
-    {"input-cfg", 0, true, nullptr, "json-file", "Input JSON lens / camera config (config mode: not built, see below).", "Input/output"},
-    {"output-cfg", 0, true, nullptr, "json-file", "Output JSON lens / camera config (config mode: not built).", "Input/output"},
+    {"input-cfg", 0, true, nullptr, "json-file", "Input JSON file with the lens and camera settings of the input images.", "Input/output"},
+    {"output-cfg", 0, true, nullptr, "json-file", "Output JSON file: the input config with the output lens and resolution.", "Input/output"},
     {"no-configs", 0, true, nullptr, "width,height", "Work without config files: input lens from the --i-* flags, input resolution given here.", "Input/output"},
     {"input-dir", 'i', true, nullptr, "dir", "Directory with the images to reproject (.exr, .png).", "Input/output"},
     {"single", 0, true, nullptr, "file", "A single input file to convert.", "Input/output"},
@@ -100,7 +103,7 @@ std::string help_text(const char *argv0) {
     if (o.default_value && *o.default_value) s += std::string(" (default: ") + o.default_value + ")";
     s += "\n";
   }
-  s += "\nNot built in this version: config-file mode (--input-cfg / --output-cfg) and JPEG input.\n";
+  s += "\nNot built in this version: JPEG input.\n";
   return s;
 }
 
@@ -399,6 +402,8 @@ int main(int argc, char **argv) {
   const std::string filter_prefix = result["filter-prefix"], filter_suffix = result["filter-suffix"];
 
   int ires_x = 0, ires_y = 0;
+  lrp_json::Value out_cfg;
+  std::string output_cfg_file;
   if (result.count("no-configs")) {
     const std::string lstr = result["no-configs"];
     const size_t comma = lstr.find(",");
@@ -427,9 +432,27 @@ int main(int argc, char **argv) {
       return 1;
     }
   } else {
-    std::printf("Error: config-file mode (--input-cfg / --output-cfg) is not built in this version.\n"
-                "Use --no-configs width,height with one of --i-rectilinear, --i-equidistant, --i-equirectangular.\n");
-    return 1;
+    // config-file mode, src/main.cpp:429-443
+    if (!result.count("input-cfg") || !result.count("output-cfg")) {
+      std::printf("Option 'input-cfg' / 'output-cfg' has no value (or use --no-configs width,height)\n\n%s\n",
+                  help_text(argv[0]).c_str());
+      return 1;
+    }
+    output_cfg_file = result["output-cfg"];
+    try {
+      std::ifstream in(result["input-cfg"]);
+      if (!in) throw std::invalid_argument("cannot open " + result["input-cfg"]);
+      std::stringstream buf;
+      buf << in.rdbuf();
+      out_cfg = lrp_json::parse(buf.str());
+      std::printf("Found camera config: %s\n", out_cfg.at("camera").dump(1).c_str());
+      ires_x = out_cfg.at("resolution").at(0).as_int();
+      ires_y = out_cfg.at("resolution").at(1).as_int();
+      job.input_lens = lrp_cfg::extract_lens_info_from_config(out_cfg);
+    } catch (const std::exception &e) { // the reference lets the exception end the program
+      std::printf("Error: %s\n", e.what());
+      return 1;
+    }
   }
 
   int output_lens_types_found = 0;
@@ -466,6 +489,39 @@ int main(int argc, char **argv) {
   std::printf("Creating directory: %s\n", job.output_dir.c_str());
   std::error_code ec;
   fs::create_directory(job.output_dir, ec);
+
+  if (!result.count("no-configs")) {
+    // src/main.cpp:497-529: the input config with the output lens, the output resolution and
+    // the frame list filtered like the files
+    try {
+      lrp_cfg::store_lens_info_in_config(job.output_lens, out_cfg);
+      out_cfg["resolution"][0] = lrp_json::Value::integer(job.ores_x);
+      out_cfg["resolution"][1] = lrp_json::Value::integer(job.ores_y);
+      if (out_cfg.contains("frames")) {
+        auto &frames = out_cfg["frames"].arr;
+        for (size_t i = 0; i < frames.size();) {
+          const std::string name = frames[i].at("name").str();
+          bool remove = false;
+          if (name.size() < filter_prefix.size() || name.size() < filter_suffix.size())
+            remove = true;
+          else if (name.substr(0, filter_prefix.size()) != filter_prefix)
+            remove = true;
+          else if (name.substr(name.size() - filter_suffix.size()) != filter_suffix)
+            remove = true;
+          if (remove)
+            frames.erase(frames.begin() + (long)i);
+          else
+            ++i;
+        }
+      }
+      std::printf("Saving output config: %s\n", output_cfg_file.c_str());
+      std::ofstream out(output_cfg_file);
+      out << out_cfg.dump(2);
+    } catch (const std::exception &e) {
+      std::printf("Error: %s\n", e.what());
+      return 1;
+    }
+  }
 
   if (dry_run) {
     std::printf("Dry-run. Exiting.\n");

@@ -23,7 +23,7 @@ _libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
 @pytest.fixture(scope="module")
 def cli(lrp):
     lrp._native.load()
-    srcs = [os.path.join(ROOT, "cli", f) for f in ("reproject_main.cpp", "lrp_image_io.cpp", "lrp_image_io.h")]
+    srcs = [os.path.join(ROOT, "cli", f) for f in os.listdir(os.path.join(ROOT, "cli"))]
     if not os.path.exists(CLI) or os.path.getmtime(CLI) < max(os.path.getmtime(s) for s in srcs):
         subprocess.run(["bash", os.path.join(ROOT, "cli", "build.sh")], check=True)
     return CLI
@@ -78,7 +78,9 @@ def test_help_lists_every_reference_flag(cli):
       "--equidistant", "3.1"], "Error: only specify one output lens type"),
     (["--single", "a.png", "-o", "o", "--png", "--no-configs", "8,8", "--i-equirectangular", "full", "--rectilinear", "18,36",
       "--output-resolution", "64"], "Error: Specify both width and height"),
-    (["--single", "a.png", "-o", "o", "--png", "--input-cfg", "a.json", "--output-cfg", "b.json"], "config-file mode"),
+    (["--single", "a.png", "-o", "o", "--png", "--input-cfg", "does_not_exist.json", "--output-cfg", "b.json"],
+     "Error: cannot open does_not_exist.json"),
+    (["--single", "a.png", "-o", "o", "--png"], "has no value"),
 ])
 def test_validation_messages_and_exit_code(cli, tmp_path, args, message):
     args = [a if a != "o" else str(tmp_path / "o") for a in args]
@@ -96,6 +98,71 @@ def test_dry_run_creates_directory_and_stops(cli, tmp_path):
     assert out.is_dir()
 
 
+# ------------------------------------------------------------------ config-file mode (CPU: --dry-run)
+CONFIGS = {
+    "rectilinear": ({"type": "PERSP", "lens_unit": "MILLIMETERS", "focal_length": 18.0}, [36.0, 24.0]),
+    "fov": ({"type": "PERSP", "lens_unit": "FOV", "angle": 1.5707963705062866}, [36.0, 36.0]),
+    "equidistant": ({"type": "PANO", "panorama_type": "FISHEYE_EQUIDISTANT", "fisheye_fov": 3.1415927410125732}, [36.0, 36.0]),
+    "equisolid": ({"type": "PANO", "panorama_type": "FISHEYE_EQUISOLID", "fisheye_lens": 12.5,
+                   "fisheye_fov": 3.1415927410125732}, [36.0, 36.0]),
+    "equirect": ({"type": "PANO", "panorama_type": "EQUIRECTANGULAR", "latitude_min": -1.5707963705062866,
+                  "latitude_max": 1.5707963705062866, "longitude_min": -3.1415927410125732,
+                  "longitude_max": 3.1415927410125732}, [0.0, 0.0]),
+}
+
+
+@pytest.mark.parametrize("in_kind", sorted(CONFIGS))
+def test_config_mode_rewrites_camera_resolution_and_frames(cli, tmp_path, in_kind):
+    import json
+
+    cam, sensor = CONFIGS[in_kind]
+    cfg = {"camera": cam, "resolution": [640, 480], "sensor_size": sensor, "custom": {"kept": [1, 2.5, "x", None, True]},
+           "frames": [{"name": "shot_0001.exr", "pose": [1.0, 2.0]}, {"name": "other.exr"}, {"name": "shot_0002.exr"}]}
+    (tmp_path / "in.json").write_text(json.dumps(cfg))
+    out_json = tmp_path / "out.json"
+    r = run(cli, "-i", tmp_path, "-o", tmp_path / "o", "--exr", "--input-cfg", tmp_path / "in.json", "--output-cfg", out_json,
+            "--rectilinear", "24,36", "--scale", "0.5", "--filter-prefix", "shot_", "--dry-run")
+    assert r.returncode == 0, r.stdout
+    assert "Found camera config: {" in r.stdout and f"Saving output config: {out_json}" in r.stdout
+    assert r.stdout.endswith("Dry-run. Exiting.\n")
+    out = json.loads(out_json.read_text())
+    assert out["custom"] == cfg["custom"]                       # unknown keys survive
+    assert out["resolution"] == [320, 240]                      # int(ires * scale)
+    assert [f["name"] for f in out["frames"]] == ["shot_0001.exr", "shot_0002.exr"]
+    assert out["frames"][0]["pose"] == [1.0, 2.0]
+    f32 = lambda v: float(np.float32(v))  # noqa: E731
+    assert out["sensor_size"] == [36.0, f32(np.float32(240.0) / np.float32(320.0) * np.float32(36.0))]
+    c = out["camera"]
+    assert c["type"] == "PERSP" and c["lens_unit"] == "MILLIMETERS" and c["focal_length"] == 24.0
+    m = np.array(c["projection_matrix"], dtype=np.float64)
+    assert m.shape == (4, 4)
+    assert m[0, 0] == f32(np.float32(2.0) * np.float32(24.0) / np.float32(36.0))
+    assert m[1, 1] == f32(np.float32(2.0) * np.float32(24.0) / np.float32(out["sensor_size"][1]))
+    assert m[3, 2] == -1.0 and m[2, 2] == f32(-(np.float32(100.0) + np.float32(0.1)) / (np.float32(100.0) - np.float32(0.1)))
+
+
+def test_config_mode_output_lens_templates(cli, tmp_path):
+    import json
+
+    cam, sensor = CONFIGS["rectilinear"]
+    (tmp_path / "in.json").write_text(json.dumps({"camera": cam, "resolution": [64, 32], "sensor_size": sensor}))
+    for flags, expect in ((["--equidistant", "3.1415927"], {"type": "PANO", "panorama_type": "FISHEYE_EQUIDISTANT"}),
+                          (["--equirectangular", "full"], {"type": "PANO", "panorama_type": "RECTILINEAR"}),  # (sic) config.cpp:98
+                          (["--equisolid", "10.5,36,3.14"], {"type": "PANO", "panorama_type": "FISHEYE_EQUISOLID"}),
+                          (["--no-reproject"], {"type": "PERSP", "focal_length": 18.0})):
+        r = run(cli, "-i", tmp_path, "-o", tmp_path / "o", "--png", "--input-cfg", tmp_path / "in.json", "--output-cfg",
+                tmp_path / "out.json", *flags, "--dry-run")
+        assert r.returncode == 0, r.stdout
+        c = json.loads((tmp_path / "out.json").read_text())["camera"]
+        for k, v in expect.items():
+            assert c[k] == v, (flags, k)
+    for bad in ({"type": "ORTHO"}, {"type": "PERSP", "lens_unit": "INCHES"}):
+        (tmp_path / "bad.json").write_text(json.dumps({"camera": bad, "resolution": [64, 32], "sensor_size": sensor}))
+        r = run(cli, "-i", tmp_path, "-o", tmp_path / "o", "--png", "--input-cfg", tmp_path / "bad.json", "--output-cfg",
+                tmp_path / "out.json", "--rectilinear", "18,36", "--dry-run")
+        assert r.returncode == 1 and ("Unknown camera_type" in r.stdout or "Unknown lens_unit" in r.stdout)
+
+
 # ------------------------------------------------------------------ codecs through the copy path (CPU)
 def test_png_codec_conventions_copy_path(cli, tmp_path):
     """--no-reproject --scale 1 is a memcpy (src/main.cpp:592-595): PNG in -> float -> PNG out
@@ -109,7 +176,7 @@ def test_png_codec_conventions_copy_path(cli, tmp_path):
     grey = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
     Image.fromarray(grey, "L").save(tmp_path / "b_grey.png")
     g16 = rng.integers(0, 65536, size=(h, w), dtype=np.uint16)
-    Image.fromarray(g16, "I;16").save(tmp_path / "c_grey16.png")
+    Image.fromarray(g16).save(tmp_path / "c_grey16.png")  # uint16 -> 16-bit greyscale PNG
     out = tmp_path / "out"
     r = run(cli, "-i", tmp_path, "-o", out, "--png", "--no-configs", f"{w},{h}", "--i-equirectangular", "full", "--no-reproject")
     assert r.returncode == 0, r.stdout + r.stderr
@@ -217,6 +284,33 @@ def test_directory_run_filters_order_skip_and_threads(cli, lrp, oracle, torch_cu
     # resume: everything exists now
     r2 = run(cli, *args, "--skip-if-exists")
     assert r2.returncode == 0 and r2.stdout.count("Already exists.") == 3
+
+
+@pytest.mark.gpu
+def test_config_mode_run_equals_oracle(cli, lrp, oracle, torch_cuda, tmp_path):
+    import json
+
+    rng = np.random.default_rng(21)
+    w, h = 80, 60
+    ch = {n: rng.random((h, w)).astype(np.float16) for n in "RGBA"}
+    exr_util.write_exr(str(tmp_path / "fish.exr"), ch, 2)
+    cam, sensor = CONFIGS["equidistant"]
+    (tmp_path / "in.json").write_text(json.dumps({"camera": cam, "resolution": [w, h], "sensor_size": sensor}))
+    out = tmp_path / "out"
+    r = run(cli, "--single", tmp_path / "fish.exr", "-o", out, "--exr", "--input-cfg", tmp_path / "in.json", "--output-cfg",
+            tmp_path / "out.json", "--rectilinear", "18,36", "--rotation", "10,5,0")
+    assert r.returncode == 0, r.stdout + r.stderr
+    src = np.stack([ch[n].astype(np.float32) for n in "RGBA"], axis=2)
+    lin = lrp.LensInfo(lrp.LensType.FISHEYE_EQUIDISTANT, (cam["fisheye_fov"],), 36.0, 36.0)
+    lout = lrp.LensInfo.rectilinear(18.0, 36.0, w, h)
+    d2r = lambda d: float(np.float32(d / 180.0 * math.pi))  # noqa: E731
+    rot = lrp.rotation_matrix(d2r(10.0), d2r(5.0), d2r(0.0))
+    want = oracle.reproject(lin, src, lout, w, h, 1, 2, rot)
+    back = exr_util.read_exr(str(out / "fish.exr"))
+    for i, n in enumerate("RGBA"):
+        w16 = want[..., i].astype(np.float16)
+        assert ((back[n].view(np.uint16) == w16.view(np.uint16)) | (np.isnan(back[n]) & np.isnan(w16))).all(), n
+    assert json.loads((tmp_path / "out.json").read_text())["camera"]["focal_length"] == 18.0
 
 
 @pytest.mark.gpu
