@@ -36,7 +36,7 @@
 #include "lrp_device.h"
 
 #ifndef LRP_ABLATE
-#define LRP_ABLATE 0 // 1..4: timing-only experiment builds (tools/ablate.sh); never shipped
+#define LRP_ABLATE 0 // 1, 2, 7: timing-only experiment builds (tools/ablate.sh); never shipped
 #endif
 #ifndef LRP_TILE_MINWAVES
 #define LRP_TILE_MINWAVES 1 // __launch_bounds__ waves per SIMD of the tile kernel
@@ -500,19 +500,6 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
 //     immediates 0/16/32/48.
 // A block with a border / seam / NaN pixel, or a window larger than the per-wave
 // LDS budget (strong minification), takes sample_direct() per pass instead.
-#if LRP_ABLATE == 5 // diagnostic build: per-phase wave-cycle sums (tools/ablate.sh 5; kbench prints them)
-__device__ unsigned long long g_lrp_stamps[8];
-#define LRP_STAMP(var)                                                                              \
-  unsigned long long var;                                                                           \
-  __builtin_amdgcn_sched_barrier(0);                                                                \
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                       \
-  __builtin_amdgcn_sched_barrier(0)
-#define LRP_ACC(i, a, b) st_sum##i += (b) - (a)
-#else
-#define LRP_STAMP(var)
-#define LRP_ACC(i, a, b)
-#endif
-
 #ifndef LRP_WIN_CAP
 #define LRP_WIN_CAP 640
 #endif
@@ -622,29 +609,14 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
     }
   };
 
-#if LRP_ABLATE == 5
-  unsigned long long st_sum0 = 0, st_sum1 = 0, st_sum2 = 0, st_sum3 = 0, st_sum4 = 0;
-#endif
   WinBlock cur, nxt;
-  LRP_STAMP(t_a);
   coords(0, cur);
-  LRP_STAMP(t_b);
   issue(0, cur);
-  LRP_STAMP(t_c);
-  LRP_ACC(0, t_a, t_b);
-  LRP_ACC(1, t_b, t_c);
 #pragma unroll 1
   for (int g = 0; g < G; ++g) {
-    LRP_STAMP(t0);
     if (g + 1 < G) coords(g + 1, nxt);
-    LRP_STAMP(t1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // window g has landed (also retires block g-1's stores)
-    LRP_STAMP(t2);
     if (kWinBuffers == 2 && g + 1 < G) issue(g + 1, nxt);
-    LRP_STAMP(t3);
-    LRP_ACC(0, t0, t1);
-    LRP_ACC(2, t1, t2);
-    LRP_ACC(1, t2, t3);
     const float4 *const win = win0 + (g & (kWinBuffers - 1)) * kWinCap;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -699,21 +671,7 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
     }
     if (kWinBuffers == 1 && g + 1 < G) issue(g + 1, nxt); // the window is free again: every tap of block g has been read
     cur = nxt;
-    LRP_STAMP(t4);
-    LRP_ACC(3, t3, t4);
   }
-#if LRP_ABLATE == 5
-  LRP_STAMP(t_end);
-  LRP_ACC(4, t_a, t_end);
-  if (lane == 0) {
-    atomicAdd(&g_lrp_stamps[0], st_sum0);
-    atomicAdd(&g_lrp_stamps[1], st_sum1);
-    atomicAdd(&g_lrp_stamps[2], st_sum2);
-    atomicAdd(&g_lrp_stamps[3], st_sum3);
-    atomicAdd(&g_lrp_stamps[4], st_sum4);
-    atomicAdd(&g_lrp_stamps[7], 1ull);
-  }
-#endif
 }
 
 using TileKernelFn = void (*)(const KParams);

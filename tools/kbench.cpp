@@ -8,7 +8,6 @@
 // Build (tools/build_kbench.sh):
 //   hipcc -O2 -std=c++17 tools/kbench.cpp -Iinclude -L<pkg>/lib -llrp_hip -Wl,-rpath,<pkg>/lib -o tools/kbench
 // Usage: kbench [--size N] [--reps R] [--distinct D] [--channels C] [--ns S] [--sum] [workload ...]
-#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -176,17 +175,6 @@ int main(int argc, char **argv) {
            best * 1e3, (double)out_size * out_size / avg_s / 1e9, bytes / avg_s / 1e9, bytes / avg_s / 8e12);
     if (sum) printf("  fnv %016llx", (unsigned long long)h);
     printf("\n");
-    // diagnostic builds (tools/ablate.sh 5) export per-phase wave-cycle sums
-    typedef int (*stamps_fn)(unsigned long long *, int);
-    if (stamps_fn fn = (stamps_fn)dlsym(RTLD_DEFAULT, "lrp_debug_read_stamps")) {
-      unsigned long long st[8];
-      HIP_OK(hipDeviceSynchronize());
-      if (fn(st, 1) == 0 && st[7] > 0) {
-        printf("    stamps per wave (cycles): coords %.0f  dma-issue %.0f  dma-wait %.0f  taps+cubic+store %.0f  total %.0f  (waves %llu)\n",
-               (double)st[0] / st[7], (double)st[1] / st[7], (double)st[2] / st[7], (double)st[3] / st[7],
-               (double)st[4] / st[7], st[7]);
-      }
-    }
     fflush(stdout);
   }
   return 0;
