@@ -253,24 +253,24 @@ template <int OutLens> __device__ __forceinline__ ColTerms column_terms(const KP
   return c;
 }
 
-// One sub-sample of output pixel (column terms `col`, row ye) -> top-left-origin
-// source texel coordinates.  All 64 lanes must be active (wave-wide vote inside).
-template <int OutLens, int InMode, bool OneSample = false>
-__device__ __forceinline__ void pixel_source(const KParams &P, const ColTerms col, int ye, int ssy, float &sx,
-                                             float &sy) {
-  const int ns = OneSample ? 1 : P.num_samples; // OneSample: the caller guarantees num_samples == 1 (ssy == 0)
+// One sub-sample of output pixel (column terms `col`, row term `row_v` of row ye) ->
+// top-left-origin source texel coordinates.  All 64 lanes must be active (wave-wide vote
+// inside).  row_v is unused for the equidistant target; ye / ssy are only used by it.
+template <int OutLens, int InMode>
+__device__ __forceinline__ void pixel_source_rt(const KParams &P, const ColTerms col, float row_v, int ye, int ssy,
+                                                float &sx, float &sy) {
   float vx, vy, vz;
   if constexpr (OutLens == kRect) {
     vx = col.a;
-    vy = P.row_tab[OneSample ? ye : ye * ns + ssy];
+    vy = row_v;
     vz = -1.0f;
   } else if constexpr (OutLens == kEquirect) {
     vx = col.a;
     vz = col.b;
-    vy = P.row_tab[OneSample ? ye : ye * ns + ssy];
+    vy = row_v;
   } else {
-    const float cy = ((float)ye + 0.5f) - (float)P.out_h * 0.5f;               // :288
-    const float scy = cy + ((float)ssy + 1.0f) / ((float)ns + 1.0f) - 0.5f;    // :298
+    const float cy = ((float)ye + 0.5f) - (float)P.out_h * 0.5f;                       // :288
+    const float scy = cy + ((float)ssy + 1.0f) / ((float)P.num_samples + 1.0f) - 0.5f; // :298
     equidistant_ray_v2(P, col.a, scy, vx, vy, vz);
   }
   if (P.has_rot) { // :303-311
@@ -291,6 +291,20 @@ __device__ __forceinline__ void pixel_source(const KParams &P, const ColTerms co
   sx = (px - 0.5f) + (float)P.in_w * 0.5f; // :323-324
   sy = (py - 0.5f) + (float)P.in_h * 0.5f;
 #endif
+}
+
+// Row term of output row ye, sub-sample ssy (0 for the equidistant target, which has none).
+template <int OutLens> __device__ __forceinline__ float row_term(const KParams &P, int ye, int ssy) {
+  if constexpr (OutLens == kEquidistant)
+    return 0.0f;
+  else
+    return P.row_tab[ye * P.num_samples + ssy];
+}
+
+template <int OutLens, int InMode>
+__device__ __forceinline__ void pixel_source(const KParams &P, const ColTerms col, int ye, int ssy, float &sx,
+                                             float &sy) {
+  pixel_source_rt<OutLens, InMode>(P, col, row_term<OutLens>(P, ye, ssy), ye, ssy, sx, sy);
 }
 
 // ---- one sample, taps straight from global memory -------------------------------
@@ -562,11 +576,19 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
     // v_max_i32 on the bits give the extremes (no canonicalising float min / max).
     int exact = 1;
     int lo_x = 0x7fffffff, lo_y = 0x7fffffff, hi_x = (int)0x80000000, hi_y = (int)0x80000000;
+    // the four row terms first, all loads in flight together (one exposed latency per
+    // block instead of one in front of every pixel's coordinate chain)
+    float row_v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yk = y_lane + 16 * g + 4 * k;
+      row_v[k] = row_term<OutLens>(P, yk < P.out_h ? yk : P.out_h - 1, 0);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int yk = y_lane + 16 * g + 4 * k;
       const int ye = yk < P.out_h ? yk : P.out_h - 1;
-      pixel_source<OutLens, InMode, true>(P, col, ye, 0, b.sx[k], b.sy[k]);
+      pixel_source_rt<OutLens, InMode>(P, col, row_v[k], ye, 0, b.sx[k], b.sy[k]);
       exact &= (int)(((b.sx[k] + 2.0f) - b.sx[k]) == 2.0f) & (int)(((b.sy[k] + 2.0f) - b.sy[k]) == 2.0f);
       const int bx = (int)f2u(b.sx[k]), by = (int)f2u(b.sy[k]);
       lo_x = min(lo_x, bx);
