@@ -198,24 +198,31 @@ int parse_equidistant(const std::string &lstr, lrp_lens &li) {
   return 0;
 }
 
+std::vector<std::string> split_commas(const std::string &text) {
+  std::vector<std::string> parts;
+  size_t begin = 0;
+  while (true) {
+    const size_t comma = text.find(',', begin);
+    parts.push_back(text.substr(begin, comma == std::string::npos ? std::string::npos : comma - begin));
+    if (comma == std::string::npos) return parts;
+    begin = comma + 1;
+  }
+}
+
+// "full" or longitude_min,longitude_max,latitude_min,latitude_max in radians (src/main.cpp:58-95)
 int parse_equirectangular(const std::string &lstr, lrp_lens &li) {
   if (lstr == "full") {
     lrp_lens_equirectangular_full(&li);
     return 0;
   }
-  double v[4] = {0, 0, 0, 0};
-  int argidx = 0;
-  for (size_t b = 0, e = lstr.find(",");; b = e + 1, e = lstr.find(",", e + 1)) {
-    const double fa = std::atof(lstr.substr(b, e == std::string::npos ? std::string::npos : e - b).c_str());
-    if (argidx < 4) v[argidx] = fa;
-    argidx++;
-    if (e == std::string::npos) break;
-  }
-  if (argidx != 4) {
-    std::printf("Error: expected 4 arguments for equirectangular, got %d.\n", argidx);
+  const std::vector<std::string> parts = split_commas(lstr);
+  if (parts.size() != 4) {
+    std::printf("Error: expected 4 arguments for equirectangular, got %d.\n", (int)parts.size());
     return 1;
   }
-  lrp_lens_equirectangular(&li, (float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  // parsed as double, narrowed to float on assignment, like the reference
+  lrp_lens_equirectangular(&li, (float)std::atof(parts[0].c_str()), (float)std::atof(parts[1].c_str()),
+                           (float)std::atof(parts[2].c_str()), (float)std::atof(parts[3].c_str()));
   return 0;
 }
 
