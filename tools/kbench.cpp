@@ -7,7 +7,7 @@
 //
 // Build (tools/build_kbench.sh):
 //   hipcc -O2 -std=c++17 tools/kbench.cpp -Iinclude -L<pkg>/lib -llrp_hip -Wl,-rpath,<pkg>/lib -o tools/kbench
-// Usage: kbench [--size N] [--reps R] [--distinct D] [--channels C] [--ns S] [--sum] [workload ...]
+// Usage: kbench [--size N] [--reps R] [--warmup W] [--distinct D] [--channels C] [--ns S] [--sum] [workload ...]
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -84,7 +84,7 @@ static uint64_t fnv1a(const void *p, size_t n) {
 }
 
 int main(int argc, char **argv) {
-  int size = 4096, reps = 20, distinct = 4, channels = 4, ns = 1, out_size = 0;
+  int size = 4096, reps = 20, distinct = 4, channels = 4, ns = 1, out_size = 0, warmup = 100;
   bool sum = false, post = false;
   std::vector<std::string> names;
   for (int i = 1; i < argc; ++i) {
@@ -93,6 +93,7 @@ int main(int argc, char **argv) {
     if (a == "--size") size = next();
     else if (a == "--out-size") out_size = next();
     else if (a == "--reps") reps = next();
+    else if (a == "--warmup") warmup = next();
     else if (a == "--distinct") distinct = next();
     else if (a == "--channels") channels = next();
     else if (a == "--ns") ns = next();
@@ -149,19 +150,36 @@ int main(int argc, char **argv) {
       out.data = dst[i % distinct];
       LRP_OKAY(lrp_reproject_device(&in, &out, ns, W->interp, W->has_rot ? rot : nullptr, post ? &pp : nullptr, 0, stream));
     };
-    for (int i = 0; i < 3; ++i) launch(i);
+    // ~20 ms of back-to-back launches first: the chip settles its clock over ~10 ms of load
+    for (int i = 0; i < warmup; ++i) launch(i);
+    HIP_OK(hipStreamSynchronize(stream));
+    // all launches queued back to back, one event pair each (no host sync in between:
+    // the chip stays at its loaded clock, as in a batch run)
+    std::vector<hipEvent_t> ev((size_t)reps + 1);
+    for (auto &e : ev) HIP_OK(hipEventCreate(&e));
+    HIP_OK(hipEventRecord(ev[0], stream));
+    for (int i = 0; i < reps; ++i) {
+      launch(i);
+      HIP_OK(hipEventRecord(ev[(size_t)i + 1], stream));
+    }
     HIP_OK(hipStreamSynchronize(stream));
     float best = 1e30f, total = 0;
     for (int i = 0; i < reps; ++i) {
-      HIP_OK(hipEventRecord(e0, stream));
-      launch(i);
-      HIP_OK(hipEventRecord(e1, stream));
-      HIP_OK(hipEventSynchronize(e1));
       float ms;
-      HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+      HIP_OK(hipEventElapsedTime(&ms, ev[(size_t)i], ev[(size_t)i + 1]));
       total += ms;
       if (ms < best) best = ms;
     }
+    if (getenv("KBENCH_SERIES")) {
+      printf("    series(us):");
+      for (int i = 0; i < reps; ++i) {
+        float ms;
+        HIP_OK(hipEventElapsedTime(&ms, ev[(size_t)i], ev[(size_t)i + 1]));
+        printf(" %.0f", ms * 1e3);
+      }
+      printf("\n");
+    }
+    for (auto &e : ev) HIP_OK(hipEventDestroy(e));
     const double avg_s = total / reps * 1e-3;
     const double bytes = (double)(in_elems + out_elems) * 4;
     uint64_t h = 0;
