@@ -537,7 +537,12 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
 #endif
 constexpr int kWinBuffers = LRP_WIN_BUFFERS; // 2: DMA of block g+1 under the cubics of block g; 1: under its own coordinates only
 constexpr int kWinCap = LRP_WIN_CAP; // float4 texels per window buffer: 10 KiB per wavefront, 40 KiB per workgroup -> 4 workgroups / CU
-constexpr int kBlk = 16;     // output block edge per wavefront
+#ifndef LRP_WIN_BLOCK_W
+#define LRP_WIN_BLOCK_W 16
+#endif
+constexpr int kBlkW = LRP_WIN_BLOCK_W;  // output block per wavefront: kBlkW x kBlkH = 256 pixels,
+constexpr int kBlkH = 256 / kBlkW;      // 4 passes of kBlkW columns x (64 / kBlkW) rows
+constexpr int kPassRows = 64 / kBlkW;
 
 // Source coordinates and window of one 16 x 16 block (4 pixels per lane).
 struct WinBlock {
@@ -570,8 +575,8 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int G = P.blocks_per_wave;
   // workgroup tile = 64 x 16G: four strips of G blocks side by side, one per wavefront
-  const int x = tx * (kBlk * kT2Waves) + wave * kBlk + (lane & 15);
-  const int y_lane = P.y_offset + ty * (kBlk * G) + (lane >> 4); // + 16 * g + 4 * pass
+  const int x = tx * (kBlkW * kT2Waves) + wave * kBlkW + (lane & (kBlkW - 1));
+  const int y_lane = P.y_offset + ty * (kBlkH * G) + lane / kBlkW; // + kBlkH * g + kPassRows * pass
   const int xe = x < P.out_w ? x : P.out_w - 1;
   const int in_w = P.in_w;
   const SrcView src = source_view<2, 4>(P);
@@ -593,12 +598,12 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
     float row_v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int yk = y_lane + 16 * g + 4 * k;
+      const int yk = y_lane + kBlkH * g + kPassRows * k;
       row_v[k] = row_term<OutLens>(P, yk < P.out_h ? yk : P.out_h - 1, 0);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int yk = y_lane + 16 * g + 4 * k;
+      const int yk = y_lane + kBlkH * g + kPassRows * k;
       const int ye = yk < P.out_h ? yk : P.out_h - 1;
       pixel_source_rt<OutLens, InMode>(P, col, row_v[k], ye, 0, b.sx[k], b.sy[k]);
       exact &= (int)(((b.sx[k] + 2.0f) - b.sx[k]) == 2.0f) & (int)(((b.sy[k] + 2.0f) - b.sy[k]) == 2.0f);
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
       // num_samples == 1: (0.0f + s) * normalize (src/reproject.cpp:334-341)
       Rgba a = px_zero<4>();
       px_add<4>(a, s);
-      const int yk = y_lane + 16 * g + 4 * k;
+      const int yk = y_lane + kBlkH * g + kPassRows * k;
 #if defined(LRP_NO_STORE) // timing experiment: almost no output traffic
       if (x < P.out_w && yk < P.out_h && a.lo.x == 12345.678f) store_px<4>(P, (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x, a);
 #else
@@ -758,10 +763,10 @@ struct WinKernelTable {
 
 // num_samples must be 1 (the pipeline keeps no accumulator across sub-samples).
 inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, hipStream_t stream) {
-  P.tiles_x = (P.out_w + kBlk * kT2Waves - 1) / (kBlk * kT2Waves);
+  P.tiles_x = (P.out_w + kBlkW * kT2Waves - 1) / (kBlkW * kT2Waves);
   const int rows = P.out_h - P.y_offset;
   // strips of 4 blocks when that still leaves >= 8 workgroups per CU, else shorter
-  const int row_blocks = (rows + kBlk - 1) / kBlk;
+  const int row_blocks = (rows + kBlkH - 1) / kBlkH;
   int G = LRP_WIN_STRIP;
   while (G > 1 && (long long)P.tiles_x * ((row_blocks + G - 1) / G) < 2048) G >>= 1;
   P.blocks_per_wave = G;
