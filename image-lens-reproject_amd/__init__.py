@@ -201,7 +201,8 @@ PIXEL_KERNEL, TILE_KERNEL, WINDOW_KERNEL = 0, 1, 2
 
 def debug_kernel(choice=-1):
     """lrp_debug_kernel: select the HIP kernel family (0 pixel, 1 tile, 2 tile + LDS-window
-    bicubic; all produce the same bits); returns the previous choice.  -1 only queries."""
+    bicubic, 3 the same without shared tap coefficients; all produce the same bits);
+    returns the previous choice.  -1 only queries."""
     return _native.load().lrp_debug_kernel(int(choice))
 
 

@@ -158,12 +158,13 @@ lrp::KParams make_params(const lrp_image *in, const lrp_image *out, int num_samp
 // LRP_KERNEL=pixel is set in the environment (A/B checks) — takes the
 // one-pixel-per-lane kernel (lrp_kernel_impl.h).  Both are HIP; there is no CPU path.
 // 0 = pixel kernel, 1 = tile kernel everywhere, 2 (default) = tile kernel with the
-// LDS-window kernel for bicubic.  Initialised from LRP_KERNEL=pixel|tile, changed
+// LDS-window kernel for bicubic, 3 = the same without its shared-coefficient tier.  Initialised from LRP_KERNEL=pixel|tile|window-raw, changed
 // at run time by lrp_debug_kernel().
 std::atomic<int> g_kernel_choice{[] {
   const char *v = std::getenv("LRP_KERNEL");
   if (v && std::strcmp(v, "pixel") == 0) return 0;
   if (v && std::strcmp(v, "tile") == 0) return 1;
+  if (v && std::strcmp(v, "window-raw") == 0) return 3;
   return 2;
 }()};
 int kernel_choice() { return g_kernel_choice.load(std::memory_order_relaxed); }
@@ -194,8 +195,10 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
       e = lrp::launch_tile_nearest(P, oi, im, stream);
     else if (interpolation == LRP_BILINEAR)
       e = lrp::launch_tile_bilinear(P, oi, im, stream);
-    else if (kernel_choice() == 2 && num_samples == 1 && out->channels == 4)
+    else if (kernel_choice() >= 2 && num_samples == 1 && out->channels == 4) {
+      P.win_coef = kernel_choice() == 2;
       e = lrp::launch_win_bicubic(P, oi, im, stream);
+    }
     else
       e = lrp::launch_tile_bicubic(P, oi, im, stream);
   } else if (interpolation == LRP_NEAREST)
@@ -263,7 +266,7 @@ extern "C" {
 int lrp_abi_version(void) { return LRP_ABI_VERSION; }
 
 int lrp_debug_kernel(int choice) {
-  if (choice < 0 || choice > 2) return kernel_choice();
+  if (choice < 0 || choice > 3) return kernel_choice();
   return g_kernel_choice.exchange(choice, std::memory_order_relaxed);
 }
 

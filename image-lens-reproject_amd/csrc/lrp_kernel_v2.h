@@ -88,6 +88,36 @@ template <bool Max> __device__ __forceinline__ int wave_extreme(int v) {
   return pick<Max>(pick<Max>(a, b), pick<Max>(c, d));
 }
 
+// Wave-wide minima / maxima of six signed values (x range of a block, y ranges of its
+// two halves) in 36 DPP-fused instructions: the butterfly runs inside v_min_i32 /
+// v_max_i32 themselves (DPP on src0), the independent chains are interleaved (a VGPR
+// written by a VALU instruction needs two wait states before a DPP read; five other
+// instructions sit in between), and the last two steps fold the 16-lane rows with
+// row_bcast:15 / row_bcast:31 so that lane 63 holds the result.
+__device__ __forceinline__ void wave_box(int &lo_x, int &hi_x, int &lo_ya, int &hi_ya, int &lo_yb, int &hi_yb) {
+#define LRP_BOX_STEP(CTRL)                                     \
+  "v_min_i32_dpp %0, %0, %0 " CTRL "\n"                         \
+  "v_max_i32_dpp %1, %1, %1 " CTRL "\n"                         \
+  "v_min_i32_dpp %2, %2, %2 " CTRL "\n"                         \
+  "v_max_i32_dpp %3, %3, %3 " CTRL "\n"                         \
+  "v_min_i32_dpp %4, %4, %4 " CTRL "\n"                         \
+  "v_max_i32_dpp %5, %5, %5 " CTRL "\n"
+  asm volatile("s_nop 1\n" LRP_BOX_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+               LRP_BOX_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+               LRP_BOX_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+               LRP_BOX_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+               LRP_BOX_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+               LRP_BOX_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+               : "+v"(lo_x), "+v"(hi_x), "+v"(lo_ya), "+v"(hi_ya), "+v"(lo_yb), "+v"(hi_yb));
+#undef LRP_BOX_STEP
+  lo_x = __builtin_amdgcn_readlane(lo_x, 63);
+  hi_x = __builtin_amdgcn_readlane(hi_x, 63);
+  lo_ya = __builtin_amdgcn_readlane(lo_ya, 63);
+  hi_ya = __builtin_amdgcn_readlane(hi_ya, 63);
+  lo_yb = __builtin_amdgcn_readlane(lo_yb, 63);
+  hi_yb = __builtin_amdgcn_readlane(hi_yb, 63);
+}
+
 __device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == ~0ull; }
 
 // ---- ray -> source coordinates with hoisted constants --------------------------
@@ -173,6 +203,9 @@ template <int CH> __device__ __forceinline__ void px_add(Px<CH> &a, const Px<CH>
 
 // cubicInterpolate (src/reproject.cpp:92-98), same association order as catmull_rom().
 __device__ __forceinline__ f2 catmull_rom2(const f2 a, const f2 b, const f2 c, const f2 d, float t, float half_t) {
+#if defined(LRP_SCALAR_CUBIC) // timing experiment: one VOP2 / VOP3 instruction per channel instead of packed pairs
+  return f2{catmull_rom(a.x, b.x, c.x, d.x, t, half_t), catmull_rom(a.y, b.y, c.y, d.y, t, half_t)};
+#endif
   const f2 inner = ((3.0f * (b - c)) + d) - a;
   const f2 mid = ((((2.0f * a) - (5.0f * b)) + (4.0f * c)) - d) + t * inner;
   const f2 outer = (c - a) + t * mid;
@@ -535,6 +568,10 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
 #ifndef LRP_WIN_BUFFERS
 #define LRP_WIN_BUFFERS 1
 #endif
+#ifndef LRP_WIN_COEF
+#define LRP_WIN_COEF 1
+#endif
+constexpr bool kWinCoef = LRP_WIN_COEF != 0 && LRP_WIN_BUFFERS == 1 && LRP_ABLATE == 0; // coefficient tier (below)
 constexpr int kWinBuffers = LRP_WIN_BUFFERS; // 2: DMA of block g+1 under the cubics of block g; 1: under its own coordinates only
 constexpr int kWinCap = LRP_WIN_CAP; // float4 texels per window buffer: 10 KiB per wavefront, 40 KiB per workgroup -> 4 workgroups / CU
 #ifndef LRP_WIN_BLOCK_W
@@ -549,6 +586,10 @@ struct WinBlock {
   float sx[4], sy[4];
   int x_lo, y_lo, bw, bh, pitch; // window origin, size and row pitch in texels (wave-uniform)
   bool staged;                   // taps come from the LDS window (wave-uniform)
+  // coefficient tier (wave-uniform): per half of the block (passes 0-1, 2-3) the first
+  // int(sy) and the number of distinct int(sy) rows; a coefficient row has the window's pitch
+  int iy0[2], iyn[2], c_plane;
+  bool coef;
 };
 
 // One wavefront walks its strip of `blocks_per_wave` blocks top to bottom:
@@ -592,7 +633,8 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
     // and a negative coordinate makes the signed minimum negative, so v_min_i32 /
     // v_max_i32 on the bits give the extremes (no canonicalising float min / max).
     int exact = 1;
-    int lo_x = 0x7fffffff, lo_y = 0x7fffffff, hi_x = (int)0x80000000, hi_y = (int)0x80000000;
+    int lo_x = 0x7fffffff, hi_x = (int)0x80000000;
+    int lo_y[2] = {0x7fffffff, 0x7fffffff}, hi_y[2] = {(int)0x80000000, (int)0x80000000};
     // the four row terms first, all loads in flight together (one exposed latency per
     // block instead of one in front of every pixel's coordinate chain)
     float row_v[4];
@@ -606,32 +648,46 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
       const int yk = y_lane + kBlkH * g + kPassRows * k;
       const int ye = yk < P.out_h ? yk : P.out_h - 1;
       pixel_source_rt<OutLens, InMode>(P, col, row_v[k], ye, 0, b.sx[k], b.sy[k]);
-      exact &= (int)(((b.sx[k] + 2.0f) - b.sx[k]) == 2.0f) & (int)(((b.sy[k] + 2.0f) - b.sy[k]) == 2.0f);
+      const f2 sxy{b.sx[k], b.sy[k]};
+      const f2 back = (sxy + 2.0f) - sxy; // both coordinates in one packed add / subtract
+      exact &= (int)(back.x == 2.0f) & (int)(back.y == 2.0f);
       const int bx = (int)f2u(b.sx[k]), by = (int)f2u(b.sy[k]);
       lo_x = min(lo_x, bx);
       hi_x = max(hi_x, bx);
-      lo_y = min(lo_y, by);
-      hi_y = max(hi_y, by);
+      lo_y[k >> 1] = min(lo_y[k >> 1], by);
+      hi_y[k >> 1] = max(hi_y[k >> 1], by);
     }
-    b.staged = false;
-    b.x_lo = b.y_lo = b.bw = b.bh = b.pitch = 0;
+    b.staged = b.coef = false;
+    b.x_lo = b.y_lo = b.bw = b.bh = b.pitch = b.c_plane = 0;
+    b.iy0[0] = b.iy0[1] = b.iyn[0] = b.iyn[1] = 0;
     if (wave_all(exact != 0)) {
-      const int w_lo_x = wave_extreme<false>(lo_x), w_hi_x = wave_extreme<true>(hi_x);
-      const int w_lo_y = wave_extreme<false>(lo_y), w_hi_y = wave_extreme<true>(hi_y);
+      int w_lo_x = lo_x, w_hi_x = hi_x, w_lo_ya = lo_y[0], w_hi_ya = hi_y[0], w_lo_yb = lo_y[1], w_hi_yb = hi_y[1];
+      wave_box(w_lo_x, w_hi_x, w_lo_ya, w_hi_ya, w_lo_yb, w_hi_yb);
+      const int w_lo_y = min(w_lo_ya, w_lo_yb), w_hi_y = max(w_hi_ya, w_hi_yb);
       const int one = (int)f2u(1.0f);
       // 1 <= s < extent - 2 for every pixel: every tap index is int(s) - 1 .. int(s) + 2, unclamped
       if (w_lo_x >= one && w_lo_y >= one && w_hi_x < (int)f2u(src.x_hi) && w_hi_y < (int)f2u(src.y_hi)) {
-        // float -> int of the four wave-uniform extremes (VALU has the converter)
+        // float -> int of the wave-uniform extremes (VALU has the converter)
         const int x_first = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_lo_x));
-        const int y_first = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_lo_y));
         const int x_last = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_hi_x));
-        const int y_last = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_hi_y));
+        const int ya_first = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_lo_ya));
+        const int ya_last = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_hi_ya));
+        const int yb_first = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_lo_yb));
+        const int yb_last = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_hi_yb));
+        const int y_first = min(ya_first, yb_first), y_last = max(ya_last, yb_last);
         b.x_lo = x_first - 1;
         b.y_lo = y_first - 1;
         b.bw = x_last + 2 - b.x_lo + 1;
         b.bh = y_last + 2 - b.y_lo + 1;
         b.pitch = b.bw | 1; // odd: consecutive window rows start an odd number of 16 B slots apart
         b.staged = b.bw <= 64 && b.pitch * b.bh <= kWinCap;
+        // coefficient tier: three planes of pitch x iyn[h] tap-column origins behind the raw window
+        b.iy0[0] = ya_first;
+        b.iyn[0] = ya_last - ya_first + 1;
+        b.iy0[1] = yb_first;
+        b.iyn[1] = yb_last - yb_first + 1;
+        b.c_plane = b.pitch * max(b.iyn[0], b.iyn[1]);
+        b.coef = kWinCoef && P.win_coef != 0 && b.staged && b.pitch * b.bh + 3 * b.c_plane <= kWinCap;
       }
     }
   };
@@ -648,6 +704,41 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
     }
   };
 
+  // Coefficient tier.  Of the 17 operations of a vertical Catmull-Rom evaluation, 11
+  // depend on the four taps only, not on the weight:
+  //     inner = ((3 (b - c)) + d) - a,  m0 = (((2 a - 5 b) + 4 c) - d),  cma = c - a
+  //     k = b + hfy * (cma + fy * (m0 + fy * inner))          (src/reproject.cpp:92-98)
+  // Under magnification the pixels of a block share their tap columns, so those three
+  // terms are evaluated ONCE per tap-column origin of the window (a lane per origin,
+  // straight from the staged window) and stored behind it in three planes; a pixel
+  // then spends 6 instead of 17 operations per channel and column.  Same operations
+  // on the same operands in the same order: the result is the reference's, bit for bit.
+  auto precompute = [&](const WinBlock &b, int h) {
+    const int n = b.pitch * b.iyn[h]; // origins: every window column x every first tap row of this half
+    const float4 *const raw = win0 + (b.iy0[h] - 1 - b.y_lo) * b.pitch;
+    float4 *const planes = win0 + b.pitch * b.bh;
+#pragma unroll 1
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int idx = i0 + lane;
+      if (idx < n) {
+        // origin idx = row * pitch + column reads the window texels idx + {0, 1, 2, 3} * pitch
+        // (origins in the pad column of an odd pitch compute unused values from stale slots)
+        const float4 *t = raw + idx;
+        const Rgba ta = as_rgba(t[0]), tb = as_rgba(t[b.pitch]), tc = as_rgba(t[2 * b.pitch]), td = as_rgba(t[3 * b.pitch]);
+        Rgba inner, m0, cma;
+        inner.lo = ((3.0f * (tb.lo - tc.lo)) + td.lo) - ta.lo;
+        inner.hi = ((3.0f * (tb.hi - tc.hi)) + td.hi) - ta.hi;
+        m0.lo = (((2.0f * ta.lo) - (5.0f * tb.lo)) + (4.0f * tc.lo)) - td.lo;
+        m0.hi = (((2.0f * ta.hi) - (5.0f * tb.hi)) + (4.0f * tc.hi)) - td.hi;
+        cma.lo = tc.lo - ta.lo;
+        cma.hi = tc.hi - ta.hi;
+        planes[idx] = float4{inner.lo.x, inner.lo.y, inner.hi.x, inner.hi.y};
+        planes[b.c_plane + idx] = float4{m0.lo.x, m0.lo.y, m0.hi.x, m0.hi.y};
+        planes[2 * b.c_plane + idx] = float4{cma.lo.x, cma.lo.y, cma.hi.x, cma.hi.y};
+      }
+    }
+  };
+
   WinBlock cur, nxt;
   coords(0, cur);
   issue(0, cur);
@@ -658,55 +749,89 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
     if (kWinBuffers == 2 && g + 1 < G) issue(g + 1, nxt);
     const float4 *const win = win0 + (g & (kWinBuffers - 1)) * kWinCap;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      Rgba s;
-      if (cur.staged) {
-        const float tx_ = __builtin_truncf(cur.sx[k]), ty_ = __builtin_truncf(cur.sy[k]);
-        const float fx = cur.sx[k] - tx_, fy = cur.sy[k] - ty_;
-        const float4 *t = win + (__umul24((uint32_t)((int)ty_ - 1 - cur.y_lo), (uint32_t)cur.pitch) +
-                                 (uint32_t)((int)tx_ - 1 - cur.x_lo));
-        const float hfx = 0.5f * fx, hfy = 0.5f * fy;
-        const float4 *t1 = t + cur.pitch, *t2 = t1 + cur.pitch, *t3 = t2 + cur.pitch;
+    for (int h = 0; h < 2; ++h) {
+      if (kWinCoef && cur.coef) precompute(cur, h);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int k = 2 * h + kk;
+        Rgba s;
+        if (kWinCoef && cur.coef) {
+          const float tx_ = __builtin_truncf(cur.sx[k]), ty_ = __builtin_truncf(cur.sy[k]);
+          const float fx = cur.sx[k] - tx_, fy = cur.sy[k] - ty_;
+          const float hfx = 0.5f * fx, hfy = 0.5f * fy;
+          const int ix = (int)tx_ - 1 - cur.x_lo, iy = (int)ty_;
+          const float4 *ci = win + (cur.pitch * cur.bh + (iy - cur.iy0[h]) * cur.pitch + ix);
+          const float4 *cm = ci + cur.c_plane, *cc = cm + cur.c_plane;
+          const float4 *tb = win + ((iy - cur.y_lo) * cur.pitch + ix);
+          auto vert = [&](int j) {
+            const Rgba inner = as_rgba(ci[j]), m0 = as_rgba(cm[j]), cma = as_rgba(cc[j]), b1 = as_rgba(tb[j]);
+            Rgba r = px_zero<4>();
+            r.lo = b1.lo + hfy * (cma.lo + fy * (m0.lo + fy * inner.lo));
+            r.hi = b1.hi + hfy * (cma.hi + fy * (m0.hi + fy * inner.hi));
+            return r;
+          };
+          const Rgba k0 = vert(0), k1 = vert(1), k2 = vert(2), k3 = vert(3);
+          s = cubic4(k0, k1, k2, k3, fx, hfx);
+        } else if (cur.staged) {
+          const float tx_ = __builtin_truncf(cur.sx[k]), ty_ = __builtin_truncf(cur.sy[k]);
+          const float fx = cur.sx[k] - tx_, fy = cur.sy[k] - ty_;
+          const float4 *t = win + (__umul24((uint32_t)((int)ty_ - 1 - cur.y_lo), (uint32_t)cur.pitch) +
+                                   (uint32_t)((int)tx_ - 1 - cur.x_lo));
+          const float hfx = 0.5f * fx, hfy = 0.5f * fy;
+          const float4 *t1 = t + cur.pitch, *t2 = t1 + cur.pitch, *t3 = t2 + cur.pitch;
 #if LRP_ABLATE == 1 // timing experiment: taps loaded, no cubic arithmetic
-        Rgba z = as_rgba(t[0]);
-        for (int i = 0; i < 4; ++i) {
-          z.lo += as_rgba(t[i]).lo + as_rgba(t1[i]).lo + as_rgba(t2[i]).lo + as_rgba(t3[i]).lo;
-          z.hi += as_rgba(t[i]).hi + as_rgba(t1[i]).hi + as_rgba(t2[i]).hi + as_rgba(t3[i]).hi;
-        }
-        s = z;
-        (void)hfx;
-        (void)hfy;
+          Rgba z = as_rgba(t[0]);
+          for (int i = 0; i < 4; ++i) {
+            z.lo += as_rgba(t[i]).lo + as_rgba(t1[i]).lo + as_rgba(t2[i]).lo + as_rgba(t3[i]).lo;
+            z.hi += as_rgba(t[i]).hi + as_rgba(t1[i]).hi + as_rgba(t2[i]).hi + as_rgba(t3[i]).hi;
+          }
+          s = z;
+          (void)hfx;
+          (void)hfy;
 #elif LRP_ABLATE == 2 // timing experiment: cubic arithmetic on register data, one tap loaded
-        const Rgba q = as_rgba(t[0]);
-        (void)t1; (void)t2; (void)t3;
-        const Rgba q1{q.lo + fx, q.hi + fy, 0.0f}, q2{q.lo * fx, q.hi * fy, 0.0f}, q3{q.lo - fx, q.hi - fy, 0.0f};
-        const Rgba k0 = cubic4(q, q1, q2, q3, fy, hfy);
-        const Rgba k1 = cubic4(q1, q2, q3, q, fy, hfy);
-        const Rgba k2 = cubic4(q2, q3, q, q1, fy, hfy);
-        const Rgba k3 = cubic4(q3, q, q1, q2, fy, hfy);
-        s = cubic4(k0, k1, k2, k3, fx, hfx);
+          const Rgba q = as_rgba(t[0]);
+          (void)t1; (void)t2; (void)t3;
+          const Rgba q1{q.lo + fx, q.hi + fy, 0.0f}, q2{q.lo * fx, q.hi * fy, 0.0f}, q3{q.lo - fx, q.hi - fy, 0.0f};
+          const Rgba k0 = cubic4(q, q1, q2, q3, fy, hfy);
+          const Rgba k1 = cubic4(q1, q2, q3, q, fy, hfy);
+          const Rgba k2 = cubic4(q2, q3, q, q1, fy, hfy);
+          const Rgba k3 = cubic4(q3, q, q1, q2, fy, hfy);
+          s = cubic4(k0, k1, k2, k3, fx, hfx);
+#elif LRP_ABLATE == 8 // timing experiment: vertical cubics at the op count of precomputed tap coefficients (6 of 17 ops)
+          auto vert = [&](const Rgba a, const Rgba b, const Rgba c, const Rgba d) {
+            Rgba r = px_zero<4>();
+            r.lo = b.lo + hfy * (c.lo + fy * (a.lo + fy * d.lo));
+            r.hi = b.hi + hfy * (c.hi + fy * (a.hi + fy * d.hi));
+            return r;
+          };
+          const Rgba k0 = vert(as_rgba(t[0]), as_rgba(t1[0]), as_rgba(t2[0]), as_rgba(t3[0]));
+          const Rgba k1 = vert(as_rgba(t[1]), as_rgba(t1[1]), as_rgba(t2[1]), as_rgba(t3[1]));
+          const Rgba k2 = vert(as_rgba(t[2]), as_rgba(t1[2]), as_rgba(t2[2]), as_rgba(t3[2]));
+          const Rgba k3 = vert(as_rgba(t[3]), as_rgba(t1[3]), as_rgba(t2[3]), as_rgba(t3[3]));
+          s = cubic4(k0, k1, k2, k3, fx, hfx);
 #elif LRP_ABLATE == 7 // timing experiment: neither taps nor arithmetic
-        s = Rgba{f2{fx, fy}, f2{hfx, hfy}, 0.0f};
-        (void)t1; (void)t2; (void)t3;
+          s = Rgba{f2{fx, fy}, f2{hfx, hfy}, 0.0f};
+          (void)t1; (void)t2; (void)t3;
 #else
-        const Rgba k0 = cubic4(as_rgba(t[0]), as_rgba(t1[0]), as_rgba(t2[0]), as_rgba(t3[0]), fy, hfy);
-        const Rgba k1 = cubic4(as_rgba(t[1]), as_rgba(t1[1]), as_rgba(t2[1]), as_rgba(t3[1]), fy, hfy);
-        const Rgba k2 = cubic4(as_rgba(t[2]), as_rgba(t1[2]), as_rgba(t2[2]), as_rgba(t3[2]), fy, hfy);
-        const Rgba k3 = cubic4(as_rgba(t[3]), as_rgba(t1[3]), as_rgba(t2[3]), as_rgba(t3[3]), fy, hfy);
-        s = cubic4(k0, k1, k2, k3, fx, hfx);
+          const Rgba k0 = cubic4(as_rgba(t[0]), as_rgba(t1[0]), as_rgba(t2[0]), as_rgba(t3[0]), fy, hfy);
+          const Rgba k1 = cubic4(as_rgba(t[1]), as_rgba(t1[1]), as_rgba(t2[1]), as_rgba(t3[1]), fy, hfy);
+          const Rgba k2 = cubic4(as_rgba(t[2]), as_rgba(t1[2]), as_rgba(t2[2]), as_rgba(t3[2]), fy, hfy);
+          const Rgba k3 = cubic4(as_rgba(t[3]), as_rgba(t1[3]), as_rgba(t2[3]), as_rgba(t3[3]), fy, hfy);
+          s = cubic4(k0, k1, k2, k3, fx, hfx);
 #endif
-      } else {
-        s = sample_direct<2, Loop, 4>(P, src, cur.sx[k], cur.sy[k]);
-      }
-      // num_samples == 1: (0.0f + s) * normalize (src/reproject.cpp:334-341)
-      Rgba a = px_zero<4>();
-      px_add<4>(a, s);
-      const int yk = y_lane + kBlkH * g + kPassRows * k;
+        } else {
+          s = sample_direct<2, Loop, 4>(P, src, cur.sx[k], cur.sy[k]);
+        }
+        // num_samples == 1: (0.0f + s) * normalize (src/reproject.cpp:334-341)
+        Rgba a = px_zero<4>();
+        px_add<4>(a, s);
+        const int yk = y_lane + kBlkH * g + kPassRows * k;
 #if defined(LRP_NO_STORE) // timing experiment: almost no output traffic
-      if (x < P.out_w && yk < P.out_h && a.lo.x == 12345.678f) store_px<4>(P, (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x, a);
+        if (x < P.out_w && yk < P.out_h && a.lo.x == 12345.678f) store_px<4>(P, (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x, a);
 #else
-      if (x < P.out_w && yk < P.out_h) store_px<4>(P, (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x, a);
+        if (x < P.out_w && yk < P.out_h) store_px<4>(P, (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x, a);
 #endif
+      }
     }
     if (kWinBuffers == 1 && g + 1 < G) issue(g + 1, nxt); // the window is free again: every tap of block g has been read
     cur = nxt;

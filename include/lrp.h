@@ -108,11 +108,11 @@ const char *lrp_strerror(int status);
 const char *lrp_last_error(void);
 
 /* Three HIP kernel families compute the same bits: 0 = one pixel per lane
- * (any channel count), 1 = tile kernel (RGBA), 2 = tile kernel + LDS-window
+ * (any channel count), 1 = tile kernel (RGB / RGBA / RGBAZ), 2 = tile kernel + LDS-window
  * bicubic (default; the library picks the pixel kernel by itself where the others
- * do not apply).  Testing / A-B knob: sets the family for subsequent calls of all
+ * do not apply), 3 = as 2 with the window kernel's shared-coefficient tier switched off.  Testing / A-B knob: sets the family for subsequent calls of all
  * threads and returns the previous one; an out-of-range value only queries.
- * The environment variable LRP_KERNEL=pixel|tile sets the initial value. */
+ * The environment variable LRP_KERNEL=pixel|tile|window-raw sets the initial value. */
 int lrp_debug_kernel(int choice);
 /* Frees the cached per-output-lens tables of every device (after synchronising
  * them).  Optional: the cache is bounded and reused across calls. */

@@ -93,10 +93,11 @@ def test_4k_rgba_rows_against_oracle_and_kernel_families_agree(lrp, oracle, torc
     src_host = d_in.cpu().numpy()
     lin, lout = cases.lenses(lrp, n, n)[in_kind], cases.lenses(lrp, n, n)[out_kind]
     rot = cases.rotation(lrp, deg)
-    outs = [render(lrp, torch, lin, d_in, lout, n, n, 1, interp, rot, kernel=k) for k in (2, 1, 0)]
+    outs = [render(lrp, torch, lin, d_in, lout, n, n, 1, interp, rot, kernel=k) for k in (2, 1, 0, 3)]
     check_rows(oracle, lin, src_host, lout, n, n, 1, interp, rot, outs[0], name)
     assert same_bytes(torch, outs[0], outs[1]), f"{name}: window/tile kernels differ"
     assert same_bytes(torch, outs[0], outs[2]), f"{name}: tile/pixel kernels differ"
+    assert same_bytes(torch, outs[0], outs[3]), f"{name}: window kernel with / without shared tap coefficients differ"
     again = render(lrp, torch, lin, d_in, lout, n, n, 1, interp, rot)
     assert same_bytes(torch, outs[0], again), f"{name}: not deterministic"
 

@@ -51,7 +51,7 @@ def test_random_configuration(lrp, oracle, torch_cuda, seed):
     d_in = torch.from_numpy(src).cuda()
     for interp in (0, 1, 2):
         want = oracle.reproject(lin, src, lout, out_w, out_h, ns, interp, rot)
-        for family in (2, 1, 0):
+        for family in (2, 3, 1, 0):
             prev = lrp.debug_kernel(family)
             try:
                 d_out = torch.full((out_h, out_w, c), -777.0, dtype=torch.float32, device="cuda")
@@ -77,7 +77,7 @@ def test_scaled_output_window_paths(lrp, oracle, torch_cuda, scale):
     lout = lrp.LensInfo.equidistant(math.pi)
     rot = cases.rotation(lrp, (10.0, 5.0, 20.0))
     want = oracle.reproject(lin, src, lout, out_w, out_h, 1, 2, rot, threads=8)
-    for family in (2, 1, 0):
+    for family in (2, 3, 1, 0):
         prev = lrp.debug_kernel(family)
         try:
             d_out = torch.empty((out_h, out_w, 4), dtype=torch.float32, device="cuda")
@@ -86,3 +86,38 @@ def test_scaled_output_window_paths(lrp, oracle, torch_cuda, scale):
         finally:
             lrp.debug_kernel(prev)
         cases.assert_same_bits(d_out.cpu().numpy(), want, f"scale {scale} family {family}")
+
+
+@pytest.mark.parametrize("pair", [("eqd180", "rect"), ("eqr_full", "rect"), ("rect", "rect"), ("eqd180", "eqd120"),
+                                  ("eqr_part", "rect_tele")])
+def test_magnified_bicubic_shared_tap_coefficients(lrp, oracle, torch_cuda, pair):
+    """Magnified RGBA bicubic: the window kernel evaluates the weight-independent part of
+    the vertical Catmull-Rom cubics once per tap column of the staged window and shares
+    it between pixels.  Small sources blown up 3-8x keep every block in that tier; 6 % of
+    the texels are special values (infinities, NaN, signed zeros, denormals, values whose
+    2x / 4x / 5x multiples overflow) so that any change of operation order would show."""
+    torch = torch_cuda
+    in_name, out_name = pair
+    in_w, in_h, out_w, out_h = 131, 97, 640, 512
+    rng = np.random.default_rng(len(in_name) * 31 + len(out_name))
+    src = cases.hash_noise(in_h, in_w, 4, seed=3, planted=False)
+    flat = src.reshape(-1)
+    specials = np.array([np.inf, -np.inf, np.nan, -0.0, 0.0, 1e-41, -1e-45, 65504.0, 3.0e38, -3.0e38, 1.7e38, 8.6e37,
+                         -6.9e37, 1.2e-38], dtype=np.float32)
+    idx = rng.choice(flat.size, size=flat.size // 16, replace=False)
+    flat[idx] = specials[rng.integers(0, len(specials), size=idx.size)]
+    d_in = torch.from_numpy(src).cuda()
+    lin, lout = cases.lenses(lrp, in_w, in_h)[in_name], cases.lenses(lrp, out_w, out_h)[out_name]
+    for deg in (None, (12.0, -7.0, 3.0)):
+        rot = cases.rotation(lrp, deg)
+        with np.errstate(all="ignore"):
+            want = oracle.reproject(lin, src, lout, out_w, out_h, 1, 2, rot, threads=8)
+        for family in (2, 3):
+            prev = lrp.debug_kernel(family)
+            try:
+                d_out = torch.full((out_h, out_w, 4), -777.0, dtype=torch.float32, device="cuda")
+                lrp.reproject(lrp.Image(lin, in_w, in_h, 4, d_in), lrp.Image(lout, out_w, out_h, 4, d_out), 1, 2, rot)
+                torch.cuda.synchronize()
+            finally:
+                lrp.debug_kernel(prev)
+            cases.assert_same_bits(d_out.cpu().numpy(), want, f"{in_name}->{out_name} rot={deg} family={family}")

@@ -60,6 +60,10 @@ static const Workload kWorkloads[] = {
     {"eqd_rect_nn", "eqd", "rect", 0, 0, {0, 0, 0}},
     {"rect_eqr_nn", "rect", "eqr", 0, 1, {0, 0, 0}},
     {"rect_eqr_bl", "rect", "eqr", 1, 1, {0, 0, 0}},
+    // partial panorama as the target (KBENCH_EQRP=lon_min,lon_max,lat_min,lat_max picks the window)
+    {"rect_eqrp_nn", "rect", "eqrp", 0, 1, {0, 0, 0}},
+    {"rect_eqrp_bl", "rect", "eqrp", 1, 1, {0, 0, 0}},
+    {"rect_eqrp_bc", "rect", "eqrp", 2, 1, {0, 0, 0}},
 };
 
 static void make_lens(lrp_lens *L, const char *kind, int w, int h) {
@@ -67,8 +71,11 @@ static void make_lens(lrp_lens *L, const char *kind, int w, int h) {
     lrp_lens_rectilinear(L, 18.0f, 36.0f, (float)w, (float)h);
   else if (!strcmp(kind, "eqd"))
     lrp_lens_equidistant(L, 3.14159265f);
-  else if (!strcmp(kind, "eqrp"))
-    lrp_lens_equirectangular(L, -1.0f, 1.5f, -0.6f, 0.7f);
+  else if (!strcmp(kind, "eqrp")) {
+    float v[4] = {-1.0f, 1.5f, -0.6f, 0.7f};
+    if (const char *e = getenv("KBENCH_EQRP")) sscanf(e, "%f,%f,%f,%f", &v[0], &v[1], &v[2], &v[3]);
+    lrp_lens_equirectangular(L, v[0], v[1], v[2], v[3]);
+  }
   else
     lrp_lens_equirectangular_full(L);
 }
