@@ -168,6 +168,14 @@ std::atomic<int> g_kernel_choice{[] {
   return 2;
 }()};
 int kernel_choice() { return g_kernel_choice.load(std::memory_order_relaxed); }
+// LRP_XSEP=0 in the environment switches the column-separable source x tables off (A/B checks).
+bool xsep_enabled() {
+  static const bool on = [] {
+    const char *v = std::getenv("LRP_XSEP");
+    return !(v && std::strcmp(v, "0") == 0);
+  }();
+  return on;
+}
 
 int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int interpolation,
                       const float *rotation, const lrp_post *post, int device, hipStream_t stream) {
@@ -181,13 +189,25 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
               (long long)out->width * num_samples < (1ll << 30) && (long long)out->height * num_samples < (1ll << 30);
   if (tile && out->lens.type != LRP_FISHEYE_EQUIDISTANT) {
     // separable output-lens terms (cached per device / lens / size / num_samples)
-    e = lrp::get_output_tables(device, out->lens.type == LRP_RECTILINEAR ? lrp::kRect : lrp::kEquirect, P.out_lens,
-                               out->width, out->height, num_samples, &P.col_tab, &P.row_tab);
+    const int out_kind = out->lens.type == LRP_RECTILINEAR ? lrp::kRect : lrp::kEquirect;
+    bool plain = false;
+    e = lrp::get_output_tables(device, out_kind, P.out_lens, out->width, out->height, num_samples, &P.col_tab,
+                               &P.row_tab, &plain);
     if (e == hipErrorOutOfMemory) {
       (void)hipGetLastError();
       tile = false; // cache full or no memory for the tables: per-pixel kernel
     } else if (e != hipSuccess) {
       return hip_fail(e, "output-lens table build");
+    } else if (plain) {
+      // Every ray component is finite and no -0.0f: multiplying by the exact identity matrix
+      // (what the CLI passes for --rotation 0,0,0) changes no bit of (vx, vy, vz) — drop it.
+      static const float kIdentity[9] = {1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f};
+      if (P.has_rot && std::memcmp(P.rot, kIdentity, sizeof(kIdentity)) == 0) P.has_rot = 0;
+      // Column-separable source x (lrp_tables.hip): ray x and z independent of the row.
+      const bool rows_free = !P.has_rot || (P.rot[1] == 0.0f && P.rot[7] == 0.0f);
+      if (xsep_enabled() && rows_free && im != lrp::kInEquidistant)
+        P.xsep_tab = lrp::get_xsep_table(device, P.col_tab, out_kind, out->width, num_samples, P.in_lens, im, in->width,
+                                         P.in_lon_span, P.has_rot ? P.rot : nullptr);
     }
   }
   if (tile) {

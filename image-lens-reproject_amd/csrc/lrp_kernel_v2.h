@@ -35,6 +35,7 @@
 #pragma once
 
 #include "lrp_device.h"
+#include "lrp_source_axes.h"
 
 #ifndef LRP_ABLATE
 #define LRP_ABLATE 0 // 1, 2, 7: timing-only experiment builds (tools/ablate.sh); never shipped
@@ -135,8 +136,8 @@ __device__ __forceinline__ void ray_to_source_v2(const KParams &P, float x, floa
   }
   if constexpr (InMode == kInRect) {
     const float focal = L.p[0];
-    cx = x * img_w / L.sensor_width * focal; // :165
-    cy = y * img_h / L.sensor_height * focal;
+    cx = rect_axis(x, img_w, L.sensor_width, focal); // :165
+    cy = rect_axis(y, img_h, L.sensor_height, focal);
   } else if constexpr (InMode == kInEquidistant) {
     const float r = lrp_sqrtf(x * x + y * y); // :193
     const float theta = atanf_(r);            // :194
@@ -146,10 +147,8 @@ __device__ __forceinline__ void ray_to_source_v2(const KParams &P, float x, floa
     cy = y / r * r_px;
   } else {
     const float lat_min = L.p[0], lon_min = L.p[2];
-    const float theta = -atan2f_(-x, -z);                            // :262
-    const float phi = asinf_(y / lrp_sqrtf(x * x + y * y + z * z)); // :263
-    cx = ((theta - lon_min) / P.in_lon_span - 0.5f) * img_w;         // :268
-    cy = ((phi - lat_min) / P.in_lat_span - 0.5f) * img_h;           // :269
+    cx = equirect_cx(x, z, lon_min, P.in_lon_span, img_w);    // :262, :268
+    cy = equirect_cy(x, y, z, lat_min, P.in_lat_span, img_h); // :263, :269
   }
 }
 
@@ -281,10 +280,21 @@ __device__ __forceinline__ int interior(float s, float lo, float hi, float reach
 // sub-sample only.
 struct ColTerms {
   float a, b; // rectilinear: vx | equirectangular: vx, vz | equidistant: scx
+  // column-separable source x (P.xsep_tab, see lrp_tables.hip): the rotated ray's x and z
+  // and the finished source texel x of this column
+  float nx, nz, sx;
 };
 template <int OutLens> __device__ __forceinline__ ColTerms column_terms(const KParams &P, int xe, int ssx) {
   const int ns = P.num_samples;
-  ColTerms c{0.0f, 0.0f};
+  ColTerms c{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  if constexpr (OutLens != kEquidistant) {
+    if (P.xsep_tab) {
+      const int n = P.out_w * ns, j = xe * ns + ssx;
+      c.nx = P.xsep_tab[j];
+      c.nz = P.xsep_tab[n + j];
+      c.sx = P.xsep_tab[2 * n + j];
+    }
+  }
   if constexpr (OutLens == kRect) {
     c.a = P.col_tab[xe * ns + ssx];
   } else if constexpr (OutLens == kEquirect) {
@@ -304,6 +314,29 @@ template <int OutLens, int InMode>
 __device__ __forceinline__ void pixel_source_rt(const KParams &P, const ColTerms col, float row_v, int ye, int ssy,
                                                 float &sx, float &sy) {
   float vx, vy, vz;
+  if constexpr (OutLens != kEquidistant && InMode != kInEquidistant) {
+    // Column-separable source x: when the ray's x and z do not depend on the output row
+    // (no rotation, or one whose [0][1] and [2][1] entries are zero) the source x of a
+    // rectilinear / equirectangular source is a function of the column alone and comes
+    // from a per-column table built with the very same operations; only y remains.
+    if (P.xsep_tab) { // wave-uniform
+      const float vz0 = OutLens == kRect ? -1.0f : col.b;
+      float ny = row_v;
+      if (P.has_rot) ny = P.rot[3] * col.a + P.rot[4] * row_v + P.rot[5] * vz0; // :308
+      const LensP &L = P.in_lens;
+      float py;
+      if constexpr (InMode == kInRect) {
+        const float nz = -col.nz;
+        if (!wave_all(nz == 1.0f)) ny = ny / nz; // :164
+        py = rect_axis(ny, (float)P.in_h, L.sensor_height, L.p[0]);
+      } else {
+        py = equirect_cy(col.nx, ny, col.nz, L.p[0], P.in_lat_span, (float)P.in_h);
+      }
+      sx = col.sx;
+      sy = texel_coord(py, (float)P.in_h); // :324
+      return;
+    }
+  }
   if constexpr (OutLens == kRect) {
     vx = col.a;
     vy = row_v;

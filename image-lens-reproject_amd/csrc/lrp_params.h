@@ -43,6 +43,9 @@ struct KParams {
   // per-pixel code would execute; null for the equidistant target (not separable).
   const float *col_tab; // [2][out_w * num_samples]
   const float *row_tab; // [out_h * num_samples]
+  // Column-separable source x (lrp_tables.hip): rotated ray x, z and source texel x per
+  // (column, sub-sample); null when the lens pair / rotation does not separate.
+  const float *xsep_tab; // [3][out_w * num_samples]
   // Lens constants that depend on the lens only, evaluated once on the host
   // with the same IEEE binary32 operations (src/reproject.cpp:178,196,251-252,265-266).
   float in_focal, out_focal;        // equidistant: sensor_width / fov

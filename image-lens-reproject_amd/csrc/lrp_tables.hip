@@ -9,6 +9,18 @@
 // order on the same inputs, so the same bits — and the tile kernel just loads
 // them.  Tables are cached per (device, output lens, output size, num_samples):
 // a batch of images with one output lens builds them once.
+//
+// Column-separable source x (build_xsep_kernel).  The rotated ray is n = R v with
+// v = (vx(column), vy(row), vz(column)).  When R[0][1] and R[2][1] are zeros — no
+// rotation, the identity, any pan-only rotation (the cubemap's side faces) — nx
+// and nz are functions of the column alone: the term R[0][1] * vy is a zero whose
+// sign is the sign of vy, and adding it changes nothing unless the rest of the sum
+// is itself a zero.  The builder evaluates nx, nz for vy = +1 and vy = -1 with the
+// per-pixel expression; only if both agree bit for bit in every column is the
+// table used.  For a rectilinear or equirectangular SOURCE the horizontal source
+// coordinate depends on nx and nz only (src/reproject.cpp:163,165 / :262,268), so
+// it is evaluated once per column here — same functions, same operations — and a
+// pixel is left with the vertical half of the projection.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -16,6 +28,7 @@
 #include <vector>
 
 #include "lrp_device.h"
+#include "lrp_source_axes.h"
 #include "lrp_tables.h"
 
 namespace lrp {
@@ -27,7 +40,13 @@ struct TableArgs {
   int32_t out_lens; // kRect or kEquirect
   int32_t out_w, out_h, ns;
   float *tab;
+  int *flags; // flags[0] != 0: some table value is -0.0f, an infinity or a NaN
 };
+
+__device__ __forceinline__ void note_value(int *flags, float v) {
+  const uint32_t b = __float_as_uint(v);
+  if (b == 0x80000000u || (b & 0x7f800000u) == 0x7f800000u) atomicOr(flags, 1);
+}
 
 __global__ __launch_bounds__(256) void build_tables_kernel(const TableArgs A) {
   const int n_col = A.out_w * A.ns, n_row = A.out_h * A.ns;
@@ -43,10 +62,10 @@ __global__ __launch_bounds__(256) void build_tables_kernel(const TableArgs A) {
   const LensP &L = A.lens;
   if (A.out_lens == kRect) {
     const float focal = L.p[0];
-    if (is_col)
-      A.tab[j] = sc / extent * L.sensor_width / focal; // :155
-    else
-      A.tab[2 * n_col + j] = sc / extent * L.sensor_height / focal; // :156
+    const float v = is_col ? sc / extent * L.sensor_width / focal    // :155
+                           : sc / extent * L.sensor_height / focal; // :156
+    A.tab[is_col ? j : 2 * n_col + j] = v;
+    note_value(A.flags, v);
   } else {
     const float lat_min = L.p[0], lat_max = L.p[1], lon_min = L.p[2], lon_max = L.p[3];
     if (is_col) {
@@ -56,24 +75,85 @@ __global__ __launch_bounds__(256) void build_tables_kernel(const TableArgs A) {
       sincosf_(lon, sn, cs);
       A.tab[j] = sn;          // :254
       A.tab[n_col + j] = -cs; // :255
+      note_value(A.flags, sn);
+      note_value(A.flags, -cs);
     } else {
       const float lat_span = lat_max - lat_min;
       const float lat = ((sc / extent) + 0.5f) * lat_span + lat_min; // :252
-      A.tab[2 * n_col + j] = sinf_(lat);                           // :256
+      const float v = sinf_(lat); // :256
+      A.tab[2 * n_col + j] = v;
+      note_value(A.flags, v);
     }
   }
+}
+
+struct XsepArgs {
+  const float *col_tab; // of the output lens
+  int32_t out_lens, n;  // n = out_w * ns
+  LensP in_lens;
+  int32_t in_mode, in_w;
+  float in_lon_span;
+  int32_t has_rot;
+  float rx[3], rz[3]; // rows 0 and 2 of the rotation matrix
+  float *tab;         // [3][n]: nx, nz, source texel x
+  int *flags;         // flags[0] != 0: the two signs of vy disagree somewhere
+};
+
+__global__ __launch_bounds__(256) void build_xsep_kernel(const XsepArgs A) {
+  const int j = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (j >= A.n) return;
+  const float vx = A.col_tab[j];
+  const float vz = A.out_lens == kRect ? -1.0f : A.col_tab[A.n + j];
+  const LensP &L = A.in_lens;
+  const float img_w = (float)A.in_w;
+  float nx[2], nz[2], sx[2];
+  for (int cls = 0; cls < 2; ++cls) {
+    const float vy = cls ? -1.0f : 1.0f;
+    nx[cls] = vx;
+    nz[cls] = vz;
+    if (A.has_rot) { // src/reproject.cpp:303-311, rows 0 and 2
+      nx[cls] = A.rx[0] * vx + A.rx[1] * vy + A.rx[2] * vz;
+      nz[cls] = A.rz[0] * vx + A.rz[1] * vy + A.rz[2] * vz;
+    }
+    float px;
+    if (A.in_mode == kInRect)
+      px = rect_axis(nx[cls] / -nz[cls], img_w, L.sensor_width, L.p[0]); // :163, :165
+    else
+      px = equirect_cx(nx[cls], nz[cls], L.p[2], A.in_lon_span, img_w);  // :262, :268
+    sx[cls] = texel_coord(px, img_w);                                     // :323
+  }
+  if (__float_as_uint(nx[0]) != __float_as_uint(nx[1]) || __float_as_uint(nz[0]) != __float_as_uint(nz[1]) ||
+      __float_as_uint(sx[0]) != __float_as_uint(sx[1]))
+    atomicOr(A.flags, 1);
+  A.tab[j] = nx[0];
+  A.tab[A.n + j] = nz[0];
+  A.tab[2 * A.n + j] = sx[0];
 }
 
 struct Entry {
   int device;
   TableArgs key; // tab = device pointer of the finished tables
+  bool plain;    // no -0.0f, infinity or NaN in the tables
 };
+
+struct XsepEntry {
+  int device;
+  XsepArgs key;  // tab = device pointer of the finished table (null: the rotation does not separate)
+};
+std::vector<XsepEntry> g_xsep;
+
+bool same_xsep(const XsepArgs &a, const XsepArgs &b) {
+  return a.col_tab == b.col_tab && a.out_lens == b.out_lens && a.n == b.n && a.in_mode == b.in_mode && a.in_w == b.in_w &&
+         a.has_rot == b.has_rot && std::memcmp(&a.in_lens, &b.in_lens, sizeof(LensP)) == 0 &&
+         std::memcmp(&a.in_lon_span, &b.in_lon_span, sizeof(float)) == 0 && std::memcmp(a.rx, b.rx, sizeof(a.rx)) == 0 &&
+         std::memcmp(a.rz, b.rz, sizeof(a.rz)) == 0;
+}
 
 std::mutex g_mutex;
 std::vector<Entry> g_entries;
 constexpr size_t kMaxEntries = 256;
 
-bool same_key(const TableArgs &a, const TableArgs &b) {
+bool same_key(const TableArgs &a, const TableArgs &b) { // tab / flags are results, not part of the key
   return a.out_lens == b.out_lens && a.out_w == b.out_w && a.out_h == b.out_h && a.ns == b.ns &&
          std::memcmp(&a.lens, &b.lens, sizeof(LensP)) == 0;
 }
@@ -81,8 +161,9 @@ bool same_key(const TableArgs &a, const TableArgs &b) {
 } // namespace
 
 hipError_t get_output_tables(int device, int out_lens, const LensP &lens, int out_w, int out_h, int ns,
-                             const float **col_tab, const float **row_tab) {
+                             const float **col_tab, const float **row_tab, bool *plain) {
   *col_tab = *row_tab = nullptr;
+  *plain = false;
   TableArgs want;
   std::memset(&want, 0, sizeof(want));
   want.lens = lens;
@@ -96,33 +177,91 @@ hipError_t get_output_tables(int device, int out_lens, const LensP &lens, int ou
     if (e.device == device && same_key(e.key, want)) {
       *col_tab = e.key.tab;
       *row_tab = e.key.tab + 2 * n_col;
+      *plain = e.plain;
       return hipSuccess;
     }
   if (g_entries.size() >= kMaxEntries) return hipErrorOutOfMemory; // caller falls back to the per-pixel kernel
   // Miss: build synchronously on the legacy default stream (host blocks once per
   // new output-lens configuration; do this before capturing a hipGraph).
   float *tab = nullptr;
-  hipError_t e = hipMalloc(&tab, (2 * n_col + n_row) * sizeof(float));
+  hipError_t e = hipMalloc(&tab, (2 * n_col + n_row + 1) * sizeof(float)); // + one flag word
   if (e != hipSuccess) return e;
   want.tab = tab;
+  want.flags = reinterpret_cast<int *>(tab + 2 * n_col + n_row);
+  int flag = 1;
+  e = hipMemsetAsync(want.flags, 0, sizeof(int), 0);
   const unsigned blocks = (unsigned)((n_col + n_row + 255) / 256);
-  hipLaunchKernelGGL(build_tables_kernel, dim3(blocks), dim3(256), 0, 0, want);
-  e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(0);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(build_tables_kernel, dim3(blocks), dim3(256), 0, 0, want);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(&flag, want.flags, sizeof(int), hipMemcpyDeviceToHost); // also waits for the build
   if (e != hipSuccess) {
     (void)hipFree(tab);
     return e;
   }
-  g_entries.push_back(Entry{device, want});
+  g_entries.push_back(Entry{device, want, flag == 0});
   *col_tab = tab;
   *row_tab = tab + 2 * n_col;
+  *plain = flag == 0;
   return hipSuccess;
+}
+
+const float *get_xsep_table(int device, const float *col_tab, int out_lens, int out_w, int ns, const LensP &in_lens,
+                            int in_mode, int in_w, float in_lon_span, const float *rot) {
+  XsepArgs want;
+  std::memset(&want, 0, sizeof(want));
+  want.col_tab = col_tab;
+  want.out_lens = out_lens;
+  want.n = out_w * ns;
+  want.in_lens = in_lens;
+  want.in_mode = in_mode == kInRect ? kInRect : kInEquirect; // wrapping does not enter the coordinate
+  want.in_w = in_w;
+  want.in_lon_span = in_lon_span;
+  want.has_rot = rot != nullptr;
+  if (rot) {
+    std::memcpy(want.rx, rot, sizeof(want.rx));
+    std::memcpy(want.rz, rot + 6, sizeof(want.rz));
+  }
+  std::lock_guard<std::mutex> lock(g_mutex);
+  for (const XsepEntry &e : g_xsep)
+    if (e.device == device && same_xsep(e.key, want)) return e.key.tab;
+  if (g_xsep.size() >= kMaxEntries) return nullptr;
+  float *tab = nullptr;
+  if (hipMalloc(&tab, (3 * (size_t)want.n + 1) * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  want.tab = tab;
+  want.flags = reinterpret_cast<int *>(tab + 3 * (size_t)want.n);
+  int flag = 1;
+  hipError_t e = hipMemsetAsync(want.flags, 0, sizeof(int), 0);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(build_xsep_kernel, dim3((unsigned)((want.n + 255) / 256)), dim3(256), 0, 0, want);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(&flag, want.flags, sizeof(int), hipMemcpyDeviceToHost);
+  if (e != hipSuccess || flag != 0) { // failed, or the sign of vy matters in some column: remember "does not separate"
+    (void)hipGetLastError();
+    (void)hipFree(tab);
+    want.tab = nullptr;
+    want.flags = nullptr;
+    if (e != hipSuccess) return nullptr;
+  }
+  g_xsep.push_back(XsepEntry{device, want});
+  return want.tab;
 }
 
 void release_output_tables() {
   std::lock_guard<std::mutex> lock(g_mutex);
   int cur = 0;
   (void)hipGetDevice(&cur);
+  for (const XsepEntry &e : g_xsep) {
+    (void)hipSetDevice(e.device);
+    (void)hipDeviceSynchronize();
+    if (e.key.tab) (void)hipFree(e.key.tab);
+  }
+  g_xsep.clear();
   for (const Entry &e : g_entries) {
     (void)hipSetDevice(e.device);
     (void)hipDeviceSynchronize();
