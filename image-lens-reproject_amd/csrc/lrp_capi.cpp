@@ -168,6 +168,14 @@ std::atomic<int> g_kernel_choice{[] {
   return 2;
 }()};
 int kernel_choice() { return g_kernel_choice.load(std::memory_order_relaxed); }
+// LRP_QUAD=0 switches the mirrored blocks of the window kernel off (A/B checks).
+bool quad_enabled() {
+  static const bool on = [] {
+    const char *v = std::getenv("LRP_QUAD");
+    return !(v && std::strcmp(v, "0") == 0);
+  }();
+  return on;
+}
 // LRP_XSEP=0 in the environment switches the column-separable source x tables off (A/B checks).
 bool xsep_enabled() {
   static const bool on = [] {
@@ -185,6 +193,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
   const int im = in_lens_mode(in->lens);
   hipError_t e;
   const bool tile_channels = out->channels >= 3 && out->channels <= 5;
+  bool mirror = false; // the output-lens tables are symmetric about the image centre
   bool tile = kernel_choice() != 0 && tile_channels && in->width <= 65535 && in->height <= 32767 &&
               (long long)out->width * num_samples < (1ll << 30) && (long long)out->height * num_samples < (1ll << 30);
   if (tile && out->lens.type != LRP_FISHEYE_EQUIDISTANT) {
@@ -192,7 +201,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     const int out_kind = out->lens.type == LRP_RECTILINEAR ? lrp::kRect : lrp::kEquirect;
     bool plain = false;
     e = lrp::get_output_tables(device, out_kind, P.out_lens, out->width, out->height, num_samples, &P.col_tab,
-                               &P.row_tab, &plain);
+                               &P.row_tab, &plain, &mirror);
     if (e == hipErrorOutOfMemory) {
       (void)hipGetLastError();
       tile = false; // cache full or no memory for the tables: per-pixel kernel
@@ -217,6 +226,14 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
       e = lrp::launch_tile_bilinear(P, oi, im, stream);
     else if (kernel_choice() >= 2 && num_samples == 1 && out->channels == 4) {
       P.win_coef = kernel_choice() == 2;
+      // Mirrored blocks: without a rotation the mapping is symmetric about both image axes and
+      // the lens-plane coordinates of the four mirror pixels differ in sign only (lrp_kernel_v2.h).
+      // Rectilinear / equirectangular target: the ray tables must be mirror images bit for bit;
+      // equidistant target: the ray is odd in cx, cy by construction.  An equirectangular source
+      // takes part through the column-separable x table only (its longitude is not odd in x).
+      const bool in_eqr = im == lrp::kInEquirect || im == lrp::kInEquirectLoop;
+      const bool sym_out = out->lens.type == LRP_FISHEYE_EQUIDISTANT ? true : mirror;
+      P.quad = quad_enabled() && kernel_choice() == 2 && !P.has_rot && sym_out && (!in_eqr || P.xsep_tab != nullptr);
       e = lrp::launch_win_bicubic(P, oi, im, stream);
     }
     else

@@ -308,11 +308,20 @@ template <int OutLens> __device__ __forceinline__ ColTerms column_terms(const KP
 }
 
 // One sub-sample of output pixel (column terms `col`, row term `row_v` of row ye) ->
-// top-left-origin source texel coordinates.  All 64 lanes must be active (wave-wide vote
-// inside).  row_v is unused for the equidistant target; ye / ssy are only used by it.
+// top-left-origin source texel coordinates, in two stages.  All 64 lanes must be active
+// (wave-wide vote inside).  row_v is unused for the equidistant target; ye / ssy are
+// only used by it.
+//
+// Stage 1, pixel_plane(): everything up to the last quantity that changes only its sign
+// when the output pixel is mirrored about the image centre (see the mirrored blocks of
+// the window kernel):
+//   rectilinear / equidistant source   (u, v) = lens-plane coordinates (px, py);
+//   equirectangular source, xsep table  v = phi (latitude of the ray), u unused;
+//   equirectangular source otherwise   (u, v) = (px, py), not mirrorable.
+// Stage 2, plane_to_texel(): the rest of src/reproject.cpp:268-269 and :323-324.
 template <int OutLens, int InMode>
-__device__ __forceinline__ void pixel_source_rt(const KParams &P, const ColTerms col, float row_v, int ye, int ssy,
-                                                float &sx, float &sy) {
+__device__ __forceinline__ void pixel_plane(const KParams &P, const ColTerms col, float row_v, int ye, int ssy,
+                                            float &u, float &v) {
   float vx, vy, vz;
   if constexpr (OutLens != kEquidistant && InMode != kInEquidistant) {
     // Column-separable source x: when the ray's x and z do not depend on the output row
@@ -324,16 +333,14 @@ __device__ __forceinline__ void pixel_source_rt(const KParams &P, const ColTerms
       float ny = row_v;
       if (P.has_rot) ny = P.rot[3] * col.a + P.rot[4] * row_v + P.rot[5] * vz0; // :308
       const LensP &L = P.in_lens;
-      float py;
       if constexpr (InMode == kInRect) {
         const float nz = -col.nz;
         if (!wave_all(nz == 1.0f)) ny = ny / nz; // :164
-        py = rect_axis(ny, (float)P.in_h, L.sensor_height, L.p[0]);
+        v = rect_axis(ny, (float)P.in_h, L.sensor_height, L.p[0]);
       } else {
-        py = equirect_cy(col.nx, ny, col.nz, L.p[0], P.in_lat_span, (float)P.in_h);
+        v = equirect_phi(col.nx, ny, col.nz);
       }
-      sx = col.sx;
-      sy = texel_coord(py, (float)P.in_h); // :324
+      u = 0.0f;
       return;
     }
   }
@@ -359,15 +366,32 @@ __device__ __forceinline__ void pixel_source_rt(const KParams &P, const ColTerms
     vz = nz;
   }
 #if defined(LRP_TRIVIAL_COORDS) // timing experiment: trivial coordinates (memory path only)
-  sx = vx * 1000.0f + (float)P.in_w * 0.5f;
-  sy = vy * 1000.0f + (float)P.in_h * 0.5f;
+  u = vx * 1000.0f;
+  v = vy * 1000.0f;
   (void)vz;
 #else
-  float px, py;
-  ray_to_source_v2<InMode>(P, vx, vy, vz, px, py);
-  sx = (px - 0.5f) + (float)P.in_w * 0.5f; // :323-324
-  sy = (py - 0.5f) + (float)P.in_h * 0.5f;
+  ray_to_source_v2<InMode>(P, vx, vy, vz, u, v);
 #endif
+}
+
+template <int OutLens, int InMode>
+__device__ __forceinline__ void plane_to_texel(const KParams &P, const ColTerms col, float u, float v, float &sx,
+                                               float &sy) {
+  bool xsep = false;
+  if constexpr (OutLens != kEquidistant && InMode != kInEquidistant) xsep = P.xsep_tab != nullptr;
+  sx = xsep ? col.sx : texel_coord(u, (float)P.in_w); // :323
+  if constexpr (InMode == kInEquirect || InMode == kInEquirectLoop) {
+    if (xsep) v = equirect_cy_of_phi(v, P.in_lens.p[0], P.in_lat_span, (float)P.in_h); // :269
+  }
+  sy = texel_coord(v, (float)P.in_h); // :324
+}
+
+template <int OutLens, int InMode>
+__device__ __forceinline__ void pixel_source_rt(const KParams &P, const ColTerms col, float row_v, int ye, int ssy,
+                                                float &sx, float &sy) {
+  float u, v;
+  pixel_plane<OutLens, InMode>(P, col, row_v, ye, ssy, u, v);
+  plane_to_texel<OutLens, InMode>(P, col, u, v, sx, sy);
 }
 
 // Row term of output row ye, sub-sample ssy (0 for the equidistant target, which has none).
@@ -621,7 +645,7 @@ struct WinBlock {
   bool staged;                   // taps come from the LDS window (wave-uniform)
   // coefficient tier (wave-uniform): per half of the block (passes 0-1, 2-3) the first
   // int(sy) and the number of distinct int(sy) rows; a coefficient row has the window's pitch
-  int iy0[2], iyn[2], c_plane;
+  int iy0[2], iyn[2], c_plane, c_base; // plane size and first slot of plane 0 (behind the raw window + a margin)
   bool coef;
 };
 
@@ -634,7 +658,7 @@ struct WinBlock {
 // (kWinBuffers == 2 issues DMA(g+1) before the cubics of block g instead; measured
 // equal, and one 10 KiB buffer per wavefront admits 1:1 and rotated mappings at
 // 4 wavefronts per SIMD, which is worth 5-25 %.)
-template <int OutLens, int InMode>
+template <int OutLens, int InMode, bool Quad>
 __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubic_win_kernel(const KParams P) {
   constexpr bool Loop = (InMode == kInEquirectLoop);
   __shared__ float4 s_win[kT2Waves][kWinBuffers][kWinCap];
@@ -648,15 +672,29 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
   const int lane = (int)(threadIdx.x & 63u);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int G = P.blocks_per_wave;
-  // workgroup tile = 64 x 16G: four strips of G blocks side by side, one per wavefront
+  // Mirrored blocks (Quad instantiations, launched when P.quad).  Without a rotation the mapping is symmetric
+  // about both image axes: the pixels (x, y), (W-1-x, y), (x, H-1-y), (W-1-x, H-1-y) have
+  // rays that differ in the signs of vx / vy only, every operation between the ray and the
+  // lens-plane coordinates is an IEEE multiply, divide, square root of a sum of squares or
+  // an odd libm function, so their plane coordinates differ in sign only — exactly.  The
+  // launch then enumerates the top-left quadrant, a wavefront's "strip" is the block and
+  // its three mirror images (g = 0..3: bit 0 mirrors x, bit 1 mirrors y), and stage 1 of
+  // the coordinate math (pixel_plane) runs once for the four of them.
+  constexpr bool quad = Quad;
+  const int qw = quad ? (P.out_w + 1) >> 1 : P.out_w; // columns / rows enumerated by the launch
+  const int qh = quad ? (P.out_h + 1) >> 1 : P.out_h;
+  // workgroup tile = 64 x 16G (64 x 16 of the quadrant when mirrored): four strips side by side, one per wavefront
   const int x = tx * (kBlkW * kT2Waves) + wave * kBlkW + (lane & (kBlkW - 1));
-  const int y_lane = P.y_offset + ty * (kBlkH * G) + lane / kBlkW; // + kBlkH * g + kPassRows * pass
-  const int xe = x < P.out_w ? x : P.out_w - 1;
+  const int y_lane = P.y_offset + ty * (quad ? kBlkH : kBlkH * G) + lane / kBlkW; // + kBlkH * g + kPassRows * pass
+  const int xe = x < qw ? x : qw - 1;
   const int in_w = P.in_w;
   const SrcView src = source_view<2, 4>(P);
   const float4 *__restrict__ src4 = reinterpret_cast<const float4 *>(P.src);
   float4 *const win0 = s_win[wave][0];
   const ColTerms col = column_terms<OutLens>(P, xe, 0);
+  ColTerms col_m = col; // the mirrored column
+  if constexpr (Quad) col_m = column_terms<OutLens>(P, P.out_w - 1 - xe, 0);
+  float qu[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qv[4] = {0.0f, 0.0f, 0.0f, 0.0f};         // stage-1 results of the quadrant pixels
 
   // phase A of block g: coordinates, interior vote, window box
   auto coords = [&](int g, WinBlock &b) {
@@ -670,17 +708,25 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
     int lo_y[2] = {0x7fffffff, 0x7fffffff}, hi_y[2] = {(int)0x80000000, (int)0x80000000};
     // the four row terms first, all loads in flight together (one exposed latency per
     // block instead of one in front of every pixel's coordinate chain)
-    float row_v[4];
+    const int mx = quad ? (g & 1) : 0, my = quad ? (g >> 1) : 0;
+    float row_v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (!quad || g == 0) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int yk = y_lane + kBlkH * g + kPassRows * k;
-      row_v[k] = row_term<OutLens>(P, yk < P.out_h ? yk : P.out_h - 1, 0);
+      for (int k = 0; k < 4; ++k) {
+        const int yk = y_lane + (quad ? 0 : kBlkH * g) + kPassRows * k;
+        row_v[k] = row_term<OutLens>(P, yk < qh ? yk : qh - 1, 0);
+      }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int yk = y_lane + kBlkH * g + kPassRows * k;
-      const int ye = yk < P.out_h ? yk : P.out_h - 1;
-      pixel_source_rt<OutLens, InMode>(P, col, row_v[k], ye, 0, b.sx[k], b.sy[k]);
+      const int yk = y_lane + (quad ? 0 : kBlkH * g) + kPassRows * k;
+      const int ye = yk < qh ? yk : qh - 1;
+      if (!quad) {
+        pixel_source_rt<OutLens, InMode>(P, col, row_v[k], ye, 0, b.sx[k], b.sy[k]);
+      } else {
+        if (g == 0) pixel_plane<OutLens, InMode>(P, col, row_v[k], ye, 0, qu[k], qv[k]);
+        plane_to_texel<OutLens, InMode>(P, mx ? col_m : col, mx ? -qu[k] : qu[k], my ? -qv[k] : qv[k], b.sx[k], b.sy[k]);
+      }
       const f2 sxy{b.sx[k], b.sy[k]};
       const f2 back = (sxy + 2.0f) - sxy; // both coordinates in one packed add / subtract
       exact &= (int)(back.x == 2.0f) & (int)(back.y == 2.0f);
@@ -691,7 +737,7 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
       hi_y[k >> 1] = max(hi_y[k >> 1], by);
     }
     b.staged = b.coef = false;
-    b.x_lo = b.y_lo = b.bw = b.bh = b.pitch = b.c_plane = 0;
+    b.x_lo = b.y_lo = b.bw = b.bh = b.pitch = b.c_plane = b.c_base = 0;
     b.iy0[0] = b.iy0[1] = b.iyn[0] = b.iyn[1] = 0;
     if (wave_all(exact != 0)) {
       int w_lo_x = lo_x, w_hi_x = hi_x, w_lo_ya = lo_y[0], w_hi_ya = hi_y[0], w_lo_yb = lo_y[1], w_hi_yb = hi_y[1];
@@ -721,6 +767,10 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
         b.iyn[1] = yb_last - yb_first + 1;
         b.c_plane = b.pitch * max(b.iyn[0], b.iyn[1]);
         b.coef = kWinCoef && P.win_coef != 0 && b.staged && b.pitch * b.bh + 3 * b.c_plane <= kWinCap;
+        // planes behind the raw window plus, where there is room, one row and one column of slack:
+        // the next block's (slightly different) window can then be requested while this block's
+        // planes are still being read (see next_window)
+        b.c_base = min(b.pitch * b.bh + b.pitch + b.bh + 1, kWinCap - 3 * b.c_plane);
       }
     }
   };
@@ -729,10 +779,22 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
       // LDS-DMA, one window row per instruction, lanes beyond the width masked off
       float4 *const win = win0 + (g & (kWinBuffers - 1)) * kWinCap;
       const float4 *gp = src4 + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane));
+      // Issued as inline assembly: the compiler's wait-count insertion then does not know
+      // that LDS is being written and puts no vmcnt(0) in front of later LDS reads (of the
+      // coefficient planes, which the DMA does not touch); the one wait that IS needed sits
+      // at the top of the block loop.  M0 = LDS byte address of the row (+ 16 B per lane).
+      // the reads of the window issued so far have returned before anything overwrites it
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane < b.bw) {
-        for (int r = 0; r < b.bh; ++r)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + (size_t)r * in_w),
-                                           (__attribute__((address_space(3))) void *)(win + r * b.pitch), 16, 0, 0);
+        uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win;
+        const uint32_t lds_step = (uint32_t)b.pitch * 16u;
+        for (int r = 0; r < b.bh; ++r) {
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                       :
+                       : "s"(lds), "v"(gp + (size_t)r * in_w)
+                       : "memory", "m0");
+          lds += lds_step;
+        }
       }
     }
   };
@@ -749,7 +811,7 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
   auto precompute = [&](const WinBlock &b, int h) {
     const int n = b.pitch * b.iyn[h]; // origins: every window column x every first tap row of this half
     const float4 *const raw = win0 + (b.iy0[h] - 1 - b.y_lo) * b.pitch;
-    float4 *const planes = win0 + b.pitch * b.bh;
+    float4 *const planes = win0 + b.c_base;
 #pragma unroll 1
     for (int i0 = 0; i0 < n; i0 += 64) {
       const int idx = i0 + lane;
@@ -772,13 +834,40 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
     }
   };
 
+  // vmcnt retires in order, stores included: a store issued BEFORE the DMA of the next window
+  // would have to be acknowledged by memory before that window counts as landed.  So the
+  // DMA of window g+1 is issued inside the last pass of block g, right behind that pass's
+  // reads of the window and ahead of its arithmetic and its store; the stores of passes
+  // 0-2 are a pass or more old by then, the store of pass 3 is the one vm operation that
+  // may still be outstanding when the next block waits: vmcnt(1).  (Every lane stores,
+  // see below, so that store is always issued.)
+  // source texel coordinates of mirrored block g from the quadrant's stage-1 results
+  auto texels = [&](int g, WinBlock &b) {
+    const int mx = g & 1, my = g >> 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      plane_to_texel<OutLens, InMode>(P, mx ? col_m : col, mx ? -qu[k] : qu[k], my ? -qv[k] : qv[k], b.sx[k], b.sy[k]);
+  };
   WinBlock cur, nxt;
   coords(0, cur);
   issue(0, cur);
+  int g_loop = 0;
+  bool dma_early = false; // the pending window was requested before its block's last store
+  auto next_window = [&]() {
+    // while this block's coefficient planes are still being read the next raw window must stay in front of them
+    dma_early = g_loop + 1 < G && (!(kWinCoef && cur.coef) || nxt.pitch * nxt.bh <= cur.c_base);
+    if (dma_early) issue(g_loop + 1, nxt);
+  };
 #pragma unroll 1
   for (int g = 0; g < G; ++g) {
-    if (g + 1 < G) coords(g + 1, nxt);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // window g has landed (also retires block g-1's stores)
+    g_loop = g;
+    // plain blocks: the next block's coordinates here, long before its window is requested in the
+    // last pass; mirrored blocks derive theirs in a few instructions right there (fewer live registers)
+    if (!Quad && g + 1 < G) coords(g + 1, nxt);
+    if (g == 0 || !dma_early || kWinBuffers != 1 || LRP_ABLATE != 0)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the window was the last thing requested
+    else
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); // window g has landed; block g-1's last store may be in flight
     if (kWinBuffers == 2 && g + 1 < G) issue(g + 1, nxt);
     const float4 *const win = win0 + (g & (kWinBuffers - 1)) * kWinCap;
 #pragma unroll
@@ -787,23 +876,29 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int k = 2 * h + kk;
+        const bool last_pass = kWinBuffers == 1 && LRP_ABLATE == 0 && k == 3;
+        if (Quad && k == 3 && g + 1 < G) coords(g + 1, nxt);
         Rgba s;
         if (kWinCoef && cur.coef) {
           const float tx_ = __builtin_truncf(cur.sx[k]), ty_ = __builtin_truncf(cur.sy[k]);
           const float fx = cur.sx[k] - tx_, fy = cur.sy[k] - ty_;
           const float hfx = 0.5f * fx, hfy = 0.5f * fy;
           const int ix = (int)tx_ - 1 - cur.x_lo, iy = (int)ty_;
-          const float4 *ci = win + (cur.pitch * cur.bh + (iy - cur.iy0[h]) * cur.pitch + ix);
+          const float4 *ci = win + (cur.c_base + (iy - cur.iy0[h]) * cur.pitch + ix);
           const float4 *cm = ci + cur.c_plane, *cc = cm + cur.c_plane;
           const float4 *tb = win + ((iy - cur.y_lo) * cur.pitch + ix);
-          auto vert = [&](int j) {
-            const Rgba inner = as_rgba(ci[j]), m0 = as_rgba(cm[j]), cma = as_rgba(cc[j]), b1 = as_rgba(tb[j]);
+          // the only reads of the raw window: the second tap row.  In the last pass they are the
+          // block's last reads of it, and the next window's DMA goes right behind them
+          const Rgba b0 = as_rgba(tb[0]), b1 = as_rgba(tb[1]), b2 = as_rgba(tb[2]), b3 = as_rgba(tb[3]);
+          if (last_pass) next_window();
+          auto vert = [&](int j, const Rgba bj) {
+            const Rgba inner = as_rgba(ci[j]), m0 = as_rgba(cm[j]), cma = as_rgba(cc[j]);
             Rgba r = px_zero<4>();
-            r.lo = b1.lo + hfy * (cma.lo + fy * (m0.lo + fy * inner.lo));
-            r.hi = b1.hi + hfy * (cma.hi + fy * (m0.hi + fy * inner.hi));
+            r.lo = bj.lo + hfy * (cma.lo + fy * (m0.lo + fy * inner.lo));
+            r.hi = bj.hi + hfy * (cma.hi + fy * (m0.hi + fy * inner.hi));
             return r;
           };
-          const Rgba k0 = vert(0), k1 = vert(1), k2 = vert(2), k3 = vert(3);
+          const Rgba k0 = vert(0, b0), k1 = vert(1, b1), k2 = vert(2, b2), k3 = vert(3, b3);
           s = cubic4(k0, k1, k2, k3, fx, hfx);
         } else if (cur.staged) {
           const float tx_ = __builtin_truncf(cur.sx[k]), ty_ = __builtin_truncf(cur.sy[k]);
@@ -846,28 +941,45 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
           s = Rgba{f2{fx, fy}, f2{hfx, hfy}, 0.0f};
           (void)t1; (void)t2; (void)t3;
 #else
-          const Rgba k0 = cubic4(as_rgba(t[0]), as_rgba(t1[0]), as_rgba(t2[0]), as_rgba(t3[0]), fy, hfy);
-          const Rgba k1 = cubic4(as_rgba(t[1]), as_rgba(t1[1]), as_rgba(t2[1]), as_rgba(t3[1]), fy, hfy);
-          const Rgba k2 = cubic4(as_rgba(t[2]), as_rgba(t1[2]), as_rgba(t2[2]), as_rgba(t3[2]), fy, hfy);
-          const Rgba k3 = cubic4(as_rgba(t[3]), as_rgba(t1[3]), as_rgba(t2[3]), as_rgba(t3[3]), fy, hfy);
+          Rgba q[4][4]; // all 16 taps first: they are the last reads of the window in the last pass
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            q[j][0] = as_rgba(t[j]);
+            q[j][1] = as_rgba(t1[j]);
+            q[j][2] = as_rgba(t2[j]);
+            q[j][3] = as_rgba(t3[j]);
+          }
+          if (last_pass) next_window();
+          const Rgba k0 = cubic4(q[0][0], q[0][1], q[0][2], q[0][3], fy, hfy);
+          const Rgba k1 = cubic4(q[1][0], q[1][1], q[1][2], q[1][3], fy, hfy);
+          const Rgba k2 = cubic4(q[2][0], q[2][1], q[2][2], q[2][3], fy, hfy);
+          const Rgba k3 = cubic4(q[3][0], q[3][1], q[3][2], q[3][3], fy, hfy);
           s = cubic4(k0, k1, k2, k3, fx, hfx);
 #endif
         } else {
+          if (last_pass) next_window(); // nothing staged: no tap of this block reads the window
           s = sample_direct<2, Loop, 4>(P, src, cur.sx[k], cur.sy[k]);
         }
         // num_samples == 1: (0.0f + s) * normalize (src/reproject.cpp:334-341)
         Rgba a = px_zero<4>();
         px_add<4>(a, s);
-        const int yk = y_lane + kBlkH * g + kPassRows * k;
+        // Every lane stores: lanes / rows beyond the image have recomputed the pixel they were
+        // clamped to (xe, ye) and write that same value to that same address again, so the
+        // store is issued by every wavefront (the vmcnt(1) above counts on it).
+        const int yk = y_lane + (quad ? 0 : kBlkH * g) + kPassRows * k;
+        const int yc = yk < qh ? yk : qh - 1;
+        const int xo = (quad && (g & 1)) ? P.out_w - 1 - xe : xe; // mirrored blocks write the mirrored pixel
+        const int yo = (quad && (g >> 1)) ? P.out_h - 1 - yc : yc;
 #if defined(LRP_NO_STORE) // timing experiment: almost no output traffic
-        if (x < P.out_w && yk < P.out_h && a.lo.x == 12345.678f) store_px<4>(P, (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x, a);
+        if (a.lo.x == 12345.678f) store_px<4>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
 #else
-        if (x < P.out_w && yk < P.out_h) store_px<4>(P, (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x, a);
+        store_px<4>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
 #endif
       }
     }
-    if (kWinBuffers == 1 && g + 1 < G) issue(g + 1, nxt); // the window is free again: every tap of block g has been read
+    if (kWinBuffers == 1 && (LRP_ABLATE != 0 || !dma_early) && g + 1 < G) issue(g + 1, nxt); // after the last read of the planes
     cur = nxt;
+    if (Quad && g + 1 < G) texels(g + 1, cur); // the window came from the same values; only the box was kept live
   }
 }
 
@@ -905,35 +1017,45 @@ template <int Interp> hipError_t launch_tile_interp(KParams P, int out_idx, int 
   return hipGetLastError();
 }
 
-struct WinKernelTable {
+template <bool Quad> struct WinKernelTable {
   static TileKernelFn get(int out_idx, int in_mode) {
     static const TileKernelFn table[3][4] = {
-        {reproject_bicubic_win_kernel<kRect, kInRect>, reproject_bicubic_win_kernel<kRect, kInEquidistant>,
-         reproject_bicubic_win_kernel<kRect, kInEquirect>, reproject_bicubic_win_kernel<kRect, kInEquirectLoop>},
-        {reproject_bicubic_win_kernel<kEquidistant, kInRect>, reproject_bicubic_win_kernel<kEquidistant, kInEquidistant>,
-         reproject_bicubic_win_kernel<kEquidistant, kInEquirect>,
-         reproject_bicubic_win_kernel<kEquidistant, kInEquirectLoop>},
-        {reproject_bicubic_win_kernel<kEquirect, kInRect>, reproject_bicubic_win_kernel<kEquirect, kInEquidistant>,
-         reproject_bicubic_win_kernel<kEquirect, kInEquirect>, reproject_bicubic_win_kernel<kEquirect, kInEquirectLoop>}};
+        {reproject_bicubic_win_kernel<kRect, kInRect, Quad>, reproject_bicubic_win_kernel<kRect, kInEquidistant, Quad>,
+         reproject_bicubic_win_kernel<kRect, kInEquirect, Quad>, reproject_bicubic_win_kernel<kRect, kInEquirectLoop, Quad>},
+        {reproject_bicubic_win_kernel<kEquidistant, kInRect, Quad>,
+         reproject_bicubic_win_kernel<kEquidistant, kInEquidistant, Quad>,
+         reproject_bicubic_win_kernel<kEquidistant, kInEquirect, Quad>,
+         reproject_bicubic_win_kernel<kEquidistant, kInEquirectLoop, Quad>},
+        {reproject_bicubic_win_kernel<kEquirect, kInRect, Quad>, reproject_bicubic_win_kernel<kEquirect, kInEquidistant, Quad>,
+         reproject_bicubic_win_kernel<kEquirect, kInEquirect, Quad>,
+         reproject_bicubic_win_kernel<kEquirect, kInEquirectLoop, Quad>}};
     return table[out_idx][in_mode];
   }
 };
 
 // num_samples must be 1 (the pipeline keeps no accumulator across sub-samples).
+template <bool Quad>
 inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, hipStream_t stream) {
-  P.tiles_x = (P.out_w + kBlkW * kT2Waves - 1) / (kBlkW * kT2Waves);
   const int rows = P.out_h - P.y_offset;
-  // strips of 4 blocks when that still leaves >= 8 workgroups per CU, else shorter
-  const int row_blocks = (rows + kBlkH - 1) / kBlkH;
-  int G = LRP_WIN_STRIP;
-  while (G > 1 && (long long)P.tiles_x * ((row_blocks + G - 1) / G) < 2048) G >>= 1;
-  P.blocks_per_wave = G;
-  P.tiles_y = (row_blocks + G - 1) / G;
+  if (Quad) {
+    // the launch enumerates the top-left quadrant; a wavefront renders a block and its three mirror images
+    P.tiles_x = ((P.out_w + 1) / 2 + kBlkW * kT2Waves - 1) / (kBlkW * kT2Waves);
+    P.tiles_y = ((P.out_h + 1) / 2 + kBlkH - 1) / kBlkH;
+    P.blocks_per_wave = 4;
+  } else {
+    P.tiles_x = (P.out_w + kBlkW * kT2Waves - 1) / (kBlkW * kT2Waves);
+    // strips of LRP_WIN_STRIP blocks when that still leaves >= 8 workgroups per CU, else shorter
+    const int row_blocks = (rows + kBlkH - 1) / kBlkH;
+    int G = LRP_WIN_STRIP;
+    while (G > 1 && (long long)P.tiles_x * ((row_blocks + G - 1) / G) < 2048) G >>= 1;
+    P.blocks_per_wave = G;
+    P.tiles_y = (row_blocks + G - 1) / G;
+  }
   const int n_tiles = P.tiles_x * P.tiles_y;
   if (n_tiles <= 0) return hipSuccess;
   const int chunk = (n_tiles + kXcds - 1) / kXcds;
-  hipLaunchKernelGGL(WinKernelTable::get(out_idx, in_mode), dim3((unsigned)(chunk * kXcds)), dim3(kT2Threads), 0, stream,
-                     P);
+  hipLaunchKernelGGL(WinKernelTable<Quad>::get(out_idx, in_mode), dim3((unsigned)(chunk * kXcds)), dim3(kT2Threads), 0,
+                     stream, P);
   return hipGetLastError();
 }
 

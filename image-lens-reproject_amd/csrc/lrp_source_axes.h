@@ -18,9 +18,12 @@ LRP_HD float equirect_cx(float x, float z, float lon_min, float lon_span, float 
 }
 
 // cy of vec_to_equirectangular: :263, :269
-LRP_HD float equirect_cy(float x, float y, float z, float lat_min, float lat_span, float img_h) {
-  const float phi = asinf_(y / lrp_sqrtf(x * x + y * y + z * z));
+LRP_HD float equirect_phi(float x, float y, float z) { return asinf_(y / lrp_sqrtf(x * x + y * y + z * z)); }
+LRP_HD float equirect_cy_of_phi(float phi, float lat_min, float lat_span, float img_h) {
   return ((phi - lat_min) / lat_span - 0.5f) * img_h;
+}
+LRP_HD float equirect_cy(float x, float y, float z, float lat_min, float lat_span, float img_h) {
+  return equirect_cy_of_phi(equirect_phi(x, y, z), lat_min, lat_span, img_h);
 }
 
 // source texel coordinate from the lens-plane coordinate: :323-324

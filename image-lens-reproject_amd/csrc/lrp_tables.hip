@@ -40,32 +40,23 @@ struct TableArgs {
   int32_t out_lens; // kRect or kEquirect
   int32_t out_w, out_h, ns;
   float *tab;
-  int *flags; // flags[0] != 0: some table value is -0.0f, an infinity or a NaN
+  int *flags; // see build_tables_kernel
 };
 
-__device__ __forceinline__ void note_value(int *flags, float v) {
-  const uint32_t b = __float_as_uint(v);
-  if (b == 0x80000000u || (b & 0x7f800000u) == 0x7f800000u) atomicOr(flags, 1);
-}
 
-__global__ __launch_bounds__(256) void build_tables_kernel(const TableArgs A) {
-  const int n_col = A.out_w * A.ns, n_row = A.out_h * A.ns;
-  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
-  if (i >= n_col + n_row) return;
-  const bool is_col = i < n_col;
-  const int j = is_col ? i : i - n_col;
+// One table value: is_col ? (column j: vx, and vz for the equirectangular target) : (row j: vy).
+__device__ __forceinline__ void table_value(const TableArgs &A, bool is_col, int j, float &v0, float &v1) {
   const int pix = j / A.ns, ss = j - pix * A.ns;
   const float extent = (float)(is_col ? A.out_w : A.out_h);
   // src/reproject.cpp:287-288,295,298
   const float c = ((float)pix + 0.5f) - extent * 0.5f;
   const float sc = c + ((float)ss + 1.0f) / ((float)A.ns + 1.0f) - 0.5f;
   const LensP &L = A.lens;
+  v1 = 0.0f;
   if (A.out_lens == kRect) {
     const float focal = L.p[0];
-    const float v = is_col ? sc / extent * L.sensor_width / focal    // :155
-                           : sc / extent * L.sensor_height / focal; // :156
-    A.tab[is_col ? j : 2 * n_col + j] = v;
-    note_value(A.flags, v);
+    v0 = is_col ? sc / extent * L.sensor_width / focal    // :155
+                : sc / extent * L.sensor_height / focal; // :156
   } else {
     const float lat_min = L.p[0], lat_max = L.p[1], lon_min = L.p[2], lon_max = L.p[3];
     if (is_col) {
@@ -73,18 +64,46 @@ __global__ __launch_bounds__(256) void build_tables_kernel(const TableArgs A) {
       const float lon = ((sc / extent) + 0.5f) * lon_span + lon_min; // :251
       float sn, cs;
       sincosf_(lon, sn, cs);
-      A.tab[j] = sn;          // :254
-      A.tab[n_col + j] = -cs; // :255
-      note_value(A.flags, sn);
-      note_value(A.flags, -cs);
+      v0 = sn;  // :254
+      v1 = -cs; // :255
     } else {
       const float lat_span = lat_max - lat_min;
       const float lat = ((sc / extent) + 0.5f) * lat_span + lat_min; // :252
-      const float v = sinf_(lat); // :256
-      A.tab[2 * n_col + j] = v;
-      note_value(A.flags, v);
+      v0 = sinf_(lat);                                             // :256
     }
   }
+}
+
+// flags[0]: bit 0 = some table value is -0.0f, an infinity or a NaN; bit 1 = the columns are
+// not mirror images of each other (vx(W-1-j) == -vx(j), vz(W-1-j) == vz(j), bit for bit);
+// bit 2 = the rows are not (vy(H-1-j) == -vy(j)).  Mirror bits are only meaningful for ns == 1.
+__global__ __launch_bounds__(256) void build_tables_kernel(const TableArgs A) {
+  const int n_col = A.out_w * A.ns, n_row = A.out_h * A.ns;
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= n_col + n_row) return;
+  const bool is_col = i < n_col;
+  const int j = is_col ? i : i - n_col;
+  float v0, v1, m0, m1;
+  table_value(A, is_col, j, v0, v1);
+  table_value(A, is_col, (is_col ? n_col : n_row) - 1 - j, m0, m1);
+  int flags = 0;
+  auto note = [&](float v) {
+    const uint32_t b = __float_as_uint(v);
+    if (b == 0x80000000u || (b & 0x7f800000u) == 0x7f800000u) flags |= 1;
+  };
+  note(v0);
+  if (__float_as_uint(m0) != (__float_as_uint(v0) ^ 0x80000000u)) flags |= is_col ? 2 : 4;
+  if (is_col) {
+    A.tab[j] = v0;
+    if (A.out_lens != kRect) {
+      A.tab[n_col + j] = v1;
+      note(v1);
+      if (__float_as_uint(m1) != __float_as_uint(v1)) flags |= 2;
+    }
+  } else {
+    A.tab[2 * n_col + j] = v0;
+  }
+  if (flags) atomicOr(A.flags, flags);
 }
 
 struct XsepArgs {
@@ -133,7 +152,7 @@ __global__ __launch_bounds__(256) void build_xsep_kernel(const XsepArgs A) {
 struct Entry {
   int device;
   TableArgs key; // tab = device pointer of the finished tables
-  bool plain;    // no -0.0f, infinity or NaN in the tables
+  int flags;     // as left by build_tables_kernel
 };
 
 struct XsepEntry {
@@ -161,9 +180,9 @@ bool same_key(const TableArgs &a, const TableArgs &b) { // tab / flags are resul
 } // namespace
 
 hipError_t get_output_tables(int device, int out_lens, const LensP &lens, int out_w, int out_h, int ns,
-                             const float **col_tab, const float **row_tab, bool *plain) {
+                             const float **col_tab, const float **row_tab, bool *plain, bool *mirror) {
   *col_tab = *row_tab = nullptr;
-  *plain = false;
+  *plain = *mirror = false;
   TableArgs want;
   std::memset(&want, 0, sizeof(want));
   want.lens = lens;
@@ -177,7 +196,8 @@ hipError_t get_output_tables(int device, int out_lens, const LensP &lens, int ou
     if (e.device == device && same_key(e.key, want)) {
       *col_tab = e.key.tab;
       *row_tab = e.key.tab + 2 * n_col;
-      *plain = e.plain;
+      *plain = !(e.flags & 1);
+      *mirror = ns == 1 && !(e.flags & 6);
       return hipSuccess;
     }
   if (g_entries.size() >= kMaxEntries) return hipErrorOutOfMemory; // caller falls back to the per-pixel kernel
@@ -188,7 +208,7 @@ hipError_t get_output_tables(int device, int out_lens, const LensP &lens, int ou
   if (e != hipSuccess) return e;
   want.tab = tab;
   want.flags = reinterpret_cast<int *>(tab + 2 * n_col + n_row);
-  int flag = 1;
+  int flag = 7;
   e = hipMemsetAsync(want.flags, 0, sizeof(int), 0);
   const unsigned blocks = (unsigned)((n_col + n_row + 255) / 256);
   if (e == hipSuccess) {
@@ -200,10 +220,11 @@ hipError_t get_output_tables(int device, int out_lens, const LensP &lens, int ou
     (void)hipFree(tab);
     return e;
   }
-  g_entries.push_back(Entry{device, want, flag == 0});
+  g_entries.push_back(Entry{device, want, flag});
   *col_tab = tab;
   *row_tab = tab + 2 * n_col;
-  *plain = flag == 0;
+  *plain = !(flag & 1);
+  *mirror = ns == 1 && !(flag & 6);
   return hipSuccess;
 }
 
