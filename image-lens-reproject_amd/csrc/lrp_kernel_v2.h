@@ -694,7 +694,21 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
   const ColTerms col = column_terms<OutLens>(P, xe, 0);
   ColTerms col_m = col; // the mirrored column
   if constexpr (Quad) col_m = column_terms<OutLens>(P, P.out_w - 1 - xe, 0);
-  float qu[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qv[4] = {0.0f, 0.0f, 0.0f, 0.0f};         // stage-1 results of the quadrant pixels
+  // Stage-1 results of the four quadrant pixels of this lane, kept for the whole strip:
+  //   rectilinear / equidistant source: (qa, qb) = plane coordinates (u, v); a mirror image negates them;
+  //   equirectangular source (through the xsep table): qa, qb = source texel y for +phi and for -phi
+  //   (the division of :269 once per sign, not once per mirror image); x comes from the column tables.
+  float qa[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  constexpr bool kInEqr = InMode == kInEquirect || InMode == kInEquirectLoop;
+  auto quad_xy = [&](int g, int k, float &sx, float &sy) { // source texel coordinates of pixel k of mirror image g
+    const bool mx = (g & 1) != 0, my = (g >> 1) != 0;
+    if constexpr (kInEqr) {
+      sx = mx ? col_m.sx : col.sx;
+      sy = my ? qb[k] : qa[k];
+    } else {
+      plane_to_texel<OutLens, InMode>(P, mx ? col_m : col, mx ? -qa[k] : qa[k], my ? -qb[k] : qb[k], sx, sy);
+    }
+  };
 
   // phase A of block g: coordinates, interior vote, window box
   auto coords = [&](int g, WinBlock &b) {
@@ -724,8 +738,19 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
       if (!quad) {
         pixel_source_rt<OutLens, InMode>(P, col, row_v[k], ye, 0, b.sx[k], b.sy[k]);
       } else {
-        if (g == 0) pixel_plane<OutLens, InMode>(P, col, row_v[k], ye, 0, qu[k], qv[k]);
-        plane_to_texel<OutLens, InMode>(P, mx ? col_m : col, mx ? -qu[k] : qu[k], my ? -qv[k] : qv[k], b.sx[k], b.sy[k]);
+        if (g == 0) {
+          float u, v;
+          pixel_plane<OutLens, InMode>(P, col, row_v[k], ye, 0, u, v);
+          if constexpr (kInEqr) { // host guarantees the xsep table: v = phi
+            float unused;
+            plane_to_texel<OutLens, InMode>(P, col, u, v, unused, qa[k]);
+            plane_to_texel<OutLens, InMode>(P, col, u, -v, unused, qb[k]);
+          } else {
+            qa[k] = u;
+            qb[k] = v;
+          }
+        }
+        quad_xy(g, k, b.sx[k], b.sy[k]);
       }
       const f2 sxy{b.sx[k], b.sy[k]};
       const f2 back = (sxy + 2.0f) - sxy; // both coordinates in one packed add / subtract
@@ -841,13 +866,6 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
   // 0-2 are a pass or more old by then, the store of pass 3 is the one vm operation that
   // may still be outstanding when the next block waits: vmcnt(1).  (Every lane stores,
   // see below, so that store is always issued.)
-  // source texel coordinates of mirrored block g from the quadrant's stage-1 results
-  auto texels = [&](int g, WinBlock &b) {
-    const int mx = g & 1, my = g >> 1;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      plane_to_texel<OutLens, InMode>(P, mx ? col_m : col, mx ? -qu[k] : qu[k], my ? -qv[k] : qv[k], b.sx[k], b.sy[k]);
-  };
   WinBlock cur, nxt;
   coords(0, cur);
   issue(0, cur);
@@ -864,10 +882,12 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
     // plain blocks: the next block's coordinates here, long before its window is requested in the
     // last pass; mirrored blocks derive theirs in a few instructions right there (fewer live registers)
     if (!Quad && g + 1 < G) coords(g + 1, nxt);
+#if !defined(LRP_NO_DMA_WAIT) // timing experiment (wrong results): how much of the frame is exposed DMA / store latency
     if (g == 0 || !dma_early || kWinBuffers != 1 || LRP_ABLATE != 0)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the window was the last thing requested
     else
       asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); // window g has landed; block g-1's last store may be in flight
+#endif
     if (kWinBuffers == 2 && g + 1 < G) issue(g + 1, nxt);
     const float4 *const win = win0 + (g & (kWinBuffers - 1)) * kWinCap;
 #pragma unroll
@@ -877,11 +897,13 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
       for (int kk = 0; kk < 2; ++kk) {
         const int k = 2 * h + kk;
         const bool last_pass = kWinBuffers == 1 && LRP_ABLATE == 0 && k == 3;
-        if (Quad && k == 3 && g + 1 < G) coords(g + 1, nxt);
+        if (Quad && k == 3 && g + 1 < G) coords(g + 1, nxt); // only its box is kept
+        float psx = cur.sx[k], psy = cur.sy[k];
+        if constexpr (Quad) quad_xy(g, k, psx, psy); // re-derived (2-4 instructions) instead of held in registers
         Rgba s;
         if (kWinCoef && cur.coef) {
-          const float tx_ = __builtin_truncf(cur.sx[k]), ty_ = __builtin_truncf(cur.sy[k]);
-          const float fx = cur.sx[k] - tx_, fy = cur.sy[k] - ty_;
+          const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
+          const float fx = psx - tx_, fy = psy - ty_;
           const float hfx = 0.5f * fx, hfy = 0.5f * fy;
           const int ix = (int)tx_ - 1 - cur.x_lo, iy = (int)ty_;
           const float4 *ci = win + (cur.c_base + (iy - cur.iy0[h]) * cur.pitch + ix);
@@ -901,8 +923,8 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
           const Rgba k0 = vert(0, b0), k1 = vert(1, b1), k2 = vert(2, b2), k3 = vert(3, b3);
           s = cubic4(k0, k1, k2, k3, fx, hfx);
         } else if (cur.staged) {
-          const float tx_ = __builtin_truncf(cur.sx[k]), ty_ = __builtin_truncf(cur.sy[k]);
-          const float fx = cur.sx[k] - tx_, fy = cur.sy[k] - ty_;
+          const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
+          const float fx = psx - tx_, fy = psy - ty_;
           const float4 *t = win + (__umul24((uint32_t)((int)ty_ - 1 - cur.y_lo), (uint32_t)cur.pitch) +
                                    (uint32_t)((int)tx_ - 1 - cur.x_lo));
           const float hfx = 0.5f * fx, hfy = 0.5f * fy;
@@ -958,7 +980,7 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
 #endif
         } else {
           if (last_pass) next_window(); // nothing staged: no tap of this block reads the window
-          s = sample_direct<2, Loop, 4>(P, src, cur.sx[k], cur.sy[k]);
+          s = sample_direct<2, Loop, 4>(P, src, psx, psy);
         }
         // num_samples == 1: (0.0f + s) * normalize (src/reproject.cpp:334-341)
         Rgba a = px_zero<4>();
@@ -979,7 +1001,6 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
     }
     if (kWinBuffers == 1 && (LRP_ABLATE != 0 || !dma_early) && g + 1 < G) issue(g + 1, nxt); // after the last read of the planes
     cur = nxt;
-    if (Quad && g + 1 < G) texels(g + 1, cur); // the window came from the same values; only the box was kept live
   }
 }
 
