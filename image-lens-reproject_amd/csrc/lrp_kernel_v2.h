@@ -634,6 +634,14 @@ constexpr int kWinCap = LRP_WIN_CAP; // float4 texels per window buffer: 10 KiB 
 #ifndef LRP_WIN_BLOCK_W
 #define LRP_WIN_BLOCK_W 16
 #endif
+#ifndef LRP_WIN_WAVES
+#define LRP_WIN_WAVES 1
+#endif
+// Wavefronts per workgroup of the window kernel.  Its wavefronts share nothing (the window is
+// wave-private), so a workgroup is ONE wavefront: each of the 16 wave slots of a CU is refilled
+// the moment its wavefront retires instead of when the slowest of four does.
+constexpr int kWinWaves = LRP_WIN_WAVES;
+constexpr int kWinThreads = 64 * kWinWaves;
 constexpr int kBlkW = LRP_WIN_BLOCK_W;  // output block per wavefront: kBlkW x kBlkH = 256 pixels,
 constexpr int kBlkH = 256 / kBlkW;      // 4 passes of kBlkW columns x (64 / kBlkW) rows
 constexpr int kPassRows = 64 / kBlkW;
@@ -659,9 +667,9 @@ struct WinBlock {
 // equal, and one 10 KiB buffer per wavefront admits 1:1 and rotated mappings at
 // 4 wavefronts per SIMD, which is worth 5-25 %.)
 template <int OutLens, int InMode, bool Quad>
-__global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubic_win_kernel(const KParams P) {
+__global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicubic_win_kernel(const KParams P) {
   constexpr bool Loop = (InMode == kInEquirectLoop);
-  __shared__ float4 s_win[kT2Waves][kWinBuffers][kWinCap];
+  __shared__ float4 s_win[kWinWaves][kWinBuffers][kWinCap];
 
   const int n_tiles = P.tiles_x * P.tiles_y;
   const int chunk = (n_tiles + kXcds - 1) / kXcds;
@@ -683,8 +691,8 @@ __global__ __launch_bounds__(kT2Threads, LRP_WIN_MINWAVES) void reproject_bicubi
   constexpr bool quad = Quad;
   const int qw = quad ? (P.out_w + 1) >> 1 : P.out_w; // columns / rows enumerated by the launch
   const int qh = quad ? (P.out_h + 1) >> 1 : P.out_h;
-  // workgroup tile = 64 x 16G (64 x 16 of the quadrant when mirrored): four strips side by side, one per wavefront
-  const int x = tx * (kBlkW * kT2Waves) + wave * kBlkW + (lane & (kBlkW - 1));
+  // workgroup tile = 16 kWinWaves x 16G (x 16 of the quadrant when mirrored): one strip per wavefront
+  const int x = tx * (kBlkW * kWinWaves) + wave * kBlkW + (lane & (kBlkW - 1));
   const int y_lane = P.y_offset + ty * (quad ? kBlkH : kBlkH * G) + lane / kBlkW; // + kBlkH * g + kPassRows * pass
   const int xe = x < qw ? x : qw - 1;
   const int in_w = P.in_w;
@@ -1060,22 +1068,22 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
   const int rows = P.out_h - P.y_offset;
   if (Quad) {
     // the launch enumerates the top-left quadrant; a wavefront renders a block and its three mirror images
-    P.tiles_x = ((P.out_w + 1) / 2 + kBlkW * kT2Waves - 1) / (kBlkW * kT2Waves);
+    P.tiles_x = ((P.out_w + 1) / 2 + kBlkW * kWinWaves - 1) / (kBlkW * kWinWaves);
     P.tiles_y = ((P.out_h + 1) / 2 + kBlkH - 1) / kBlkH;
     P.blocks_per_wave = 4;
   } else {
-    P.tiles_x = (P.out_w + kBlkW * kT2Waves - 1) / (kBlkW * kT2Waves);
+    P.tiles_x = (P.out_w + kBlkW * kWinWaves - 1) / (kBlkW * kWinWaves);
     // strips of LRP_WIN_STRIP blocks when that still leaves >= 8 workgroups per CU, else shorter
     const int row_blocks = (rows + kBlkH - 1) / kBlkH;
     int G = LRP_WIN_STRIP;
-    while (G > 1 && (long long)P.tiles_x * ((row_blocks + G - 1) / G) < 2048) G >>= 1;
+    while (G > 1 && (long long)P.tiles_x * kWinWaves * ((row_blocks + G - 1) / G) < 8192) G >>= 1; // >= 2 rounds of wavefronts
     P.blocks_per_wave = G;
     P.tiles_y = (row_blocks + G - 1) / G;
   }
   const int n_tiles = P.tiles_x * P.tiles_y;
   if (n_tiles <= 0) return hipSuccess;
   const int chunk = (n_tiles + kXcds - 1) / kXcds;
-  hipLaunchKernelGGL(WinKernelTable<Quad>::get(out_idx, in_mode), dim3((unsigned)(chunk * kXcds)), dim3(kT2Threads), 0,
+  hipLaunchKernelGGL(WinKernelTable<Quad>::get(out_idx, in_mode), dim3((unsigned)(chunk * kXcds)), dim3(kWinThreads), 0,
                      stream, P);
   return hipGetLastError();
 }
