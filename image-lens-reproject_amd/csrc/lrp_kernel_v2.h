@@ -535,7 +535,11 @@ __device__ __forceinline__ void store_px(const KParams &P, uint32_t pixel_index,
   typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
   typedef float v3f_a4 __attribute__((ext_vector_type(3), aligned(4)));
   if constexpr (CH == 4) {
+#if defined(LRP_PLAIN_STORE) // timing experiment: ordinary (L2-allocating) stores
+    *reinterpret_cast<v4f *>(d) = v4f{c[0], c[1], c[2], c[3]};
+#else
     __builtin_nontemporal_store(v4f{c[0], c[1], c[2], c[3]}, reinterpret_cast<v4f *>(d));
+#endif
   } else if constexpr (CH == 3) { // one dwordx3 per lane: a wavefront's row is 768 contiguous bytes
     __builtin_nontemporal_store(v3f_a4{c[0], c[1], c[2]}, reinterpret_cast<v3f_a4 *>(d));
   } else { // dwordx4 + dword (4-byte aligned): 1280 contiguous bytes per wavefront row

@@ -106,6 +106,42 @@ uint64_t lrp_check_unary(int func, uint32_t begin, uint64_t count, uint32_t stri
   return bad.load();
 }
 
+// Odd symmetry of the own functions, bit for bit: f(-x) == -f(x) for every non-negative bit
+// pattern (NaN in, NaN out).  The mirrored blocks of the window kernel rely on it for asinf
+// (phi of the mirrored ray = -phi) besides the IEEE symmetry of *, /, sqrt.
+uint64_t lrp_check_odd(int func, int threads, uint32_t *first_bad) {
+  std::atomic<uint64_t> bad{0};
+  std::atomic<uint64_t> first{~0ull};
+  if (threads < 1) threads = 1;
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) {
+    pool.emplace_back([&, t]() {
+      uint64_t local = 0;
+      for (uint64_t i = (uint64_t)t; i < (1ull << 31); i += (uint64_t)threads) {
+        const uint32_t u = (uint32_t)i, un = u | 0x80000000u;
+        float x, xn;
+        memcpy(&x, &u, 4);
+        memcpy(&xn, &un, 4);
+        const float a = own(func, x), b = own(func, xn);
+        uint32_t ua, ub;
+        memcpy(&ua, &a, 4);
+        memcpy(&ub, &b, 4);
+        const bool ok = (a != a && b != b) || ub == (ua ^ 0x80000000u);
+        if (!ok) {
+          ++local;
+          uint64_t cur = first.load();
+          while ((uint64_t)u < cur && !first.compare_exchange_weak(cur, (uint64_t)u)) {
+          }
+        }
+      }
+      bad += local;
+    });
+  }
+  for (auto &th : pool) th.join();
+  if (first_bad) *first_bad = (uint32_t)first.load();
+  return bad.load();
+}
+
 // atan2f: `count` pseudo-random pairs.  mode 0: both operands uniform over all
 // bit patterns; mode 1: uniform finite magnitudes in a lens-like range
 // (|v| in [2^-20, 2^20)) with random signs; mode 2: exponent-difference probe

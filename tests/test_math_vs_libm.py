@@ -24,6 +24,8 @@ def chk():
     L.lrp_check_atan2.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
                                   ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
     L.lrp_eval_atan2.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_uint64]
+    L.lrp_check_odd.restype = ctypes.c_uint64
+    L.lrp_check_odd.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]
     return L
 
 
@@ -33,6 +35,15 @@ def test_unary_exhaustive(chk, func, name):
     first = ctypes.c_uint32(0)
     bad = chk.lrp_check_unary(func, 0, 1 << 32, 1, THREADS, ctypes.byref(first))
     assert bad == 0, f"{name}: {bad} of 2^32 inputs differ from libm, first bit pattern 0x{first.value:08x}"
+
+
+@pytest.mark.parametrize("func,name", [(0, "sinf"), (4, "atanf"), (5, "asinf")])
+def test_odd_functions_are_odd_bit_for_bit(chk, func, name):
+    """f(-x) == -f(x) for all 2^31 magnitudes: the mirrored blocks of the window kernel share one
+    evaluation between the four mirror images of a pixel (asinf for equirectangular sources)."""
+    first = ctypes.c_uint32(0)
+    bad = chk.lrp_check_odd(func, THREADS, ctypes.byref(first))
+    assert bad == 0, f"{name}: {bad} magnitudes with f(-x) != -f(x), first 0x{first.value:08x}"
 
 
 @pytest.mark.parametrize("mode,count", [(0, 1 << 27), (1, 1 << 28), (2, 1 << 26)])

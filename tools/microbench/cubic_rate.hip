@@ -1,6 +1,10 @@
 // cubic_rate.hip — cost of the reference's bicubic arithmetic (20 Catmull-Rom
 // evaluations per RGBA pixel, un-fused) on register data, packed (v_pk_*) versus
 // scalar, as a function of resident wavefronts per SIMD.
+// CAVEAT (found later in the round): only 4 of the 32 tap pairs change per iteration, so the
+// compiler hoists the weight-independent 11 of 17 operations of the other cubics out of the
+// loop; the cycles printed here are for ~122 of the 170 packed instructions.  Instruction
+// costs proper: valu_operands.hip.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off cubic_rate.hip -o cubic_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -38,8 +38,8 @@ if cal:
     write_factor = KNOWN / write[k] if k in write and write[k] else 1.0
     calibration = {"kernel": k, "known_bytes_each_way": KNOWN, "FETCH_SIZE_bytes_raw": fetch[k],
                    "WRITE_SIZE_bytes_raw": write.get(k), "read_factor": read_factor, "write_factor": write_factor}
-names = {"reproject_bicubic_win_kernel<0, 1>": "fisheye_to_rect_bicubic",
-         "reproject_bicubic_win_kernel<0, 3>": "equirect_to_rect_bicubic",
+names = {"reproject_bicubic_win_kernel<0, 1,": "fisheye_to_rect_bicubic",
+         "reproject_bicubic_win_kernel<0, 3,": "equirect_to_rect_bicubic",
          "reproject_tile_kernel<1, 3, 1, 4>": "equirect_to_fisheye_bilinear",
          "reproject_tile_kernel<0, 3, 0, 4>": "equirect_to_rect_nearest"}
 result = {"_calibration": calibration,
