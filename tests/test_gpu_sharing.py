@@ -1,0 +1,108 @@
+"""-m gpu: the three work-sharing paths of the tile / window kernels against the oracle, bit
+for bit, at the edges of their applicability.
+
+* column-separable source x (lrp_tables.hip build_xsep_kernel): no rotation, identity, pan-only
+  rotations (cubemap side faces), and rotations for which it must NOT be used;
+* dropped identity rotation (ray tables without -0.0f / non-finite values);
+* mirrored blocks of the window kernel: odd and even sizes (the centre column / row is its own
+  mirror image), non-square and tiny images, every source lens, equidistant target;
+* shared tap-column coefficients: magnified windows around the image centre and at the seam.
+Each case renders with the default family (everything on), with the window kernel's sharing
+switched off (family 3) and with the one-pixel-per-lane kernel (family 0)."""
+import math
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def render_all(lrp, torch, lin, src, lout, out_w, out_h, interp, rot, what, want, channels=4, families=(2, 3, 0)):
+    d_in = torch.from_numpy(src).cuda()
+    for family in families:
+        prev = lrp.debug_kernel(family)
+        try:
+            d_out = torch.full((out_h, out_w, channels), -777.0, dtype=torch.float32, device="cuda")
+            lrp.reproject(lrp.Image(lin, src.shape[1], src.shape[0], channels, d_in),
+                          lrp.Image(lout, out_w, out_h, channels, d_out), 1, interp, rot)
+            torch.cuda.synchronize()
+        finally:
+            lrp.debug_kernel(prev)
+        cases.assert_same_bits(d_out.cpu().numpy(), want, f"{what}, family {family}")
+
+
+SIZES = [(256, 192), (255, 193), (257, 191), (64, 48), (33, 17), (16, 16), (5, 3), (130, 1), (1, 77)]
+
+
+@pytest.mark.parametrize("out_w,out_h", SIZES)
+@pytest.mark.parametrize("in_name,out_name", [("eqd180", "rect"), ("eqr_full", "rect"), ("rect_tele", "rect"),
+                                              ("eqd180", "eqd120"), ("rect", "eqd120"), ("eqr_part", "rect")])
+def test_mirrored_blocks_all_sizes(lrp, oracle, torch_cuda, out_w, out_h, in_name, out_name):
+    """No rotation and the identity matrix: the window kernel renders a block and its three
+    mirror images from one evaluation of the coordinate math (where the lens pair allows)."""
+    in_w, in_h = 150, 110
+    src = cases.hash_noise(in_h, in_w, 4, seed=out_w * 7 + out_h)
+    lin, lout = cases.lenses(lrp, in_w, in_h)[in_name], cases.lenses(lrp, out_w, out_h)[out_name]
+    for deg in (None, (0.0, 0.0, 0.0)):
+        rot = cases.rotation(lrp, deg)
+        want = oracle.reproject(lin, src, lout, out_w, out_h, 1, 2, rot, threads=8)
+        render_all(lrp, torch_cuda, lin, src, lout, out_w, out_h, 2, rot, f"{in_name}->{out_name} {out_w}x{out_h} rot={deg}", want)
+
+
+@pytest.mark.parametrize("deg", [(90.0, 0.0, 0.0), (180.0, 0.0, 0.0), (270.0, 0.0, 0.0), (37.5, 0.0, 0.0), (-120.0, 0.0, 0.0),
+                                 (0.0, 90.0, 0.0), (0.0, -90.0, 0.0), (0.0, 0.0, 45.0), (20.0, 1e-3, 0.0), (20.0, 0.0, 1e-3)])
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_column_separable_source_x_and_its_limits(lrp, oracle, torch_cuda, deg, interp):
+    """Pan-only rotations keep the ray's x and z independent of the row (column table used);
+    pitch / roll do not (table must not be used).  Equirectangular and rectilinear sources,
+    rectilinear and equirectangular targets, RGB and RGBA."""
+    in_w, in_h, out_w, out_h = 384, 192, 200, 136
+    rot = cases.rotation(lrp, deg)
+    for in_name, out_name, c in (("eqr_full", "rect", 4), ("eqr_part", "rect", 3), ("rect", "eqr_full", 4),
+                                 ("eqr_full", "eqr_part", 4), ("rect_tele", "rect", 5)):
+        src = cases.hash_noise(in_h, in_w, c, seed=interp + 10 * c)
+        lin, lout = cases.lenses(lrp, in_w, in_h)[in_name], cases.lenses(lrp, out_w, out_h)[out_name]
+        want = oracle.reproject(lin, src, lout, out_w, out_h, 1, interp, rot, threads=8)
+        fam = (2, 3, 0) if c == 4 else (2, 0)
+        render_all(lrp, torch_cuda, lin, src, lout, out_w, out_h, interp, rot, f"{in_name}->{out_name} C={c} rot={deg} interp={interp}",
+                   want, channels=c, families=fam)
+
+
+def test_identity_is_not_dropped_when_the_tables_hold_negative_zero(lrp, oracle, torch_cuda):
+    """A negative focal length turns the centre column's +0 into -0: R v then differs from v in
+    the sign of a zero, and the identity matrix must be applied as given."""
+    in_w, in_h, out_w, out_h = 96, 64, 63, 41  # odd output size: centre column and row are exactly 0
+    L = lrp.LensInfo
+    lout = L.rectilinear(-18.0, 36.0, out_w, out_h)
+    src = cases.hash_noise(in_h, in_w, 4, seed=5)
+    for lin in (L.equirectangular(), L.equidistant(math.pi), L.rectilinear(24.0, 36.0, in_w, in_h)):
+        for deg in (None, (0.0, 0.0, 0.0), (90.0, 0.0, 0.0)):
+            rot = cases.rotation(lrp, deg)
+            for interp in (0, 2):
+                with np.errstate(all="ignore"):
+                    want = oracle.reproject(lin, src, lout, out_w, out_h, 1, interp, rot)
+                render_all(lrp, torch_cuda, lin, src, lout, out_w, out_h, interp, rot, f"negative focal, lens {lin.type}, rot={deg}", want)
+
+
+def test_mirrored_4k_frame_with_odd_size_matches_pixel_kernel(lrp, torch_cuda):
+    """4095 x 4097 output (odd both ways) from a 4K fisheye frame: mirrored window kernel against
+    the one-pixel-per-lane kernel over the whole frame."""
+    torch = torch_cuda
+    n = 4096
+    d_in = torch.empty((n, n, 4), dtype=torch.float32, device="cuda")
+    lrp.synth_fill(d_in, n, n, 4, 0x5EED0042)
+    out_w, out_h = 4095, 4097
+    lin, lout = lrp.LensInfo.equidistant(math.pi), lrp.LensInfo.rectilinear(18.0, 36.0, out_w, out_h)
+    outs = []
+    for family in (2, 0):
+        prev = lrp.debug_kernel(family)
+        try:
+            d_out = torch.full((out_h, out_w, 4), -1.0, dtype=torch.float32, device="cuda")
+            lrp.reproject(lrp.Image(lin, n, n, 4, d_in), lrp.Image(lout, out_w, out_h, 4, d_out), 1, 2, None)
+            torch.cuda.synchronize()
+        finally:
+            lrp.debug_kernel(prev)
+        outs.append(d_out)
+    assert bool(torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)))
