@@ -220,23 +220,24 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     }
   }
   if (tile) {
+    // Mirrored pixels / blocks: without a rotation the mapping is symmetric about both image axes
+    // and the lens-plane coordinates of the four mirror pixels differ in sign only (lrp_kernel_v2.h).
+    // Rectilinear / equirectangular target: the ray tables must be mirror images bit for bit;
+    // equidistant target: the ray is odd in cx, cy by construction.  An equirectangular source
+    // takes part through the column-separable x table only (its longitude is not odd in x).
+    // Family 3 keeps every sharing path of the tile / window kernels off (cross-checks).
+    const bool in_eqr = im == lrp::kInEquirect || im == lrp::kInEquirectLoop;
+    const bool sym_out = out->lens.type == LRP_FISHEYE_EQUIDISTANT ? true : mirror;
+    P.quad = quad_enabled() && kernel_choice() != 3 && num_samples == 1 && !P.has_rot && sym_out &&
+             (!in_eqr || P.xsep_tab != nullptr);
     if (interpolation == LRP_NEAREST)
       e = lrp::launch_tile_nearest(P, oi, im, stream);
     else if (interpolation == LRP_BILINEAR)
       e = lrp::launch_tile_bilinear(P, oi, im, stream);
     else if (kernel_choice() >= 2 && num_samples == 1 && out->channels == 4) {
       P.win_coef = kernel_choice() == 2;
-      // Mirrored blocks: without a rotation the mapping is symmetric about both image axes and
-      // the lens-plane coordinates of the four mirror pixels differ in sign only (lrp_kernel_v2.h).
-      // Rectilinear / equirectangular target: the ray tables must be mirror images bit for bit;
-      // equidistant target: the ray is odd in cx, cy by construction.  An equirectangular source
-      // takes part through the column-separable x table only (its longitude is not odd in x).
-      const bool in_eqr = im == lrp::kInEquirect || im == lrp::kInEquirectLoop;
-      const bool sym_out = out->lens.type == LRP_FISHEYE_EQUIDISTANT ? true : mirror;
-      P.quad = quad_enabled() && kernel_choice() == 2 && !P.has_rot && sym_out && (!in_eqr || P.xsep_tab != nullptr);
       e = lrp::launch_win_bicubic(P, oi, im, stream);
-    }
-    else
+    } else
       e = lrp::launch_tile_bicubic(P, oi, im, stream);
   } else if (interpolation == LRP_NEAREST)
     e = lrp::launch_nearest(P, oi, im, stream);

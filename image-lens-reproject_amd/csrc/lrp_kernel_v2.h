@@ -566,9 +566,50 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
   const int y_first = P.y_offset + (ty * kT2Waves + wave) * kT2Rows; // wave-uniform
   // Lanes / rows beyond the image recompute the last valid pixel and never store
   // (all 64 lanes stay active for the wave-wide votes).
+  const SrcView src = source_view<Interp, CH>(P);
+  if (P.quad) {
+    // Mirrored pixels (num_samples == 1, no rotation; see the window kernel below for why this is
+    // exact): the launch enumerates the top-left quadrant, stage 1 of the coordinate math runs
+    // once per quadrant pixel and serves its three mirror images as well.
+    constexpr bool kInEqr = InMode == kInEquirect || InMode == kInEquirectLoop;
+    const int qw = (P.out_w + 1) >> 1, qh = (P.out_h + 1) >> 1;
+    const int xq = x < qw ? x : qw - 1;
+    const ColTerms col = column_terms<OutLens>(P, xq, 0);
+    const ColTerms col_m = column_terms<OutLens>(P, P.out_w - 1 - xq, 0);
+#pragma unroll
+    for (int k = 0; k < kT2Rows; ++k) {
+      const int yk = y_first + k;
+      const int yq = yk < qh ? yk : qh - 1; // wave-uniform
+      float u, v, qa, qb;
+      pixel_plane<OutLens, InMode>(P, col, row_term<OutLens>(P, yq, 0), yq, 0, u, v);
+      if constexpr (kInEqr) { // through the column table (host guarantees it): v = phi; y texel for both signs
+        float unused;
+        plane_to_texel<OutLens, InMode>(P, col, u, v, unused, qa);
+        plane_to_texel<OutLens, InMode>(P, col, u, -v, unused, qb);
+      } else {
+        qa = u;
+        qb = v;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const bool mx = (g & 1) != 0, my = (g >> 1) != 0;
+        float sx, sy;
+        if constexpr (kInEqr) {
+          sx = mx ? col_m.sx : col.sx;
+          sy = my ? qb : qa;
+        } else {
+          plane_to_texel<OutLens, InMode>(P, mx ? col_m : col, mx ? -qa : qa, my ? -qb : qb, sx, sy);
+        }
+        Px<CH> a = px_zero<CH>();
+        px_add<CH>(a, sample_direct<Interp, Loop, CH>(P, src, sx, sy)); // :334-336
+        const int xo = mx ? P.out_w - 1 - x : x, yo = my ? P.out_h - 1 - yk : yk;
+        if (x < qw && yk < qh) store_px<CH>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
+      }
+    }
+    return;
+  }
   const int xe = x < P.out_w ? x : P.out_w - 1;
   const int ns = P.num_samples;
-  const SrcView src = source_view<Interp, CH>(P);
 
   Px<CH> acc[kT2Rows];
 #pragma unroll
@@ -1036,10 +1077,15 @@ template <int Interp, int CH> struct TileKernelTable {
 
 // P.channels must be 3, 4 or 5.
 template <int Interp> hipError_t launch_tile_interp(KParams P, int out_idx, int in_mode, hipStream_t stream) {
-  P.tiles_x = (P.out_w + kT2W - 1) / kT2W;
-  const int rows = P.out_h - P.y_offset;
   constexpr int tile_h = tile_rows<Interp>() * kT2Waves;
-  P.tiles_y = (rows + tile_h - 1) / tile_h;
+  if (P.quad) { // the top-left quadrant only: every pixel also renders its three mirror images
+    P.tiles_x = ((P.out_w + 1) / 2 + kT2W - 1) / kT2W;
+    P.tiles_y = ((P.out_h + 1) / 2 + tile_h - 1) / tile_h;
+  } else {
+    P.tiles_x = (P.out_w + kT2W - 1) / kT2W;
+    const int rows = P.out_h - P.y_offset;
+    P.tiles_y = (rows + tile_h - 1) / tile_h;
+  }
   const int n_tiles = P.tiles_x * P.tiles_y;
   if (n_tiles <= 0) return hipSuccess;
   const int chunk = (n_tiles + kXcds - 1) / kXcds;
