@@ -230,14 +230,20 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     const bool sym_out = out->lens.type == LRP_FISHEYE_EQUIDISTANT ? true : mirror;
     P.quad = quad_enabled() && kernel_choice() != 3 && num_samples == 1 && !P.has_rot && sym_out &&
              (!in_eqr || P.xsep_tab != nullptr);
-    if (interpolation == LRP_NEAREST)
+    const bool window = interpolation == LRP_BICUBIC && kernel_choice() >= 2 && num_samples == 1 && out->channels == 4;
+    // Equidistant target, rotated (or an equirectangular source): the four mirror pixels still
+    // share the ray through the output lens (tile kernels only).
+    if (!P.quad && !window && quad_enabled() && kernel_choice() != 3 && num_samples == 1 &&
+        out->lens.type == LRP_FISHEYE_EQUIDISTANT)
+      P.quad = 2;
+    if (window) {
+      P.win_coef = kernel_choice() == 2;
+      e = lrp::launch_win_bicubic(P, oi, im, stream);
+    } else if (interpolation == LRP_NEAREST)
       e = lrp::launch_tile_nearest(P, oi, im, stream);
     else if (interpolation == LRP_BILINEAR)
       e = lrp::launch_tile_bilinear(P, oi, im, stream);
-    else if (kernel_choice() >= 2 && num_samples == 1 && out->channels == 4) {
-      P.win_coef = kernel_choice() == 2;
-      e = lrp::launch_win_bicubic(P, oi, im, stream);
-    } else
+    else
       e = lrp::launch_tile_bicubic(P, oi, im, stream);
   } else if (interpolation == LRP_NEAREST)
     e = lrp::launch_nearest(P, oi, im, stream);

@@ -307,6 +307,46 @@ template <int OutLens> __device__ __forceinline__ ColTerms column_terms(const KP
   return c;
 }
 
+// Stage 0: the ray of one sub-sample through the OUTPUT lens (src/reproject.cpp:152-158, 171-186,
+// 245-257).  Mirroring the output pixel about the image centre negates vx / vy exactly.
+template <int OutLens>
+__device__ __forceinline__ void pixel_ray(const KParams &P, const ColTerms col, float row_v, int ye, int ssy, float &vx,
+                                          float &vy, float &vz) {
+  if constexpr (OutLens == kRect) {
+    vx = col.a;
+    vy = row_v;
+    vz = -1.0f;
+  } else if constexpr (OutLens == kEquirect) {
+    vx = col.a;
+    vz = col.b;
+    vy = row_v;
+  } else {
+    const float cy = ((float)ye + 0.5f) - (float)P.out_h * 0.5f;                       // :288
+    const float scy = cy + ((float)ssy + 1.0f) / ((float)P.num_samples + 1.0f) - 0.5f; // :298
+    equidistant_ray_v2(P, col.a, scy, vx, vy, vz);
+  }
+}
+
+// Rotation (:303-311) and projection through the INPUT lens up to the lens-plane coordinates.
+template <int InMode>
+__device__ __forceinline__ void ray_to_plane(const KParams &P, float vx, float vy, float vz, float &u, float &v) {
+  if (P.has_rot) {
+    const float nx = P.rot[0] * vx + P.rot[1] * vy + P.rot[2] * vz;
+    const float ny = P.rot[3] * vx + P.rot[4] * vy + P.rot[5] * vz;
+    const float nz = P.rot[6] * vx + P.rot[7] * vy + P.rot[8] * vz;
+    vx = nx;
+    vy = ny;
+    vz = nz;
+  }
+#if defined(LRP_TRIVIAL_COORDS) // timing experiment: trivial coordinates (memory path only)
+  u = vx * 1000.0f;
+  v = vy * 1000.0f;
+  (void)vz;
+#else
+  ray_to_source_v2<InMode>(P, vx, vy, vz, u, v);
+#endif
+}
+
 // One sub-sample of output pixel (column terms `col`, row term `row_v` of row ye) ->
 // top-left-origin source texel coordinates, in two stages.  All 64 lanes must be active
 // (wave-wide vote inside).  row_v is unused for the equidistant target; ye / ssy are
@@ -344,34 +384,8 @@ __device__ __forceinline__ void pixel_plane(const KParams &P, const ColTerms col
       return;
     }
   }
-  if constexpr (OutLens == kRect) {
-    vx = col.a;
-    vy = row_v;
-    vz = -1.0f;
-  } else if constexpr (OutLens == kEquirect) {
-    vx = col.a;
-    vz = col.b;
-    vy = row_v;
-  } else {
-    const float cy = ((float)ye + 0.5f) - (float)P.out_h * 0.5f;                       // :288
-    const float scy = cy + ((float)ssy + 1.0f) / ((float)P.num_samples + 1.0f) - 0.5f; // :298
-    equidistant_ray_v2(P, col.a, scy, vx, vy, vz);
-  }
-  if (P.has_rot) { // :303-311
-    const float nx = P.rot[0] * vx + P.rot[1] * vy + P.rot[2] * vz;
-    const float ny = P.rot[3] * vx + P.rot[4] * vy + P.rot[5] * vz;
-    const float nz = P.rot[6] * vx + P.rot[7] * vy + P.rot[8] * vz;
-    vx = nx;
-    vy = ny;
-    vz = nz;
-  }
-#if defined(LRP_TRIVIAL_COORDS) // timing experiment: trivial coordinates (memory path only)
-  u = vx * 1000.0f;
-  v = vy * 1000.0f;
-  (void)vz;
-#else
-  ray_to_source_v2<InMode>(P, vx, vy, vz, u, v);
-#endif
+  pixel_ray<OutLens>(P, col, row_v, ye, ssy, vx, vy, vz);
+  ray_to_plane<InMode>(P, vx, vy, vz, u, v);
 }
 
 template <int OutLens, int InMode>
@@ -567,6 +581,40 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
   // Lanes / rows beyond the image recompute the last valid pixel and never store
   // (all 64 lanes stay active for the wave-wide votes).
   const SrcView src = source_view<Interp, CH>(P);
+  if (P.quad == 2) {
+    // Mirrored rays (equidistant target, num_samples == 1, any rotation): the ray through the
+    // OUTPUT lens — a square root, sincosf and three divides per pixel that no table can hold,
+    // the target is not separable — is odd in cx, cy (src/reproject.cpp:171-186: r_px is even,
+    // vx = s * cx, vy = s * cy, vz = cos theta), so it is evaluated once per quadrant pixel; the
+    // rotation and the source lens then run per mirror image as usual.
+    if constexpr (OutLens == kEquidistant) {
+      const int qw = (P.out_w + 1) >> 1, qh = (P.out_h + 1) >> 1;
+      const int xq = x < qw ? x : qw - 1;
+      const ColTerms col = column_terms<OutLens>(P, xq, 0);
+#pragma unroll
+      for (int k = 0; k < kT2Rows; ++k) {
+        const int yk = y_first + k;
+        const int yq = yk < qh ? yk : qh - 1; // wave-uniform
+        float vx, vy, vz;
+        pixel_ray<OutLens>(P, col, 0.0f, yq, 0, vx, vy, vz);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bool mx = (g & 1) != 0, my = (g >> 1) != 0;
+          float u, v, sx, sy;
+          // the centre column / row of an odd-sized image is its own mirror image: its ray component
+          // is +0 and stays +0 (a -0 would be a different input to atan2f)
+          const bool neg_x = mx && 2 * x != P.out_w - 1, neg_y = my && 2 * yk != P.out_h - 1;
+          ray_to_plane<InMode>(P, neg_x ? -vx : vx, neg_y ? -vy : vy, vz, u, v);
+          plane_to_texel<OutLens, InMode>(P, col, u, v, sx, sy);
+          Px<CH> a = px_zero<CH>();
+          px_add<CH>(a, sample_direct<Interp, Loop, CH>(P, src, sx, sy)); // :334-336
+          const int xo = mx ? P.out_w - 1 - x : x, yo = my ? P.out_h - 1 - yk : yk;
+          if (x < qw && yk < qh) store_px<CH>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
+        }
+      }
+    }
+    return;
+  }
   if (P.quad) {
     // Mirrored pixels (num_samples == 1, no rotation; see the window kernel below for why this is
     // exact): the launch enumerates the top-left quadrant, stage 1 of the coordinate math runs

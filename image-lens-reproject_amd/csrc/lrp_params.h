@@ -52,7 +52,7 @@ struct KParams {
   float in_lon_span, in_lat_span;   // equirectangular source
   int32_t blocks_per_wave;          // window kernel: 16 x 16 blocks per wavefront strip
   int32_t win_coef;                 // window kernel: shared tap-column coefficients allowed (0: raw taps only)
-  int32_t quad;                     // window kernel: mirrored blocks (mapping symmetric about both image axes)
+  int32_t quad;                     // 1: mirrored pixels / blocks (mapping symmetric about both image axes); 2: mirrored rays (tile kernels, equidistant target)
 };
 
 } // namespace lrp

@@ -106,3 +106,22 @@ def test_mirrored_4k_frame_with_odd_size_matches_pixel_kernel(lrp, torch_cuda):
             lrp.debug_kernel(prev)
         outs.append(d_out)
     assert bool(torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)))
+
+
+@pytest.mark.parametrize("out_w,out_h", [(200, 136), (201, 137), (65, 33), (7, 5)])
+@pytest.mark.parametrize("deg", [None, (30.0, -15.0, 5.0), (0.0, 90.0, 0.0), (180.0, 0.0, 0.0)])
+def test_mirrored_rays_equidistant_target(lrp, oracle, torch_cuda, out_w, out_h, deg):
+    """Equidistant target: the four mirror pixels share the ray through the output lens under any
+    rotation (tile kernels); the centre column / row of an odd-sized image is its own mirror
+    image and keeps its +0 ray component."""
+    in_w, in_h = 300, 160
+    rot = cases.rotation(lrp, deg)
+    lout = cases.lenses(lrp, out_w, out_h)["eqd180"]
+    for in_name in ("eqr_full", "eqr_part", "rect", "eqd120"):
+        lin = cases.lenses(lrp, in_w, in_h)[in_name]
+        for c, interp in ((4, 0), (4, 1), (3, 2), (5, 1)):
+            src = cases.hash_noise(in_h, in_w, c, seed=c + interp)
+            with np.errstate(all="ignore"):
+                want = oracle.reproject(lin, src, lout, out_w, out_h, 1, interp, rot, threads=8)
+            render_all(lrp, torch_cuda, lin, src, lout, out_w, out_h, interp, rot,
+                       f"{in_name}->eqd180 {out_w}x{out_h} C={c} interp={interp} rot={deg}", want, channels=c, families=(2, 0))
