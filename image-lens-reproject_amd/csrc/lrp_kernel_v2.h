@@ -759,9 +759,17 @@ struct WinBlock {
 // (kWinBuffers == 2 issues DMA(g+1) before the cubics of block g instead; measured
 // equal, and one 10 KiB buffer per wavefront admits 1:1 and rotated mappings at
 // 4 wavefronts per SIMD, which is worth 5-25 %.)
-template <int OutLens, int InMode, bool Quad>
+//
+// CH == 3 (RGB, what the PNG / JPEG path delivers): global_load_lds_dwordx3 reads 12 bytes per
+// lane and writes them at a 16-byte lane stride (measured: the fourth dword of each slot is left
+// untouched), i.e. the hardware expands RGB texels into RGBA-sized slots.  Everything after the
+// DMA is therefore the RGBA code; the fourth component carries stale LDS contents through the
+// arithmetic (no traps are enabled) and is never stored.
+template <int OutLens, int InMode, bool Quad, int CH>
 __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicubic_win_kernel(const KParams P) {
+  static_assert(CH == 3 || CH == 4, "window kernel: RGB or RGBA");
   constexpr bool Loop = (InMode == kInEquirectLoop);
+  constexpr int kPlanes = 3;
   __shared__ float4 s_win[kWinWaves][kWinBuffers][kWinCap];
 
   const int n_tiles = P.tiles_x * P.tiles_y;
@@ -789,7 +797,7 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
   const int y_lane = P.y_offset + ty * (quad ? kBlkH : kBlkH * G) + lane / kBlkW; // + kBlkH * g + kPassRows * pass
   const int xe = x < qw ? x : qw - 1;
   const int in_w = P.in_w;
-  const SrcView src = source_view<2, 4>(P);
+  const SrcView src = source_view<2, CH>(P);
   const float4 *__restrict__ src4 = reinterpret_cast<const float4 *>(P.src);
   float4 *const win0 = s_win[wave][0];
   const ColTerms col = column_terms<OutLens>(P, xe, 0);
@@ -811,6 +819,8 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
     }
   };
 
+  // 16-byte LDS slots of the raw window
+  auto raw_slots = [](const WinBlock &b) { return b.pitch * b.bh; };
   // phase A of block g: coordinates, interior vote, window box
   auto coords = [&](int g, WinBlock &b) {
     // Per pixel only the exactness half of interior() (it also fails for NaN / inf);
@@ -885,18 +895,18 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
         b.bw = x_last + 2 - b.x_lo + 1;
         b.bh = y_last + 2 - b.y_lo + 1;
         b.pitch = b.bw | 1; // odd: consecutive window rows start an odd number of 16 B slots apart
-        b.staged = b.bw <= 64 && b.pitch * b.bh <= kWinCap;
+        b.staged = b.bw <= 64 && raw_slots(b) <= kWinCap;
         // coefficient tier: three planes of pitch x iyn[h] tap-column origins behind the raw window
         b.iy0[0] = ya_first;
         b.iyn[0] = ya_last - ya_first + 1;
         b.iy0[1] = yb_first;
         b.iyn[1] = yb_last - yb_first + 1;
         b.c_plane = b.pitch * max(b.iyn[0], b.iyn[1]);
-        b.coef = kWinCoef && P.win_coef != 0 && b.staged && b.pitch * b.bh + 3 * b.c_plane <= kWinCap;
+        b.coef = kWinCoef && P.win_coef != 0 && b.staged && raw_slots(b) + kPlanes * b.c_plane <= kWinCap;
         // planes behind the raw window plus, where there is room, one row and one column of slack:
         // the next block's (slightly different) window can then be requested while this block's
         // planes are still being read (see next_window)
-        b.c_base = min(b.pitch * b.bh + b.pitch + b.bh + 1, kWinCap - 3 * b.c_plane);
+        b.c_base = min(raw_slots(b) + b.pitch + b.bh + 1, kWinCap - kPlanes * b.c_plane);
       }
     }
   };
@@ -905,6 +915,7 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
       // LDS-DMA, one window row per instruction, lanes beyond the width masked off
       float4 *const win = win0 + (g & (kWinBuffers - 1)) * kWinCap;
       const float4 *gp = src4 + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane));
+      const float *gp3 = P.src + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane)) * 3u;
       // Issued as inline assembly: the compiler's wait-count insertion then does not know
       // that LDS is being written and puts no vmcnt(0) in front of later LDS reads (of the
       // coefficient planes, which the DMA does not touch); the one wait that IS needed sits
@@ -913,12 +924,18 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane < b.bw) {
         uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win;
-        const uint32_t lds_step = (uint32_t)b.pitch * 16u;
+        const uint32_t lds_step = (uint32_t)b.pitch * 16u; // dwordx3 too writes one 16-byte slot per lane
         for (int r = 0; r < b.bh; ++r) {
-          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                       :
-                       : "s"(lds), "v"(gp + (size_t)r * in_w)
-                       : "memory", "m0");
+          if constexpr (CH == 4)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                         :
+                         : "s"(lds), "v"(gp + (size_t)r * in_w)
+                         : "memory", "m0");
+          else
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, off"
+                         :
+                         : "s"(lds), "v"(gp3 + (size_t)r * in_w * 3)
+                         : "memory", "m0");
           lds += lds_step;
         }
       }
@@ -938,25 +955,36 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
     const int n = b.pitch * b.iyn[h]; // origins: every window column x every first tap row of this half
     const float4 *const raw = win0 + (b.iy0[h] - 1 - b.y_lo) * b.pitch;
     float4 *const planes = win0 + b.c_base;
-#pragma unroll 1
-    for (int i0 = 0; i0 < n; i0 += 64) {
-      const int idx = i0 + lane;
+    auto load4 = [&](int idx, Rgba t[4]) { // origin idx = row * pitch + column reads the window texels idx + {0, 1, 2, 3} * pitch
+      const float4 *q = raw + (idx < n ? idx : n - 1); // (origins in the pad column of an odd pitch compute unused values from stale slots)
+      t[0] = as_rgba(q[0]);
+      t[1] = as_rgba(q[b.pitch]);
+      t[2] = as_rgba(q[2 * b.pitch]);
+      t[3] = as_rgba(q[3 * b.pitch]);
+    };
+    auto emit = [&](int idx, const Rgba t[4]) {
+      Rgba inner, m0, cma;
+      inner.lo = ((3.0f * (t[1].lo - t[2].lo)) + t[3].lo) - t[0].lo;
+      inner.hi = ((3.0f * (t[1].hi - t[2].hi)) + t[3].hi) - t[0].hi;
+      m0.lo = (((2.0f * t[0].lo) - (5.0f * t[1].lo)) + (4.0f * t[2].lo)) - t[3].lo;
+      m0.hi = (((2.0f * t[0].hi) - (5.0f * t[1].hi)) + (4.0f * t[2].hi)) - t[3].hi;
+      cma.lo = t[2].lo - t[0].lo;
+      cma.hi = t[2].hi - t[0].hi;
       if (idx < n) {
-        // origin idx = row * pitch + column reads the window texels idx + {0, 1, 2, 3} * pitch
-        // (origins in the pad column of an odd pitch compute unused values from stale slots)
-        const float4 *t = raw + idx;
-        const Rgba ta = as_rgba(t[0]), tb = as_rgba(t[b.pitch]), tc = as_rgba(t[2 * b.pitch]), td = as_rgba(t[3 * b.pitch]);
-        Rgba inner, m0, cma;
-        inner.lo = ((3.0f * (tb.lo - tc.lo)) + td.lo) - ta.lo;
-        inner.hi = ((3.0f * (tb.hi - tc.hi)) + td.hi) - ta.hi;
-        m0.lo = (((2.0f * ta.lo) - (5.0f * tb.lo)) + (4.0f * tc.lo)) - td.lo;
-        m0.hi = (((2.0f * ta.hi) - (5.0f * tb.hi)) + (4.0f * tc.hi)) - td.hi;
-        cma.lo = tc.lo - ta.lo;
-        cma.hi = tc.hi - ta.hi;
         planes[idx] = float4{inner.lo.x, inner.lo.y, inner.hi.x, inner.hi.y};
         planes[b.c_plane + idx] = float4{m0.lo.x, m0.lo.y, m0.hi.x, m0.hi.y};
         planes[2 * b.c_plane + idx] = float4{cma.lo.x, cma.lo.y, cma.hi.x, cma.hi.y};
       }
+    };
+    // two chunks of 64 origins per trip, the second chunk's reads in flight under the first chunk's arithmetic
+#pragma unroll 1
+    for (int i0 = 0; i0 < n; i0 += 128) {
+      const bool two = i0 + 64 < n; // wave-uniform
+      Rgba t0[4], t1[4];
+      load4(i0 + lane, t0);
+      if (two) load4(i0 + 64 + lane, t1);
+      emit(i0 + lane, t0);
+      if (two) emit(i0 + 64 + lane, t1);
     }
   };
 
@@ -974,7 +1002,7 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
   bool dma_early = false; // the pending window was requested before its block's last store
   auto next_window = [&]() {
     // while this block's coefficient planes are still being read the next raw window must stay in front of them
-    dma_early = g_loop + 1 < G && (!(kWinCoef && cur.coef) || nxt.pitch * nxt.bh <= cur.c_base);
+    dma_early = g_loop + 1 < G && (!(kWinCoef && cur.coef) || raw_slots(nxt) <= cur.c_base);
     if (dma_early) issue(g_loop + 1, nxt);
   };
 #pragma unroll 1
@@ -993,7 +1021,9 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
     const float4 *const win = win0 + (g & (kWinBuffers - 1)) * kWinCap;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+#if !defined(LRP_SKIP_PLANES) // timing experiment (wrong results): the coefficient phase removed
       if (kWinCoef && cur.coef) precompute(cur, h);
+#endif
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int k = 2 * h + kk;
@@ -1015,7 +1045,12 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
           const Rgba b0 = as_rgba(tb[0]), b1 = as_rgba(tb[1]), b2 = as_rgba(tb[2]), b3 = as_rgba(tb[3]);
           if (last_pass) next_window();
           auto vert = [&](int j, const Rgba bj) {
+#if defined(LRP_SKIP_TAP_READS) // timing experiment (wrong results): no LDS reads of the planes
+            const Rgba inner{f2{fx, fy} * (float)j, f2{hfx, fy}, 0.0f}, m0{f2{fy, fx} + (float)j, f2{fx, hfy}, 0.0f}, cma{f2{hfx, hfy}, f2{fy, fx} - (float)j, 0.0f};
+            (void)ci; (void)cm; (void)cc;
+#else
             const Rgba inner = as_rgba(ci[j]), m0 = as_rgba(cm[j]), cma = as_rgba(cc[j]);
+#endif
             Rgba r = px_zero<4>();
             r.lo = bj.lo + hfy * (cma.lo + fy * (m0.lo + fy * inner.lo));
             r.hi = bj.hi + hfy * (cma.hi + fy * (m0.hi + fy * inner.hi));
@@ -1081,11 +1116,13 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
 #endif
         } else {
           if (last_pass) next_window(); // nothing staged: no tap of this block reads the window
-          s = sample_direct<2, Loop, 4>(P, src, psx, psy);
+          const Px<CH> d = sample_direct<2, Loop, CH>(P, src, psx, psy);
+          s = Rgba{d.lo, CH == 4 ? d.hi : f2{d.e, 0.0f}, 0.0f};
         }
         // num_samples == 1: (0.0f + s) * normalize (src/reproject.cpp:334-341)
-        Rgba a = px_zero<4>();
-        px_add<4>(a, s);
+        Rgba a4 = px_zero<4>();
+        px_add<4>(a4, s);
+        const Px<CH> a{a4.lo, CH == 4 ? a4.hi : f2{0.0f, 0.0f}, CH == 4 ? 0.0f : a4.hi.x};
         // Every lane stores: lanes / rows beyond the image have recomputed the pixel they were
         // clamped to (xe, ye) and write that same value to that same address again, so the
         // store is issued by every wavefront (the vmcnt(1) above counts on it).
@@ -1094,9 +1131,9 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
         const int xo = (quad && (g & 1)) ? P.out_w - 1 - xe : xe; // mirrored blocks write the mirrored pixel
         const int yo = (quad && (g >> 1)) ? P.out_h - 1 - yc : yc;
 #if defined(LRP_NO_STORE) // timing experiment: almost no output traffic
-        if (a.lo.x == 12345.678f) store_px<4>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
+        if (a.lo.x == 12345.678f) store_px<CH>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
 #else
-        store_px<4>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
+        store_px<CH>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
 #endif
       }
     }
@@ -1144,24 +1181,24 @@ template <int Interp> hipError_t launch_tile_interp(KParams P, int out_idx, int 
   return hipGetLastError();
 }
 
-template <bool Quad> struct WinKernelTable {
+template <bool Quad, int CH> struct WinKernelTable {
   static TileKernelFn get(int out_idx, int in_mode) {
     static const TileKernelFn table[3][4] = {
-        {reproject_bicubic_win_kernel<kRect, kInRect, Quad>, reproject_bicubic_win_kernel<kRect, kInEquidistant, Quad>,
-         reproject_bicubic_win_kernel<kRect, kInEquirect, Quad>, reproject_bicubic_win_kernel<kRect, kInEquirectLoop, Quad>},
-        {reproject_bicubic_win_kernel<kEquidistant, kInRect, Quad>,
-         reproject_bicubic_win_kernel<kEquidistant, kInEquidistant, Quad>,
-         reproject_bicubic_win_kernel<kEquidistant, kInEquirect, Quad>,
-         reproject_bicubic_win_kernel<kEquidistant, kInEquirectLoop, Quad>},
-        {reproject_bicubic_win_kernel<kEquirect, kInRect, Quad>, reproject_bicubic_win_kernel<kEquirect, kInEquidistant, Quad>,
-         reproject_bicubic_win_kernel<kEquirect, kInEquirect, Quad>,
-         reproject_bicubic_win_kernel<kEquirect, kInEquirectLoop, Quad>}};
+        {reproject_bicubic_win_kernel<kRect, kInRect, Quad, CH>, reproject_bicubic_win_kernel<kRect, kInEquidistant, Quad, CH>,
+         reproject_bicubic_win_kernel<kRect, kInEquirect, Quad, CH>, reproject_bicubic_win_kernel<kRect, kInEquirectLoop, Quad, CH>},
+        {reproject_bicubic_win_kernel<kEquidistant, kInRect, Quad, CH>,
+         reproject_bicubic_win_kernel<kEquidistant, kInEquidistant, Quad, CH>,
+         reproject_bicubic_win_kernel<kEquidistant, kInEquirect, Quad, CH>,
+         reproject_bicubic_win_kernel<kEquidistant, kInEquirectLoop, Quad, CH>},
+        {reproject_bicubic_win_kernel<kEquirect, kInRect, Quad, CH>, reproject_bicubic_win_kernel<kEquirect, kInEquidistant, Quad, CH>,
+         reproject_bicubic_win_kernel<kEquirect, kInEquirect, Quad, CH>,
+         reproject_bicubic_win_kernel<kEquirect, kInEquirectLoop, Quad, CH>}};
     return table[out_idx][in_mode];
   }
 };
 
 // num_samples must be 1 (the pipeline keeps no accumulator across sub-samples).
-template <bool Quad>
+template <bool Quad, int CH>
 inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, hipStream_t stream) {
   const int rows = P.out_h - P.y_offset;
   if (Quad) {
@@ -1181,8 +1218,8 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
   const int n_tiles = P.tiles_x * P.tiles_y;
   if (n_tiles <= 0) return hipSuccess;
   const int chunk = (n_tiles + kXcds - 1) / kXcds;
-  hipLaunchKernelGGL(WinKernelTable<Quad>::get(out_idx, in_mode), dim3((unsigned)(chunk * kXcds)), dim3(kWinThreads), 0,
-                     stream, P);
+  const TileKernelFn fn = WinKernelTable<Quad, CH>::get(out_idx, in_mode);
+  hipLaunchKernelGGL(fn, dim3((unsigned)(chunk * kXcds)), dim3(kWinThreads), 0, stream, P);
   return hipGetLastError();
 }
 
