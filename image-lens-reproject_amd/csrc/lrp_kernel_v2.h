@@ -929,12 +929,12 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
           if constexpr (CH == 4)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                          :
-                         : "s"(lds), "v"(gp + (size_t)r * in_w)
+                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(gp + (size_t)r * in_w)
                          : "memory", "m0");
           else
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, off"
                          :
-                         : "s"(lds), "v"(gp3 + (size_t)r * in_w * 3)
+                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(gp3 + (size_t)r * in_w * 3)
                          : "memory", "m0");
           lds += lds_step;
         }
