@@ -247,7 +247,7 @@ __device__ __forceinline__ Px<CH> texel_at(__amdgpu_buffer_rsrc_t rsrc, uint32_t
 // bicubicInterpolate (src/reproject.cpp:100-107): vertical cubic per tap column,
 // then the horizontal one.  Taps: byte offset v[i] (column part, VGPR) + r[j]
 // (row part; SGPR in the interior path).
-template <int CH, bool ScalarRows>
+template <int CH, bool ScalarRows, bool LowReg = false>
 __device__ __forceinline__ Px<CH> bicubic_taps(__amdgpu_buffer_rsrc_t rsrc, uint32_t v0, uint32_t v1, uint32_t v2,
                                                uint32_t v3, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, float fx,
                                                float fy) {
@@ -262,6 +262,9 @@ __device__ __forceinline__ Px<CH> bicubic_taps(__amdgpu_buffer_rsrc_t rsrc, uint
   const float hfx = 0.5f * fx, hfy = 0.5f * fy;
   const Px<CH> k0 = cubic_px<CH>(tap(v0, r0), tap(v0, r1), tap(v0, r2), tap(v0, r3), fy, hfy);
   const Px<CH> k1 = cubic_px<CH>(tap(v1, r0), tap(v1, r1), tap(v1, r2), tap(v1, r3), fy, hfy);
+  // LowReg (the window kernel's fallback): the loads of columns 2, 3 stay behind the cubics of
+  // columns 0, 1 — half the tap registers live at once, one more memory round trip
+  if constexpr (LowReg) asm volatile("" ::: "memory");
   const Px<CH> k2 = cubic_px<CH>(tap(v2, r0), tap(v2, r1), tap(v2, r2), tap(v2, r3), fy, hfy);
   const Px<CH> k3 = cubic_px<CH>(tap(v3, r0), tap(v3, r1), tap(v3, r2), tap(v3, r3), fy, hfy);
   return cubic_px<CH>(k0, k1, k2, k3, fx, hfx);
@@ -440,9 +443,12 @@ template <int Interp, int CH> __device__ __forceinline__ SrcView source_view(con
 
 // sample_nearest / sample_bilinear / sample_bicubic (src/reproject.cpp:39-148).
 // All 64 lanes must be active (wave-wide vote).
-template <int Interp, bool Loop, int CH>
+// TexelBytes != 4 * CH: the RGB window kernel's fallback reads its 12-byte texels as 16-byte
+// vectors (CH = 4, TexelBytes = 12; dword alignment is all a buffer load needs and a read past the
+// last texel returns 0) and discards the fourth component like the rest of that kernel.
+template <int Interp, bool Loop, int CH, bool LowReg = false, int TexelBytes = 4 * CH>
 __device__ __forceinline__ Px<CH> sample_direct(const KParams &P, const SrcView &src, float sx, float sy) {
-  constexpr uint32_t T = 4u * CH; // texel bytes
+  constexpr uint32_t T = (uint32_t)TexelBytes; // texel bytes
   const int in_w = P.in_w, in_h = P.in_h;
   const uint32_t row_bytes = src.row_bytes;
   const __amdgpu_buffer_rsrc_t rsrc = src.rsrc;
@@ -455,7 +461,7 @@ __device__ __forceinline__ Px<CH> sample_direct(const KParams &P, const SrcView 
       const float tx_ = __builtin_truncf(sx), ty_ = __builtin_truncf(sy);
       const float fx = sx - tx_, fy = sy - ty_;
       const uint32_t v0 = __umul24((uint32_t)((int)ty_ - 1), row_bytes) + (uint32_t)((int)tx_ - 1) * T;
-      s = bicubic_taps<CH, true>(rsrc, v0, v0 + T, v0 + 2u * T, v0 + 3u * T, 0u, row_bytes, 2u * row_bytes,
+      s = bicubic_taps<CH, true, LowReg>(rsrc, v0, v0 + T, v0 + 2u * T, v0 + 3u * T, 0u, row_bytes, 2u * row_bytes,
                                  3u * row_bytes, fx, fy);
     } else {
       int xs[4], ys[4];
@@ -485,7 +491,7 @@ __device__ __forceinline__ Px<CH> sample_direct(const KParams &P, const SrcView 
         s = cubic_px<CH>(cubic_px<CH>(t0, t0, t0, t0, fy, hfy), cubic_px<CH>(t1, t1, t1, t1, fy, hfy),
                          cubic_px<CH>(t2, t2, t2, t2, fy, hfy), cubic_px<CH>(t3, t3, t3, t3, fy, hfy), fx, hfx);
       } else {
-        s = bicubic_taps<CH, false>(rsrc, c0, (uint32_t)xs[1] * T, (uint32_t)xs[2] * T, (uint32_t)xs[3] * T, r0,
+        s = bicubic_taps<CH, false, LowReg>(rsrc, c0, (uint32_t)xs[1] * T, (uint32_t)xs[2] * T, (uint32_t)xs[3] * T, r0,
                                     (uint32_t)ys[1] * row_bytes, (uint32_t)ys[2] * row_bytes,
                                     (uint32_t)ys[3] * row_bytes, fx, fy);
       }
@@ -1116,8 +1122,7 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
 #endif
         } else {
           if (last_pass) next_window(); // nothing staged: no tap of this block reads the window
-          const Px<CH> d = sample_direct<2, Loop, CH>(P, src, psx, psy);
-          s = Rgba{d.lo, CH == 4 ? d.hi : f2{d.e, 0.0f}, 0.0f};
+          s = sample_direct<2, Loop, 4, false, 4 * CH>(P, src, psx, psy);
         }
         // num_samples == 1: (0.0f + s) * normalize (src/reproject.cpp:334-341)
         Rgba a4 = px_zero<4>();
