@@ -260,13 +260,31 @@ __device__ __forceinline__ Px<CH> bicubic_taps(__amdgpu_buffer_rsrc_t rsrc, uint
       return texel_at<CH>(rsrc, v + r, 0u);
   };
   const float hfx = 0.5f * fx, hfy = 0.5f * fy;
-  const Px<CH> k0 = cubic_px<CH>(tap(v0, r0), tap(v0, r1), tap(v0, r2), tap(v0, r3), fy, hfy);
-  const Px<CH> k1 = cubic_px<CH>(tap(v1, r0), tap(v1, r1), tap(v1, r2), tap(v1, r3), fy, hfy);
-  // LowReg (the window kernel's fallback): the loads of columns 2, 3 stay behind the cubics of
-  // columns 0, 1 — half the tap registers live at once, one more memory round trip
-  if constexpr (LowReg) asm volatile("" ::: "memory");
-  const Px<CH> k2 = cubic_px<CH>(tap(v2, r0), tap(v2, r1), tap(v2, r2), tap(v2, r3), fy, hfy);
-  const Px<CH> k3 = cubic_px<CH>(tap(v3, r0), tap(v3, r1), tap(v3, r2), tap(v3, r3), fy, hfy);
+  if constexpr (LowReg) {
+    const Px<CH> k0 = cubic_px<CH>(tap(v0, r0), tap(v0, r1), tap(v0, r2), tap(v0, r3), fy, hfy);
+    const Px<CH> k1 = cubic_px<CH>(tap(v1, r0), tap(v1, r1), tap(v1, r2), tap(v1, r3), fy, hfy);
+    // the loads of columns 2, 3 stay behind the cubics of columns 0, 1: half the tap registers
+    // live at once, one more memory round trip
+    asm volatile("" ::: "memory");
+    const Px<CH> k2 = cubic_px<CH>(tap(v2, r0), tap(v2, r1), tap(v2, r2), tap(v2, r3), fy, hfy);
+    const Px<CH> k3 = cubic_px<CH>(tap(v3, r0), tap(v3, r1), tap(v3, r2), tap(v3, r3), fy, hfy);
+    return cubic_px<CH>(k0, k1, k2, k3, fx, hfx);
+  }
+  // Loads in ROW-major order: the four taps of a row are 4 T contiguous bytes, i.e. one or two
+  // 128-byte cache lines that the second to fourth load find in flight.  Column-major order
+  // touches a row's line again only after 64 lanes x 4 rows of other lines have gone through
+  // a 32 KiB L1 that 16 wavefronts share — under minification (every lane its own lines) that
+  // fetches each line up to four times.
+  const uint32_t v[4] = {v0, v1, v2, v3}, r[4] = {r0, r1, r2, r3};
+  Px<CH> t[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i][j] = tap(v[i], r[j]);
+  const Px<CH> k0 = cubic_px<CH>(t[0][0], t[0][1], t[0][2], t[0][3], fy, hfy);
+  const Px<CH> k1 = cubic_px<CH>(t[1][0], t[1][1], t[1][2], t[1][3], fy, hfy);
+  const Px<CH> k2 = cubic_px<CH>(t[2][0], t[2][1], t[2][2], t[2][3], fy, hfy);
+  const Px<CH> k3 = cubic_px<CH>(t[3][0], t[3][1], t[3][2], t[3][3], fy, hfy);
   return cubic_px<CH>(k0, k1, k2, k3, fx, hfx);
 }
 
