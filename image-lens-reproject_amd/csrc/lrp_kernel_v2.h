@@ -295,6 +295,25 @@ __device__ __forceinline__ Px<CH> bicubic_taps(__amdgpu_buffer_rsrc_t rsrc, uint
 __device__ __forceinline__ int interior(float s, float lo, float hi, float reach) {
   return (int)(s >= lo) & (int)(s < hi) & (int)(((s + reach) - s) == reach);
 }
+// The exactness half of interior() is sufficient, not necessary: next to a power of two
+// (2046 <= s < 2048 for reach 2) s + reach is rounded for half of all s, yet the truncation
+// still lands on int(s) + reach unless s is within one ulp of the next integer.  The precise
+// condition — asked only after the cheap vote has failed, i.e. for the stripe of blocks that
+// crosses such a coordinate — is int(s + k) == int(s) + k for k = 1 .. reach, finite s.
+__device__ __forceinline__ int taps_consecutive(float s, float reach) {
+  const float t = __builtin_truncf(s);
+  int ok = (int)(__builtin_truncf(s + 1.0f) == t + 1.0f);
+  if (reach == 2.0f) ok &= (int)(__builtin_truncf(s + 2.0f) == t + 2.0f);
+  return ok & (int)(__builtin_fabsf(s) < 8388608.0f);
+}
+__device__ __forceinline__ int interior_precise(float s, float lo, float hi, float reach) {
+  return (int)(s >= lo) & (int)(s < hi) & taps_consecutive(s, reach);
+}
+// wave-wide: every lane interior (cheap test first)
+__device__ __forceinline__ bool all_interior(float sx, float sy, float lo, float x_hi, float y_hi, float reach) {
+  if (__builtin_amdgcn_ballot_w64((interior(sx, lo, x_hi, reach) & interior(sy, lo, y_hi, reach)) != 0) == ~0ull) return true;
+  return __builtin_amdgcn_ballot_w64((interior_precise(sx, lo, x_hi, reach) & interior_precise(sy, lo, y_hi, reach)) != 0) == ~0ull;
+}
 
 // ---- output pixel -> source coordinates (src/reproject.cpp:287-324) ----------------
 // Terms of the output lens that depend on the column and the horizontal
@@ -473,7 +492,7 @@ __device__ __forceinline__ Px<CH> sample_direct(const KParams &P, const SrcView 
   const float x_hi = src.x_hi, y_hi = src.y_hi;
   Px<CH> s;
   if constexpr (Interp == 2) {
-    if (wave_all((interior(sx, 1.0f, x_hi, 2.0f) & interior(sy, 1.0f, y_hi, 2.0f)) != 0)) {
+    if (all_interior(sx, sy, 1.0f, x_hi, y_hi, 2.0f)) {
       // every lane: 4 consecutive columns x 4 consecutive rows, nothing clamped
       // (src/reproject.cpp:114-131 reduce to int(s) - 1 .. int(s) + 2, f = s - int(s))
       const float tx_ = __builtin_truncf(sx), ty_ = __builtin_truncf(sy);
@@ -519,7 +538,7 @@ __device__ __forceinline__ Px<CH> sample_direct(const KParams &P, const SrcView 
     // indices to lx = int(sx), ux = lx + 1, fx = sx - lx
     uint32_t o_ll, o_lu, o_ul, o_uu;
     float fx, fy;
-    if (wave_all((interior(sx, 0.0f, x_hi, 1.0f) & interior(sy, 0.0f, y_hi, 1.0f)) != 0)) {
+    if (all_interior(sx, sy, 0.0f, x_hi, y_hi, 1.0f)) {
       const float tx_ = __builtin_truncf(sx), ty_ = __builtin_truncf(sy);
       fx = sx - tx_;
       fy = sy - ty_;
@@ -763,6 +782,10 @@ constexpr int kBlkW = LRP_WIN_BLOCK_W;  // output block per wavefront: kBlkW x k
 constexpr int kBlkH = 256 / kBlkW;      // 4 passes of kBlkW columns x (64 / kBlkW) rows
 constexpr int kPassRows = 64 / kBlkW;
 
+#if defined(LRP_TIER_STATS) // diagnostic builds (tools/ablate.sh): blocks per tier (coefficients, raw taps, direct)
+__device__ unsigned g_tier_stats[4];
+#endif
+
 // Source coordinates and window of one 16 x 16 block (4 pixels per lane).
 struct WinBlock {
   float sx[4], sy[4];
@@ -899,7 +922,14 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
     b.staged = b.coef = false;
     b.x_lo = b.y_lo = b.bw = b.bh = b.pitch = b.c_plane = b.c_base = 0;
     b.iy0[0] = b.iy0[1] = b.iyn[0] = b.iyn[1] = 0;
-    if (wave_all(exact != 0)) {
+    bool all_exact = wave_all(exact != 0);
+    if (!all_exact) { // the precise test, for the stripe of blocks next to a power-of-two coordinate
+      int ok = 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ok &= taps_consecutive(b.sx[k], 2.0f) & taps_consecutive(b.sy[k], 2.0f);
+      all_exact = wave_all(ok != 0);
+    }
+    if (all_exact) {
       int w_lo_x = lo_x, w_hi_x = hi_x, w_lo_ya = lo_y[0], w_hi_ya = hi_y[0], w_lo_yb = lo_y[1], w_hi_yb = hi_y[1];
       wave_box(w_lo_x, w_hi_x, w_lo_ya, w_hi_ya, w_lo_yb, w_hi_yb);
       const int w_lo_y = min(w_lo_ya, w_lo_yb), w_hi_y = max(w_hi_ya, w_hi_yb);
@@ -1043,6 +1073,9 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
 #endif
     if (kWinBuffers == 2 && g + 1 < G) issue(g + 1, nxt);
     const float4 *const win = win0 + (g & (kWinBuffers - 1)) * kWinCap;
+#if defined(LRP_TIER_STATS)
+    if (lane == 0) atomicAdd(&g_tier_stats[(kWinCoef && cur.coef) ? 0 : (cur.staged ? 1 : 2)], 1u);
+#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #if !defined(LRP_SKIP_PLANES) // timing experiment (wrong results): the coefficient phase removed

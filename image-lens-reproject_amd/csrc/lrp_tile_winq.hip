@@ -6,3 +6,11 @@ hipError_t launch_win_bicubic_quad(const KParams &P, int out_idx, int in_mode, h
   return launch_win_bicubic_impl<true, 4>(P, out_idx, in_mode, stream);
 }
 } // namespace lrp
+
+#if defined(LRP_TIER_STATS)
+extern "C" void lrp_debug_read_tiers(unsigned out[4]) { // mirrored RGBA instantiations only
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lrp::g_tier_stats), sizeof(unsigned) * 4);
+  unsigned zero[4] = {0, 0, 0, 0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(lrp::g_tier_stats), zero, sizeof(zero));
+}
+#endif

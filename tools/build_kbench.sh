@@ -4,5 +4,5 @@ set -euo pipefail
 root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 lib="$root/image-lens-reproject_amd/lib"
 /opt/rocm/bin/hipcc -O2 -std=c++17 "$root/tools/kbench.cpp" -I"$root/include" -L"$lib" -llrp_hip \
-  -Wl,-rpath,'$ORIGIN/../image-lens-reproject_amd/lib' -o "$root/tools/kbench"
+  -Wl,-rpath,'$ORIGIN/../image-lens-reproject_amd/lib' -ldl -o "$root/tools/kbench"
 echo "built $root/tools/kbench"

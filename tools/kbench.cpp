@@ -9,6 +9,7 @@
 //   hipcc -O2 -std=c++17 tools/kbench.cpp -Iinclude -L<pkg>/lib -llrp_hip -Wl,-rpath,<pkg>/lib -o tools/kbench
 // Usage: kbench [--size N] [--reps R] [--warmup W] [--distinct D] [--channels C] [--ns S] [--sum] [workload ...]
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -195,6 +196,11 @@ int main(int argc, char **argv) {
       HIP_OK(hipStreamSynchronize(stream));
       HIP_OK(hipMemcpy(host.data(), dst[0], out_elems * 4, hipMemcpyDeviceToHost));
       h = fnv1a(host.data(), out_elems * 4);
+    }
+    if (auto rd = (void (*)(unsigned *))dlsym(RTLD_DEFAULT, "lrp_debug_read_tiers")) { // diagnostic builds only
+      unsigned t[4] = {0, 0, 0, 0};
+      rd(t);
+      printf("    window-kernel blocks per tier (all launches so far): coefficients %u, raw taps %u, direct %u\n", t[0], t[1], t[2]);
     }
     printf("%-18s avg %8.1f us  min %8.1f us  %8.2f Gpix/s  %7.1f GB/s algorithmic  frac %.3f", W->name, avg_s * 1e6,
            best * 1e3, (double)out_size * out_size / avg_s / 1e9, bytes / avg_s / 1e9, bytes / avg_s / 8e12);
