@@ -277,10 +277,35 @@ __device__ __forceinline__ Px<CH> bicubic_taps(__amdgpu_buffer_rsrc_t rsrc, uint
   // fetches each line up to four times.
   const uint32_t v[4] = {v0, v1, v2, v3}, r[4] = {r0, r1, r2, r3};
   Px<CH> t[4][4];
+  if constexpr (ScalarRows && (CH == 3 || CH == 5)) {
+    // interior path (v1..v3 = v0 + T, 2T, 3T): the four texels of a tap row are 48 / 80
+    // contiguous bytes — 3 / 5 dwordx4 loads instead of 4 dwordx3 / 4 dwordx4 + 4 dword
+    constexpr int NV = CH == 3 ? 3 : 5;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+      float f[NV * 4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) t[i][j] = tap(v[i], r[j]);
+      for (int i = 0; i < NV; ++i) {
+        const u4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(v0 + 16u * i), (int)r[j], 0);
+        f[4 * i] = u2f(q.x);
+        f[4 * i + 1] = u2f(q.y);
+        f[4 * i + 2] = u2f(q.z);
+        f[4 * i + 3] = u2f(q.w);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if constexpr (CH == 3)
+          t[c][j] = Px<3>{f2{f[3 * c], f[3 * c + 1]}, f2{0.0f, 0.0f}, f[3 * c + 2]};
+        else
+          t[c][j] = Px<CH>{f2{f[5 * c], f[5 * c + 1]}, f2{f[5 * c + 2], f[5 * c + 3]}, f[5 * c + 4]};
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[i][j] = tap(v[i], r[j]);
+  }
   const Px<CH> k0 = cubic_px<CH>(t[0][0], t[0][1], t[0][2], t[0][3], fy, hfy);
   const Px<CH> k1 = cubic_px<CH>(t[1][0], t[1][1], t[1][2], t[1][3], fy, hfy);
   const Px<CH> k2 = cubic_px<CH>(t[2][0], t[2][1], t[2][2], t[2][3], fy, hfy);
