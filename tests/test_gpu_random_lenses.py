@@ -121,3 +121,45 @@ def test_magnified_bicubic_shared_tap_coefficients(lrp, oracle, torch_cuda, pair
             finally:
                 lrp.debug_kernel(prev)
             cases.assert_same_bits(d_out.cpu().numpy(), want, f"{in_name}->{out_name} rot={deg} family={family}")
+
+
+@pytest.mark.parametrize("chunk", range(int(__import__("os").environ.get("LRP_STRESS_CHUNKS", "8"))))
+def test_kernel_families_agree_on_many_random_configurations(lrp, torch_cuda, chunk):
+    """40 random configurations per chunk (sizes up to 1500, all lens pairs, unrotated / identity /
+    pan-only / general rotations, 3-5 channels, 1-3 sub-samples), every sampler: the default
+    family (all work sharing on) must produce the bytes of the one-pixel-per-lane kernel, which
+    shares nothing.  No oracle involved, so the configurations can be large and many."""
+    torch = torch_cuda
+    rng = np.random.default_rng(777 + chunk)
+    for case in range(40):
+        in_w, in_h = int(rng.integers(8, 1500)), int(rng.integers(8, 1100))
+        out_w, out_h = int(rng.integers(1, 1500)), int(rng.integers(1, 1100))
+        c = int(rng.choice([3, 4, 4, 5]))
+        ns = int(rng.choice([1, 1, 1, 1, 2, 3]))
+        lin, lout = random_lens(lrp, rng, in_w, in_h), random_lens(lrp, rng, out_w, out_h)
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            rot = None
+        elif kind == 1:
+            rot = cases.rotation(lrp, (0.0, 0.0, 0.0))
+        elif kind == 2:
+            rot = cases.rotation(lrp, (float(rng.choice([90.0, 180.0, 270.0, 33.0, -71.5])), 0.0, 0.0))
+        else:
+            rot = cases.rotation(lrp, tuple(float(v) for v in rng.uniform(-180.0, 180.0, size=3)))
+        d_in = torch.empty((in_h, in_w, c), dtype=torch.float32, device="cuda")
+        lrp.synth_fill(d_in, in_w, in_h, c, 0x1234 + case + 100 * chunk)
+        for interp in (0, 1, 2):
+            outs = []
+            for family in (2, 0):
+                prev = lrp.debug_kernel(family)
+                try:
+                    d_out = torch.full((out_h, out_w, c), -777.0, dtype=torch.float32, device="cuda")
+                    lrp.reproject(lrp.Image(lin, in_w, in_h, c, d_in), lrp.Image(lout, out_w, out_h, c, d_out), ns, interp, rot)
+                    torch.cuda.synchronize()
+                finally:
+                    lrp.debug_kernel(prev)
+                outs.append(d_out)
+            a, b = outs[0].view(torch.int32), outs[1].view(torch.int32)
+            same = (a == b) | (torch.isnan(outs[0]) & torch.isnan(outs[1]))
+            assert bool(same.all()), (f"chunk {chunk} case {case}: {in_w}x{in_h}x{c} -> {out_w}x{out_h}, lens {lin.type}->{lout.type}, "
+                                      f"rot kind {kind}, ns={ns}, interp={interp}: {int((~same).sum())} values differ")
