@@ -204,7 +204,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
                                &P.row_tab, &plain, &mirror);
     if (e == hipErrorOutOfMemory) {
       (void)hipGetLastError();
-      tile = false; // cache full or no memory for the tables: per-pixel kernel
+      tile = false; // no memory for the tables: per-pixel kernel
     } else if (e != hipSuccess) {
       return hip_fail(e, "output-lens table build");
     } else if (plain) {

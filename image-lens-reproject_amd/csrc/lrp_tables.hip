@@ -172,6 +172,54 @@ std::mutex g_mutex;
 std::vector<Entry> g_entries;
 constexpr size_t kMaxEntries = 256;
 
+// Cache full: wait for the devices' work (kernels in flight may still read the tables), then
+// drop the older half of the output tables together with the column tables built on them.
+// A table build blocks the calling thread anyway; a process that keeps producing new output
+// geometries pays one device synchronisation per 128 of them.  (hipGraphs captured earlier
+// keep pointing at freed tables — same contract as lrp_release_cached_tables.)
+void evict_older_half() { // g_mutex held
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  const size_t n_drop = g_entries.size() / 2;
+  std::vector<const float *> dropped;
+  for (size_t i = 0; i < n_drop; ++i) {
+    (void)hipSetDevice(g_entries[i].device);
+    (void)hipDeviceSynchronize();
+    dropped.push_back(g_entries[i].key.tab);
+    (void)hipFree(g_entries[i].key.tab);
+  }
+  g_entries.erase(g_entries.begin(), g_entries.begin() + (long)n_drop);
+  for (size_t i = 0; i < g_xsep.size();) {
+    bool gone = false;
+    for (const float *t : dropped) gone = gone || g_xsep[i].key.col_tab == t;
+    if (gone) {
+      if (g_xsep[i].key.tab) {
+        (void)hipSetDevice(g_xsep[i].device);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(g_xsep[i].key.tab);
+      }
+      g_xsep.erase(g_xsep.begin() + (long)i);
+    } else {
+      ++i;
+    }
+  }
+  (void)hipSetDevice(cur);
+}
+
+void evict_older_xsep_half() { // g_mutex held
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  const size_t n_drop = g_xsep.size() / 2;
+  for (size_t i = 0; i < n_drop; ++i)
+    if (g_xsep[i].key.tab) {
+      (void)hipSetDevice(g_xsep[i].device);
+      (void)hipDeviceSynchronize();
+      (void)hipFree(g_xsep[i].key.tab);
+    }
+  g_xsep.erase(g_xsep.begin(), g_xsep.begin() + (long)n_drop);
+  (void)hipSetDevice(cur);
+}
+
 bool same_key(const TableArgs &a, const TableArgs &b) { // tab / flags are results, not part of the key
   return a.out_lens == b.out_lens && a.out_w == b.out_w && a.out_h == b.out_h && a.ns == b.ns &&
          std::memcmp(&a.lens, &b.lens, sizeof(LensP)) == 0;
@@ -200,7 +248,7 @@ hipError_t get_output_tables(int device, int out_lens, const LensP &lens, int ou
       *mirror = ns == 1 && !(e.flags & 6);
       return hipSuccess;
     }
-  if (g_entries.size() >= kMaxEntries) return hipErrorOutOfMemory; // caller falls back to the per-pixel kernel
+  if (g_entries.size() >= kMaxEntries) evict_older_half();
   // Miss: build synchronously on the legacy default stream (host blocks once per
   // new output-lens configuration; do this before capturing a hipGraph).
   float *tab = nullptr;
@@ -247,7 +295,7 @@ const float *get_xsep_table(int device, const float *col_tab, int out_lens, int 
   std::lock_guard<std::mutex> lock(g_mutex);
   for (const XsepEntry &e : g_xsep)
     if (e.device == device && same_xsep(e.key, want)) return e.key.tab;
-  if (g_xsep.size() >= kMaxEntries) return nullptr;
+  if (g_xsep.size() >= kMaxEntries) evict_older_xsep_half();
   float *tab = nullptr;
   if (hipMalloc(&tab, (3 * (size_t)want.n + 1) * sizeof(float)) != hipSuccess) {
     (void)hipGetLastError();
