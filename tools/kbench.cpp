@@ -53,7 +53,8 @@ static const Workload kWorkloads[] = {
     {"eqr_rect_nn", "eqr", "rect", 0, 1, {0, 0, 0}},       // configs[0] shape
     {"eqr_eqd_bl_rot", "eqr", "eqd", 1, 1, {30, -15, 5}},  // configs[2]
     {"rect_eqr_bc", "rect", "eqr", 2, 1, {0, 0, 0}},       // configs[3] shape (without post)
-    {"eqr_rect_bc_rot", "eqr", "rect", 2, 1, {90, 0, 0}},  // configs[4] face
+    {"eqr_rect_bc_rot", "eqr", "rect", 2, 1, {90, 0, 0}},  // configs[4] side face (pan)
+    {"eqr_rect_bc_pitch", "eqr", "rect", 2, 1, {0, 90, 0}}, // configs[4] top face (pitch: looks at the pole)
     {"rect_rect_bc", "rect", "rect", 2, 1, {10, 5, 0}},
     {"eqd_eqd_bc", "eqd", "eqd", 2, 1, {10, 5, 0}},
     {"eqr_eqr_bc_rot", "eqr", "eqr", 2, 1, {30, -15, 5}},
