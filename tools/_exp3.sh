@@ -1,5 +1,6 @@
 cd /root/repo
-timeout 120 tools/kbench --reps 20 --distinct 4 --sum eqr_rect_bc_pitch | grep -v "^#"
-echo "== config 5 shape: 8192^2 RGB equirect -> 2048^2 faces"
-timeout 200 tools/kbench --size 8192 --out-size 2048 --channels 3 --reps 30 --distinct 2 --sum eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch | grep -v "^#"
-LRP_KERNEL=pixel timeout 200 tools/kbench --size 8192 --out-size 2048 --channels 3 --reps 10 --distinct 2 --sum eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch | grep -v "^#"
+for s in 1 2 3 4 1 2; do
+  timeout 300 python bench.py --no-cpu-baseline --streams $s 2>&1 | tail -1 | python3 -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print('streams',d['config']['streams'],'value',round(d['value']),'ms/step',round(d['ms_per_step'],3),'kernel_avg_us',round(d['roofline']['kernel_ms_avg']*1e3,1),'frac',round(d['roofline']['frac'],3))"
+done
