@@ -1,6 +1,9 @@
 cd /root/repo
-for s in 1 2 3 4 1 2; do
-  timeout 300 python bench.py --no-cpu-baseline --streams $s 2>&1 | tail -1 | python3 -c "
-import sys,json
-d=json.loads(sys.stdin.read()); print('streams',d['config']['streams'],'value',round(d['value']),'ms/step',round(d['ms_per_step'],3),'kernel_avg_us',round(d['roofline']['kernel_ms_avg']*1e3,1),'frac',round(d['roofline']['frac'],3))"
+timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+for rep in 1 2; do
+for v in base ""; do
+  echo "== variant '$v'"
+  if [ -n "$v" ]; then export LD_LIBRARY_PATH=$PWD/tools/_ablate/$v; else unset LD_LIBRARY_PATH; fi
+  timeout 120 tools/kbench --reps 48 --distinct 8 --sum eqd_rect_bc eqr_rect_bc eqr_rect_bc_rot rect_rect_bc | grep -v "^#"
+done
 done
