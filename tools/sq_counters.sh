@@ -12,5 +12,5 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/p$i -- $R/tools/kbench --reps 6 --warmup 20 --distinct 8 eqd_rect_bc eqr_rect_bc eqr_rect_bc_rot > $out/p$i.log 2>&1
   echo "pass $i rc=$?"
 done
-python3 $R/tools/pmc_summary.py $out | grep -v "(n=[12])$" | grep -v "rocclr\|build_" > $out/summary.txt
+python3 $R/tools/pmc_summary.py $out > $out/summary.txt
 cat $out/summary.txt
