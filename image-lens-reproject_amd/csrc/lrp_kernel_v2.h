@@ -1,37 +1,39 @@
-// lrp_kernel_v2.h — the tile kernel: the hot path as it runs on gfx950.
+// lrp_kernel_v2.h — the tile and window kernels: the hot path as it runs on gfx950.
 //
-// Work decomposition
+// Work decomposition (tile kernel: nearest, bilinear, RGBAZ / super-sampled bicubic)
 //   * A 256-thread workgroup (4 wavefronts) owns a 64 x 4R tile of output pixels
 //     (R = 4 rows per wavefront for nearest, 2 for bilinear / bicubic).  Lane l of
 //     every wavefront owns output column tile_x*64 + l; wavefront w owns the R
 //     contiguous rows Rw .. Rw+R-1, so each of its stores is one contiguous 1 KiB
-//     run (64 lanes x float4) and every per-row quantity is wave-uniform (SGPR /
-//     scalar loads).
+//     run (64 lanes x float4) and every per-row quantity is wave-uniform.
 //   * Tiles are numbered so that the workgroups the dispatcher deals to one XCD
 //     (blockIdx % 8 equal) walk a contiguous band of the output: neighbouring
 //     tiles read neighbouring source rows, which then hit in that XCD's 4 MiB L2.
 //
-// Instruction diet (the reference loop is VALU-bound on this chip, not HBM-bound:
-// an IEEE divide costs ~46 issue cycles per wavefront, a sqrt ~53)
-//   * separable output-lens terms come from per-column / per-row tables
-//     (lrp_tables.hip) instead of 4 divides or 3 double-precision polynomials
-//     per pixel;
+// Instruction diet (the reference loop is VALU-bound on this chip, not HBM-bound: every
+// packed, SGPR-operand, compare / select / convert / divide-helper instruction costs 4 issue
+// cycles per wavefront, an IEEE divide 11 instructions, a sqrt ~12 — DESIGN.md section 5).
+// Nothing below changes an operation, an operand or an order of the reference; work is only
+// evaluated fewer times:
+//   * separable output-lens terms come from per-column / per-row tables (lrp_tables.hip)
+//     instead of 4 divides or 3 double-precision polynomials per pixel;
 //   * lens-only constants (sensor_width / fov, angular spans) come from the host;
-//   * x / -z, y / -z is skipped when -z == 1 for the whole wavefront (division by
-//     one is the identity in IEEE arithmetic) — the no-rotation / identity case.
-//   Every remaining operation is the reference's, in the reference's order.
+//   * x / -z, y / -z is skipped when -z == 1 for the whole wavefront (division by one is the
+//     identity in IEEE arithmetic);
+//   * the horizontal source coordinate of a rectilinear / equirectangular source comes from a
+//     per-column table whenever the rotated ray's x and z do not depend on the row;
+//   * without a rotation the four mirror images of a pixel share stage 1 of the coordinate
+//     math (P.quad); for the equidistant target they share the ray under any rotation.
 //
-// Bicubic taps through LDS
-//   The 16 taps of neighbouring pixels overlap almost completely, and 16 float4
-//   gathers per pixel saturate the texture-address path long before HBM.  Each
-//   wavefront reduces the tap-index bounding box of its 256 pixels with DPP
-//   butterflies, the four partial boxes meet in LDS, and the workgroup copies the
-//   window (coalesced row segments, float4 per lane) into LDS once.  A pixel
-//   whose taps are 4 consecutive columns x 4 consecutive rows — everything except
-//   image borders and the +-pi seam — then needs ONE address: its 16 taps are
-//   ds_read_b128 at compile-time offsets from it.  Windows larger than the LDS
-//   budget (poles, seam, strong minification) and non-consecutive taps fall back,
-//   per workgroup resp. per wavefront, to explicit per-tap addressing.
+// Bicubic taps through LDS (window kernel, RGBA and RGB, one wavefront per workgroup)
+//   The 16 taps of neighbouring pixels overlap almost completely, and 16 float4 gathers per
+//   pixel saturate the texture-address path long before HBM.  A wavefront reduces the
+//   tap-index bounding box of its 16 x 16 block with DPP-fused min / max, fetches that window
+//   with LDS-DMA into its private 10 KiB of LDS (no barrier anywhere), evaluates the
+//   weight-independent part of the vertical Catmull-Rom cubics once per window column and
+//   reads 12 coefficient vectors + 4 taps per pixel at compile-time offsets from one address.
+//   Windows larger than the LDS budget (poles, seam, strong minification) and non-consecutive
+//   taps fall back, per wavefront, to explicit per-tap addressing.
 #pragma once
 
 #include "lrp_device.h"
@@ -67,7 +69,6 @@ template <int Interp> constexpr int tile_rows() {
 }
 constexpr int kT2Waves = 4;      // wavefronts per workgroup
 constexpr int kT2Threads = 64 * kT2Waves;
-constexpr int kWinTexels = 2560; // staged source window capacity: 2560 float4 = 40 KiB -> 4 workgroups / CU
 
 // ---- wavefront-wide integer min / max (all 64 lanes active) ------------------
 template <int Ctrl> __device__ __forceinline__ int dpp_i32(int v) {
@@ -755,28 +756,28 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
   }
 }
 
-// ---- the bicubic window kernel (RGBA float) -----------------------------------------
+// ---- the bicubic window kernel (RGBA / RGB float) ------------------------------------
 //
-// 16 float4 gathers per pixel keep the texture-address path of a CU busy for
-// ~256 cycles per wavefront, as long as the 180 packed cubic instructions keep its
-// SIMD busy — the two do not overlap well.  The taps of neighbouring pixels overlap
-// almost completely, so each wavefront stages the source window of its own 16 x 16
-// output block in LDS once and reads the taps from there (ds_read_b128, 4 LDS
-// cycles each):
+// 16 float4 gathers per pixel keep the texture-address path of a CU busy for ~256 cycles per
+// wavefront and thrash its L1; the taps of neighbouring pixels overlap almost completely, so
+// each wavefront stages the source window of its own 16 x 16 output block in LDS once:
 //   * block = 16 x 16 output pixels per wavefront, 4 passes of 16 columns x 4 rows
 //     (square blocks keep the window small under any rotation of the mapping);
 //   * all 256 pixels interior (no clamped / wrapped tap; the common case) ->
 //     window = [min int(sx) - 1, max int(sx) + 2] x [min int(sy) - 1, max int(sy) + 2],
-//     reduced with DPP butterflies, no LDS, no barrier;
-//   * the window rows are fetched with global_load_lds_dwordx4 (LDS-DMA: per-lane
-//     global address, wave-uniform LDS row base + lane * 16; no VGPR round trip),
-//     lanes beyond the window width masked off;
-//   * s_waitcnt vmcnt(0) orders the wavefront's own ds_reads behind its DMA — the
-//     window is private to the wavefront, so there is no workgroup barrier at all;
-//   * a pixel's 16 taps are then ONE LDS address + 3 row increments and the
-//     immediates 0/16/32/48.
-// A block with a border / seam / NaN pixel, or a window larger than the per-wave
-// LDS budget (strong minification), takes sample_direct() per pass instead.
+//     reduced with DPP-fused v_min_i32 / v_max_i32, no LDS, no barrier;
+//   * the window rows are fetched with global_load_lds_dwordx4 / dwordx3 (LDS-DMA: per-lane
+//     global address, wave-uniform LDS row base + lane * 16; no VGPR round trip), lanes
+//     beyond the window width masked off;
+//   * s_waitcnt vmcnt orders the wavefront's own ds_reads behind its DMA — the window is
+//     private to the wavefront, so there is no workgroup barrier at all;
+//   * tier 1 (magnified mappings): the weight-independent 11 of the 17 operations of every
+//     vertical cubic are evaluated once per window column and row into three coefficient
+//     planes behind the window; a pixel reads 12 coefficient vectors + 4 taps;
+//   * tier 2 (window fits, planes do not): a pixel's 16 taps are ONE LDS address + 3 row
+//     increments and the immediates 0/16/32/48.
+// A block with a border / seam / NaN pixel, or a window larger than the per-wave LDS budget
+// (strong minification), takes sample_direct() per pass instead.
 #ifndef LRP_WIN_CAP
 #define LRP_WIN_CAP 640
 #endif
