@@ -823,15 +823,17 @@ struct WinBlock {
   bool coef;
 };
 
-// One wavefront walks its strip of `blocks_per_wave` blocks top to bottom:
+// One wavefront walks its strip of `blocks_per_wave` blocks (plain: top to bottom; mirrored: a
+// quadrant block and its three mirror images):
 //     A(0); DMA(0)
-//     for g:  A(g+1)                      | DMA(g) in flight under the coordinate math
-//             s_waitcnt vmcnt(0)          | window g has landed
-//             taps + cubics + store of g
-//             DMA(g+1)                    | every tap of block g has been read
-// (kWinBuffers == 2 issues DMA(g+1) before the cubics of block g instead; measured
-// equal, and one 10 KiB buffer per wavefront admits 1:1 and rotated mappings at
-// 4 wavefronts per SIMD, which is worth 5-25 %.)
+//     for g:  A(g+1)                        | plain blocks: coordinates + box of the next block
+//             s_waitcnt vmcnt(0 or 1)       | window g has landed
+//             half 0: planes, passes 0, 1   | coefficient planes of the half, then its two passes
+//             half 1: planes, passes 2, 3   | mirrored blocks derive A(g+1) at the start of pass 3
+//                     DMA(g+1) inside pass 3, behind its last reads of the raw window and ahead
+//                     of its arithmetic and its store (vmcnt retires in order)
+// One 10 KiB buffer per wavefront: 4 wavefronts per SIMD (a double-buffered variant at 3 per
+// SIMD measured 5-25 % slower).
 //
 // CH == 3 (RGB, what the PNG / JPEG path delivers): global_load_lds_dwordx3 reads 12 bytes per
 // lane and writes them at a 16-byte lane stride (measured: the fourth dword of each slot is left
