@@ -10,8 +10,12 @@ RGBA float frames that are already resident in HBM (generated on the device by
 the counter-based generator; seeds 0x5EED0000 + i).  The batch is sharded
 one-shard-per-GPU with no collective on the data path (images are independent,
 reference src/main.cpp:540-622), i.e. weak scaling: every rank renders `--batch`
-frames per step.  Inside a GPU the frames round-robin over `--streams` HIP
-streams.
+frames per step.  The frames of a step share one geometry (a directory of frames
+from one camera, the reference's --input-dir path), so a step is ONE kernel launch
+(lrp_reproject_batch_device, 16 frames per launch: the chip neither drains nor
+refills between frames); `--per-frame-launches` issues one launch per frame instead,
+round-robin over `--streams` HIP streams.  `roofline.achieved` = algorithmic bytes
+of the frames one launch renders / that launch's duration (HIP events on its stream).
 """
 import argparse
 import importlib
@@ -142,7 +146,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
-    ap.add_argument("--distinct", type=int, default=8, help="distinct resident source frames per GPU")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct resident source / destination frames per GPU")
+    ap.add_argument("--per-frame-launches", action="store_true",
+                    help="one kernel launch per frame (lrp_reproject_device) instead of one per step "
+                         "(lrp_reproject_batch_device: all frames of a step share one geometry)")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the frames of a step round-robin over (one frame fills the chip; >1 only "
                          "overlaps kernel tails and makes per-kernel durations in a profile overlap)")
@@ -194,10 +201,18 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
     torch.cuda.synchronize()
 
+    batch_in = [im_in[i % n_res] for i in range(args.batch)]
+    batch_out = [im_out[i % n_res] for i in range(args.batch)]
+    launches_per_step = args.batch if args.per_frame_launches else (args.batch + 15) // 16
+    frames_per_launch = args.batch / launches_per_step
+
     def step():
-        for i in range(args.batch):
-            st = streams[i % len(streams)]
-            pkg.reproject(im_in[i % n_res], im_out[i % n_res], 1, wl["interp"], rot, stream=st)
+        if args.per_frame_launches:
+            for i in range(args.batch):
+                st = streams[i % len(streams)]
+                pkg.reproject(im_in[i % n_res], im_out[i % n_res], 1, wl["interp"], rot, stream=st)
+        else:  # the frames of a step share one geometry: one launch per 16 frames
+            pkg.reproject_batch(batch_in, batch_out, 1, wl["interp"], rot, stream=streams[0])
 
     def barrier():
         torch.cuda.synchronize()
@@ -223,9 +238,15 @@ def main():
     kst = streams[0]
     reps = 40
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    if not args.per_frame_launches:
+        reps = 10
+        ev = ev[:reps]
     for i in range(reps):
         ev[i][0].record(kst)
-        pkg.reproject(im_in[i % n_res], im_out[i % n_res], 1, wl["interp"], rot, stream=kst)
+        if args.per_frame_launches:
+            pkg.reproject(im_in[i % n_res], im_out[i % n_res], 1, wl["interp"], rot, stream=kst)
+        else:
+            pkg.reproject_batch(batch_in[:16], batch_out[:16], 1, wl["interp"], rot, stream=kst)
         ev[i][1].record(kst)
     torch.cuda.synchronize()
     k_ms = sorted(a.elapsed_time(b) for a, b in ev)
@@ -234,7 +255,9 @@ def main():
     if rank == 0:
         pix_per_step = world * args.batch * size * size
         value = pix_per_step * args.steps / elapsed / 1e6
-        algo_bytes = 2 * size * size * c * 4  # (inW*inH + outW*outH)*C*4 per launch
+        frames_in_timed_launch = 1 if args.per_frame_launches else min(16, args.batch)
+        # (inW*inH + outW*outH)*C*4 per frame x the frames one launch renders
+        algo_bytes = 2 * size * size * c * 4 * frames_in_timed_launch
         traffic = measured_traffic(args.workload)
         achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
         out = {
@@ -256,6 +279,8 @@ def main():
                 "frames_per_gpu_per_step": args.batch,
                 "resident_distinct_frames": n_res,
                 "streams": len(streams),
+                "launches_per_step": launches_per_step,
+                "frames_per_launch": frames_per_launch,
                 "parallelism": f"image-sharded x{world}, no collective",
             },
             "roofline": {
@@ -264,12 +289,14 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
+                "traffic": ((traffic or {}).get("hbm_bytes_per_launch") or 0) * frames_in_timed_launch or None,
                 "traffic_detail": traffic,
                 "kernel": KERNEL_NAMES[wl["interp"]],
                 "kernel_ms_avg": k_avg_ms,
                 "kernel_ms_min": k_ms[0],
                 "algorithmic_bytes_per_launch": algo_bytes,
+                "frames_per_launch": frames_in_timed_launch,
+                "traffic_note": "PMC bytes measured per single-frame launch (traffic_detail) x frames_per_launch",
                 "note": "the un-fused IEEE arithmetic of the reference makes this kernel VALU-bound, not HBM-bound "
                         "(DESIGN.md section 5); frac is algorithmic bytes / kernel time / 8 TB/s as the contract asks",
             },

@@ -249,6 +249,30 @@ def reproject_multi(in_image, out_images, num_samples, interpolation, rotation_m
     _check(st)
 
 
+def reproject_batch(in_images, out_images, num_samples, interpolation, rotation_matrix=None, post=None, device=None,
+                    stream=None):
+    """n images of one geometry (same sizes, channels, lenses), device tensors only: one kernel
+    launch per 16 images (lrp_reproject_batch_device); results equal n reproject() calls."""
+    lib = _native.load()
+    if len(in_images) != len(out_images):
+        raise ValueError("in_images and out_images must have the same length")
+    if not in_images:
+        return
+    ins = (LrpImage * len(in_images))(*[i.to_c() for i in in_images])
+    outs = (LrpImage * len(out_images))(*[o.to_c() for o in out_images])
+    rot = None
+    keep = None
+    if rotation_matrix is not None:
+        keep = np.ascontiguousarray(np.asarray(rotation_matrix, dtype=np.float32).reshape(9))
+        rot = keep.ctypes.data
+    cpost = LrpPost(float(post[0]), float(post[1])) if post is not None else None
+    dev = in_images[0].data.device.index if device is None else device
+    st = lib.lrp_reproject_batch_device(ins, outs, len(in_images), int(num_samples), int(interpolation), rot,
+                                        ctypes.byref(cpost) if cpost is not None else None, dev, _stream_handle(stream))
+    del keep
+    _check(st)
+
+
 def post_process(image, exposure, reinhard, device=None, stream=None):
     """reproject::post_process (src/reproject.cpp:421-437), in place."""
     lib = _native.load()

@@ -79,6 +79,20 @@ SYMBOLS = {
             ctypes.c_void_p,
         ],
     ),
+    "lrp_reproject_batch_device": (
+        ctypes.c_int,
+        [
+            _P(LrpImage),
+            _P(LrpImage),
+            ctypes.c_int,
+            ctypes.c_int,
+            ctypes.c_int,
+            _FLOATP,
+            _P(LrpPost),
+            ctypes.c_int,
+            ctypes.c_void_p,
+        ],
+    ),
     "lrp_context_create": (ctypes.c_int, [_P(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]),
     "lrp_context_destroy": (None, [ctypes.c_void_p]),
     "lrp_context_submit": (

@@ -4,6 +4,7 @@
 // lrp_kernels_*.hip / lrp_aux_kernels.hip translation units.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -185,8 +186,11 @@ bool xsep_enabled() {
   return on;
 }
 
+// n_batch > 0: `in` / `out` are arrays of n_batch images of one geometry (checked by the caller);
+// the tile / window kernels render them in launches of up to kMaxBatch frames, the per-pixel
+// kernels one launch per frame.
 int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int interpolation,
-                      const float *rotation, const lrp_post *post, int device, hipStream_t stream) {
+                      const float *rotation, const lrp_post *post, int device, hipStream_t stream, int n_batch = 0) {
   if (num_samples <= 0) return LRP_OK; // reference loop body never runs: output untouched
   lrp::KParams P = make_params(in, out, num_samples, rotation, post);
   const int oi = out_lens_index(out->lens.type);
@@ -237,21 +241,40 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     if (!P.quad && !window && quad_enabled() && kernel_choice() != 3 && num_samples == 1 &&
         out->lens.type == LRP_FISHEYE_EQUIDISTANT)
       P.quad = 2;
-    if (window) {
-      P.win_coef = kernel_choice() == 2;
-      e = lrp::launch_win_bicubic(P, oi, im, stream);
-    } else if (interpolation == LRP_NEAREST)
-      e = lrp::launch_tile_nearest(P, oi, im, stream);
-    else if (interpolation == LRP_BILINEAR)
-      e = lrp::launch_tile_bilinear(P, oi, im, stream);
-    else
-      e = lrp::launch_tile_bicubic(P, oi, im, stream);
-  } else if (interpolation == LRP_NEAREST)
-    e = lrp::launch_nearest(P, oi, im, stream);
-  else if (interpolation == LRP_BILINEAR)
-    e = lrp::launch_bilinear(P, oi, im, stream);
-  else
-    e = lrp::launch_bicubic(P, oi, im, stream);
+    P.win_coef = kernel_choice() == 2;
+    auto launch = [&]() {
+      if (window) return lrp::launch_win_bicubic(P, oi, im, stream);
+      if (interpolation == LRP_NEAREST) return lrp::launch_tile_nearest(P, oi, im, stream);
+      if (interpolation == LRP_BILINEAR) return lrp::launch_tile_bilinear(P, oi, im, stream);
+      return lrp::launch_tile_bicubic(P, oi, im, stream);
+    };
+    if (n_batch <= 0) {
+      e = launch();
+    } else {
+      e = hipSuccess;
+      for (int first = 0; first < n_batch && e == hipSuccess; first += lrp::kMaxBatch) {
+        P.batch_n = std::min(lrp::kMaxBatch, n_batch - first);
+        for (int i = 0; i < P.batch_n; ++i) {
+          P.batch_src[i] = in[first + i].data;
+          P.batch_dst[i] = out[first + i].data;
+        }
+        e = launch();
+      }
+    }
+  } else {
+    const int n = n_batch > 0 ? n_batch : 1;
+    e = hipSuccess;
+    for (int i = 0; i < n && e == hipSuccess; ++i) {
+      P.src = in[i].data;
+      P.dst = out[i].data;
+      if (interpolation == LRP_NEAREST)
+        e = lrp::launch_nearest(P, oi, im, stream);
+      else if (interpolation == LRP_BILINEAR)
+        e = lrp::launch_bilinear(P, oi, im, stream);
+      else
+        e = lrp::launch_bicubic(P, oi, im, stream);
+    }
+  }
   if (e != hipSuccess) return hip_fail(e, "reproject kernel launch");
   return LRP_OK;
 }
@@ -363,6 +386,24 @@ int lrp_reproject_multi_device(const lrp_image *in, lrp_image *outs, int n_out, 
     if (st != LRP_OK) return st;
   }
   return LRP_OK;
+}
+
+int lrp_reproject_batch_device(const lrp_image *ins, lrp_image *outs, int n, int num_samples, int interpolation,
+                               const float *rotation, const lrp_post *post, int device, void *stream) {
+  if (n < 0 || (n > 0 && (!ins || !outs))) return fail(LRP_ERR_BAD_ARG, "bad image arrays");
+  if (n == 0) return LRP_OK;
+  for (int i = 0; i < n; ++i) {
+    int st = validate(&ins[i], &outs[i], interpolation, true);
+    if (st != LRP_OK) return st;
+    const bool same = ins[i].width == ins[0].width && ins[i].height == ins[0].height && ins[i].channels == ins[0].channels &&
+                      outs[i].width == outs[0].width && outs[i].height == outs[0].height &&
+                      std::memcmp(&ins[i].lens, &ins[0].lens, sizeof(lrp_lens)) == 0 &&
+                      std::memcmp(&outs[i].lens, &outs[0].lens, sizeof(lrp_lens)) == 0;
+    if (!same) return fail(LRP_ERR_BAD_ARG, "the images of a batch must share sizes, channel count and lenses");
+  }
+  int st = select_device(device);
+  if (st != LRP_OK) return st;
+  return enqueue_reproject(ins, outs, num_samples, interpolation, rotation, post, device, (hipStream_t)stream, n);
 }
 
 int lrp_post_process_device(lrp_image *img, float exposure, float reinhard, int device, void *stream) {

@@ -70,6 +70,18 @@ template <int Interp> constexpr int tile_rows() {
 constexpr int kT2Waves = 4;      // wavefronts per workgroup
 constexpr int kT2Threads = 64 * kT2Waves;
 
+// Batched launches: frame blockIdx.y of a batch of images that share one geometry (lenses, sizes,
+// rotation): one launch keeps the wave slots full across frame boundaries — no inter-kernel gap,
+// no drain of the last wavefronts before the next frame starts.
+__device__ __forceinline__ KParams batch_frame(const KParams &Pk) {
+  KParams P = Pk;
+  if (Pk.batch_n > 0) {
+    P.src = Pk.batch_src[blockIdx.y];
+    P.dst = Pk.batch_dst[blockIdx.y];
+  }
+  return P;
+}
+
 // ---- wavefront-wide integer min / max (all 64 lanes active) ------------------
 template <int Ctrl> __device__ __forceinline__ int dpp_i32(int v) {
   return __builtin_amdgcn_update_dpp(v, v, Ctrl, 0xF, 0xF, false);
@@ -633,8 +645,9 @@ __device__ __forceinline__ void store_px(const KParams &P, uint32_t pixel_index,
 
 // ---- the tile kernel (RGB / RGBA / RGBAZ float) ----------------------------------
 template <int OutLens, int InMode, int Interp, int CH>
-__global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_kernel(const KParams P) {
+__global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_kernel(const KParams Pk) {
   constexpr bool Loop = (InMode == kInEquirectLoop);
+  const KParams P = batch_frame(Pk);
 
   const int n_tiles = P.tiles_x * P.tiles_y;
   const int chunk = (n_tiles + kXcds - 1) / kXcds;
@@ -841,8 +854,9 @@ struct WinBlock {
 // DMA is therefore the RGBA code; the fourth component carries stale LDS contents through the
 // arithmetic (no traps are enabled) and is never stored.
 template <int OutLens, int InMode, bool Quad, int CH>
-__global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicubic_win_kernel(const KParams P) {
+__global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicubic_win_kernel(const KParams Pk) {
   static_assert(CH == 3 || CH == 4, "window kernel: RGB or RGBA");
+  const KParams P = batch_frame(Pk);
   constexpr bool Loop = (InMode == kInEquirectLoop);
   constexpr int kPlanes = 3;
   __shared__ float4 s_win[kWinWaves][kWinBuffers][kWinCap];
@@ -1261,7 +1275,7 @@ template <int Interp> hipError_t launch_tile_interp(KParams P, int out_idx, int 
   const TileKernelFn fn = P.channels == 4   ? TileKernelTable<Interp, 4>::get(out_idx, in_mode)
                           : P.channels == 3 ? TileKernelTable<Interp, 3>::get(out_idx, in_mode)
                                             : TileKernelTable<Interp, 5>::get(out_idx, in_mode);
-  hipLaunchKernelGGL(fn, dim3((unsigned)(chunk * kXcds)), dim3(kT2Threads), 0, stream, P);
+  hipLaunchKernelGGL(fn, dim3((unsigned)(chunk * kXcds), (unsigned)(P.batch_n > 0 ? P.batch_n : 1)), dim3(kT2Threads), 0, stream, P);
   return hipGetLastError();
 }
 
@@ -1303,7 +1317,7 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
   if (n_tiles <= 0) return hipSuccess;
   const int chunk = (n_tiles + kXcds - 1) / kXcds;
   const TileKernelFn fn = WinKernelTable<Quad, CH>::get(out_idx, in_mode);
-  hipLaunchKernelGGL(fn, dim3((unsigned)(chunk * kXcds)), dim3(kWinThreads), 0, stream, P);
+  hipLaunchKernelGGL(fn, dim3((unsigned)(chunk * kXcds), (unsigned)(P.batch_n > 0 ? P.batch_n : 1)), dim3(kWinThreads), 0, stream, P);
   return hipGetLastError();
 }
 

@@ -12,6 +12,7 @@ enum : int { kRect = 0, kEquidistant = 1, kEquirect = 4 };
 // Input-lens mode: equirectangular sources split into clamped and wrapping
 // (reference LoopHorizontally, src/reproject.cpp:386-394).
 enum : int { kInRect = 0, kInEquidistant = 1, kInEquirect = 2, kInEquirectLoop = 3 };
+constexpr int kMaxBatch = 16; // frames of one geometry rendered by one launch (blockIdx.y = frame)
 constexpr int kXcds = 8; // XCDs (private L2s) of an MI355X; blockIdx % 8 labels the blocks that share one
 
 struct LensP {
@@ -52,6 +53,10 @@ struct KParams {
   float in_lon_span, in_lat_span;   // equirectangular source
   int32_t blocks_per_wave;          // window kernel: 16 x 16 blocks per wavefront strip
   int32_t win_coef;                 // window kernel: shared tap-column coefficients allowed (0: raw taps only)
+  // Batched launch (tile / window kernels): frame blockIdx.y reads batch_src[y], writes batch_dst[y]
+  int32_t batch_n;
+  const float *batch_src[kMaxBatch];
+  float *batch_dst[kMaxBatch];
   int32_t quad;                     // 1: mirrored pixels / blocks (mapping symmetric about both image axes); 2: mirrored rays (tile kernels, equidistant target)
 };
 

@@ -153,6 +153,15 @@ int lrp_reproject_multi_device(const lrp_image *in, lrp_image *outs, int n_out, 
                                int interpolation, const float *rotations, const lrp_post *post,
                                int device, void *stream);
 
+/* n images of ONE geometry (same sizes, channel count, lenses; one rotation, one
+ * post setting — a directory of frames from one camera, src/main.cpp:540-622) on
+ * device-resident buffers: rendered by one kernel launch per 16 images instead of
+ * one per image, so the GPU does not drain and refill between frames.  Results are
+ * those of n lrp_reproject_device calls. */
+int lrp_reproject_batch_device(const lrp_image *ins, lrp_image *outs, int n, int num_samples,
+                               int interpolation, const float *rotation, const lrp_post *post,
+                               int device, void *stream);
+
 /* ---- batches of independent images (the reference's --input-dir path) ------ */
 
 /* A context owns a three-stage pipeline on one device — an upload stream, a

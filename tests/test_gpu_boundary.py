@@ -107,3 +107,40 @@ def test_kernel_family_knob(lrp, torch_cuda):
     assert lrp.debug_kernel(7) == 0  # out of range: query only
     lrp.debug_kernel(prev)
     assert lrp.debug_kernel(-1) == prev
+
+
+@pytest.mark.parametrize("channels,interp,deg", [(4, 2, None), (4, 2, (30.0, -15.0, 5.0)), (3, 2, (90.0, 0.0, 0.0)), (4, 1, None),
+                                                 (5, 2, None), (4, 0, (0.0, 0.0, 0.0)), (2, 2, None)])
+def test_batched_launch_equals_single_calls(lrp, torch_cuda, channels, interp, deg):
+    """lrp_reproject_batch_device: 37 frames of one geometry (three launches: 16 + 16 + 5; the
+    2-channel case goes through the per-pixel kernel frame by frame) against 37 single calls."""
+    torch = torch_cuda
+    in_w, in_h, out_w, out_h, n = 320, 200, 290, 210, 37
+    lin = cases.lenses(lrp, in_w, in_h)["eqd180"]
+    lout = cases.lenses(lrp, out_w, out_h)["rect"]
+    rot = cases.rotation(lrp, deg)
+    srcs = [torch.empty((in_h, in_w, channels), dtype=torch.float32, device="cuda") for _ in range(n)]
+    for i, s in enumerate(srcs):
+        lrp.synth_fill(s, in_w, in_h, channels, 0xBA7C0000 + i)
+    single = [torch.full((out_h, out_w, channels), -1.0, dtype=torch.float32, device="cuda") for _ in range(n)]
+    batched = [torch.full((out_h, out_w, channels), -2.0, dtype=torch.float32, device="cuda") for _ in range(n)]
+    for s, d in zip(srcs, single):
+        lrp.reproject(lrp.Image(lin, in_w, in_h, channels, s), lrp.Image(lout, out_w, out_h, channels, d), 1, interp, rot)
+    lrp.reproject_batch([lrp.Image(lin, in_w, in_h, channels, s) for s in srcs],
+                        [lrp.Image(lout, out_w, out_h, channels, d) for d in batched], 1, interp, rot)
+    torch.cuda.synchronize()
+    for i in range(n):
+        assert bool(torch.equal(single[i].view(torch.int32), batched[i].view(torch.int32))), f"frame {i} differs"
+
+
+def test_batched_launch_rejects_mixed_geometries(lrp, torch_cuda):
+    torch = torch_cuda
+    a = torch.zeros((64, 64, 4), dtype=torch.float32, device="cuda")
+    b = torch.zeros((64, 48, 4), dtype=torch.float32, device="cuda")
+    o1 = torch.zeros((32, 32, 4), dtype=torch.float32, device="cuda")
+    o2 = torch.zeros((32, 32, 4), dtype=torch.float32, device="cuda")
+    L = lrp.LensInfo
+    with pytest.raises(Exception):
+        lrp.reproject_batch([lrp.Image(L.equirectangular(), 64, 64, 4, a), lrp.Image(L.equirectangular(), 48, 64, 4, b)],
+                            [lrp.Image(L.rectilinear(18.0, 36.0, 32, 32), 32, 32, 4, o1),
+                             lrp.Image(L.rectilinear(18.0, 36.0, 32, 32), 32, 32, 4, o2)], 1, 2, None)
