@@ -6,6 +6,7 @@ R="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd "$R"
 out=gpurun_out/final; rm -rf $out; mkdir -p $out
 (timeout 1200 python -m pytest tests -m gpu -q > $out/gpu_tests.log 2>&1; echo "exit $?" >> $out/gpu_tests.log); tail -3 $out/gpu_tests.log
 timeout 200 ./tools/kbench --sum --reps 30 > $out/kbench_rgba.log 2>&1
+timeout 300 ./tools/kbench --sum --reps 8 --batch 16 eqd_rect_bc eqr_rect_bc eqr_rect_bc_rot rect_rect_bc eqr_eqd_bl_rot eqr_rect_bl eqr_rect_nn > $out/kbench_rgba_batched.log 2>&1
 timeout 200 ./tools/kbench --sum --reps 20 --channels 3 eqd_rect_bc eqr_rect_bc eqr_rect_bl eqr_rect_nn rect_eqr_bc > $out/kbench_rgb.log 2>&1
 timeout 200 ./tools/kbench --sum --reps 20 --channels 5 eqd_rect_bc eqr_rect_bc eqr_rect_bl eqr_rect_nn rect_eqr_bc > $out/kbench_rgbaz.log 2>&1
 LRP_KERNEL=pixel timeout 200 ./tools/kbench --sum --reps 20 eqd_rect_bc eqr_rect_bc eqr_rect_bl eqr_rect_nn eqd_rect_nn eqd_rect_bl > $out/kbench_pixel_kernel.log 2>&1

@@ -7,7 +7,8 @@
 //
 // Build (tools/build_kbench.sh):
 //   hipcc -O2 -std=c++17 tools/kbench.cpp -Iinclude -L<pkg>/lib -llrp_hip -Wl,-rpath,<pkg>/lib -o tools/kbench
-// Usage: kbench [--size N] [--reps R] [--warmup W] [--distinct D] [--channels C] [--ns S] [--sum] [workload ...]
+// Usage: kbench [--size N] [--reps R] [--warmup W] [--distinct D] [--channels C] [--ns S] [--batch B] [--sum] [workload ...]
+//   --batch B: every launch renders B frames (lrp_reproject_batch_device, B <= distinct); times are per launch / B
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
@@ -93,7 +94,7 @@ static uint64_t fnv1a(const void *p, size_t n) {
 }
 
 int main(int argc, char **argv) {
-  int size = 4096, reps = 20, distinct = 4, channels = 4, ns = 1, out_size = 0, warmup = 100;
+  int size = 4096, reps = 20, distinct = 4, channels = 4, ns = 1, out_size = 0, warmup = 100, batch = 0;
   bool sum = false, post = false;
   std::vector<std::string> names;
   for (int i = 1; i < argc; ++i) {
@@ -106,11 +107,13 @@ int main(int argc, char **argv) {
     else if (a == "--distinct") distinct = next();
     else if (a == "--channels") channels = next();
     else if (a == "--ns") ns = next();
+    else if (a == "--batch") batch = next();
     else if (a == "--sum") sum = true;
     else if (a == "--post") post = true;
     else names.push_back(a);
   }
   if (!out_size) out_size = size;
+  if (batch > 0 && distinct < batch) distinct = batch;
   if (names.empty())
     for (const auto &w : kWorkloads) names.push_back(w.name);
   if (lrp_device_count() < 1) {
@@ -154,11 +157,22 @@ int main(int argc, char **argv) {
     const float d2r = 3.14159265358979f / 180.0f;
     lrp_rotation_matrix(W->rot_deg[0] * d2r, W->rot_deg[1] * d2r, W->rot_deg[2] * d2r, rot);
     lrp_post pp{2.0f, 4.0f};
+    std::vector<lrp_image> ins((size_t)(batch > 0 ? batch : 0), in), outs((size_t)(batch > 0 ? batch : 0), out);
+    for (int b = 0; b < batch; ++b) {
+      ins[(size_t)b].data = src[(size_t)b];
+      outs[(size_t)b].data = dst[(size_t)b];
+    }
     auto launch = [&](int i) {
+      if (batch > 0) {
+        LRP_OKAY(lrp_reproject_batch_device(ins.data(), outs.data(), batch, ns, W->interp, W->has_rot ? rot : nullptr,
+                                            post ? &pp : nullptr, 0, stream));
+        return;
+      }
       in.data = src[i % distinct];
       out.data = dst[i % distinct];
       LRP_OKAY(lrp_reproject_device(&in, &out, ns, W->interp, W->has_rot ? rot : nullptr, post ? &pp : nullptr, 0, stream));
     };
+    if (batch > 0 && warmup > 100 / batch) warmup = 100 / batch + 2;
     // ~20 ms of back-to-back launches first: the chip settles its clock over ~10 ms of load
     for (int i = 0; i < warmup; ++i) launch(i);
     HIP_OK(hipStreamSynchronize(stream));
@@ -189,7 +203,8 @@ int main(int argc, char **argv) {
       printf("\n");
     }
     for (auto &e : ev) HIP_OK(hipEventDestroy(e));
-    const double avg_s = total / reps * 1e-3;
+    const double avg_s = total / reps * 1e-3 / (batch > 0 ? batch : 1); // per frame
+    best /= (float)(batch > 0 ? batch : 1);
     const double bytes = (double)(in_elems + out_elems) * 4;
     uint64_t h = 0;
     if (sum) {
