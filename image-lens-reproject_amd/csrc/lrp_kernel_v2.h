@@ -833,7 +833,7 @@ struct WinBlock {
   // coefficient tier (wave-uniform): per half of the block (passes 0-1, 2-3) the first
   // int(sy) and the number of distinct int(sy) rows; a coefficient row has the window's pitch
   int iy0[2], iyn[2], c_plane, c_base; // plane size and first slot of plane 0 (behind the raw window + a margin)
-  bool coef;
+  bool coef, whole;                    // whole: one set of planes for the block (iy0 / iyn equal for both halves)
 };
 
 // One wavefront walks its strip of `blocks_per_wave` blocks (plain: top to bottom; mirrored: a
@@ -961,7 +961,7 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
       lo_y[k >> 1] = min(lo_y[k >> 1], by);
       hi_y[k >> 1] = max(hi_y[k >> 1], by);
     }
-    b.staged = b.coef = false;
+    b.staged = b.coef = b.whole = false;
     b.x_lo = b.y_lo = b.bw = b.bh = b.pitch = b.c_plane = b.c_base = 0;
     b.iy0[0] = b.iy0[1] = b.iyn[0] = b.iyn[1] = 0;
     bool all_exact = wave_all(exact != 0);
@@ -997,6 +997,13 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
         b.iyn[0] = ya_last - ya_first + 1;
         b.iy0[1] = yb_first;
         b.iyn[1] = yb_last - yb_first + 1;
+        // strongly magnified blocks have room for the planes of ALL their origin rows: one
+        // precompute per block (fuller lanes: e.g. 132 origins in 3 trips instead of 2 x 77 in 4)
+        b.whole = raw_slots(b) + kPlanes * b.pitch * (y_last - y_first + 1) <= kWinCap;
+        if (b.whole) {
+          b.iy0[0] = b.iy0[1] = y_first;
+          b.iyn[0] = b.iyn[1] = y_last - y_first + 1;
+        }
         b.c_plane = b.pitch * max(b.iyn[0], b.iyn[1]);
         b.coef = kWinCoef && P.win_coef != 0 && b.staged && raw_slots(b) + kPlanes * b.c_plane <= kWinCap;
         // planes behind the raw window plus, where there is room, one row and one column of slack:
@@ -1121,7 +1128,7 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #if !defined(LRP_SKIP_PLANES) // timing experiment (wrong results): the coefficient phase removed
-      if (kWinCoef && cur.coef) precompute(cur, h);
+      if (kWinCoef && cur.coef && (h == 0 || !cur.whole)) precompute(cur, h);
 #endif
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
