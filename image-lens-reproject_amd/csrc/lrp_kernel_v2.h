@@ -613,10 +613,16 @@ __device__ __forceinline__ Px<CH> sample_direct(const KParams &P, const SrcView 
 }
 
 // src/reproject.cpp:338-341 + optional fused post_process (:421-437), one pixel.
-template <int CH>
+// UnitNorm: num_samples == 1, normalize == 1.0f: x * 1.0f is x for every float (the sum 0.0f + s
+// has already turned -0 into +0 and quieted a NaN), so the five multiplies are not issued.
+template <int CH, bool UnitNorm = false>
 __device__ __forceinline__ void store_px(const KParams &P, uint32_t pixel_index, Px<CH> a) {
-  const float n = P.normalize;
-  float c[5] = {a.lo.x * n, a.lo.y * n, (CH == 3 ? a.e : a.hi.x) * n, a.hi.y * n, a.e * n};
+  const float n = UnitNorm ? 1.0f : P.normalize;
+  float c[5] = {a.lo.x, a.lo.y, (CH == 3 ? a.e : a.hi.x), a.hi.y, a.e};
+  if constexpr (!UnitNorm) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) c[i] *= n;
+  }
   if (P.has_post) {
     c[0] = tonemap(c[0], P.exposure, P.reinhard);
     c[1] = tonemap(c[1], P.exposure, P.reinhard);
@@ -691,7 +697,7 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
           Px<CH> a = px_zero<CH>();
           px_add<CH>(a, sample_direct<Interp, Loop, CH>(P, src, sx, sy)); // :334-336
           const int xo = mx ? P.out_w - 1 - x : x, yo = my ? P.out_h - 1 - yk : yk;
-          if (x < qw && yk < qh) store_px<CH>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
+          if (x < qw && yk < qh) store_px<CH, true>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
         }
       }
     }
@@ -733,7 +739,7 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
         Px<CH> a = px_zero<CH>();
         px_add<CH>(a, sample_direct<Interp, Loop, CH>(P, src, sx, sy)); // :334-336
         const int xo = mx ? P.out_w - 1 - x : x, yo = my ? P.out_h - 1 - yk : yk;
-        if (x < qw && yk < qh) store_px<CH>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
+        if (x < qw && yk < qh) store_px<CH, true>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
       }
     }
     return;
@@ -764,7 +770,12 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
 #pragma unroll
     for (int k = 0; k < kT2Rows; ++k) {
       const int yk = y_first + k;
-      if (yk < P.out_h) store_px<CH>(P, (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x, acc[k]);
+      if (yk < P.out_h) {
+        if (ns == 1)
+          store_px<CH, true>(P, (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x, acc[k]);
+        else
+          store_px<CH>(P, (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x, acc[k]);
+      }
     }
   }
 }
@@ -1236,9 +1247,9 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
         const int xo = (quad && (g & 1)) ? P.out_w - 1 - xe : xe; // mirrored blocks write the mirrored pixel
         const int yo = (quad && (g >> 1)) ? P.out_h - 1 - yc : yc;
 #if defined(LRP_NO_STORE) // timing experiment: almost no output traffic
-        if (a.lo.x == 12345.678f) store_px<CH>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
+        if (a.lo.x == 12345.678f) store_px<CH, true>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
 #else
-        store_px<CH>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
+        store_px<CH, true>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
 #endif
       }
     }
