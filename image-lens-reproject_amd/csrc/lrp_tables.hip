@@ -92,7 +92,9 @@ __global__ __launch_bounds__(256) void build_tables_kernel(const TableArgs A) {
     if (b == 0x80000000u || (b & 0x7f800000u) == 0x7f800000u) flags |= 1;
   };
   note(v0);
-  if (__float_as_uint(m0) != (__float_as_uint(v0) ^ 0x80000000u)) flags |= is_col ? 2 : 4;
+  // the centre column / row of an odd-sized image is its own mirror image (its +0 has no -0 partner)
+  const bool self = 2 * j == (is_col ? n_col : n_row) - 1;
+  if (!self && __float_as_uint(m0) != (__float_as_uint(v0) ^ 0x80000000u)) flags |= is_col ? 2 : 4;
   if (is_col) {
     A.tab[j] = v0;
     if (A.out_lens != kRect) {
