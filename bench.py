@@ -2,27 +2,42 @@
 """bench.py — Mpix/s of the lens-reprojection hot path on MI355X.
 
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`;
-for N > 1 it is launched by torch.distributed.run, one rank per GPU.  Prints ONE
-JSON line on rank 0.
+for N > 1 it is launched by torch.distributed.run, one rank per GPU (started without
+torchrun it starts torchrun itself, as a child, before anything touches the GPU).
+Prints ONE JSON line on rank 0.
 
-A step = one pass of the hot path over one batch of `--batch` synthetic 4096x4096
-RGBA float frames that are already resident in HBM (generated on the device by
-the counter-based generator; seeds 0x5EED0000 + i).  The batch is sharded
-one-shard-per-GPU with no collective on the data path (images are independent,
-reference src/main.cpp:540-622), i.e. weak scaling: every rank renders `--batch`
-frames per step.  The frames of a step share one geometry (a directory of frames
-from one camera, the reference's --input-dir path), so a step is ONE kernel launch
-(lrp_reproject_batch_device, 16 frames per launch: the chip neither drains nor
-refills between frames); `--per-frame-launches` issues one launch per frame instead,
-round-robin over `--streams` HIP streams.  `roofline.achieved` = algorithmic bytes
-of the frames one launch renders / that launch's duration (HIP events on its stream).
+A step = one pass of the hot path over one batch of `--batch` (default 256, north_star's
+"256-image batch") synthetic 4096x4096 RGBA float frames that are already resident in
+HBM (generated on the device by the counter-based generator; image i has seed
+0x5EED0000 + i on whichever rank renders it).  The batch is one sorted list of
+independent images sharded in contiguous static blocks, block r -> rank r, exactly as
+the reference hands files to its pool threads (src/main.cpp:538-544, 624-655;
+image-lens-reproject_amd/sharding.py): STRONG scaling, total work fixed, no
+collective on the data path.  `--scaling weak` gives every rank its own `--batch`
+frames instead.  The frames of a step share one geometry (a directory of frames from
+one camera, the reference's --input-dir path), so a rank renders its block with one
+kernel launch per 16 frames (lrp_reproject_batch_device); `--per-frame-launches`
+issues one launch per frame instead, round-robin over `--streams` HIP streams.
+
+Reported next to the headline value, all measured in this process:
+  roofline            dominant kernel of the headline workload, HIP events on its stream
+                      (frac = read + write algorithmic bytes / time / 8 TB/s,
+                       frac_read_only = source bytes only, single_launch_us = one frame per launch)
+  secondary           the same figures for north_star's target case (equirect -> rect bicubic)
+  outputs_digest      sha256 over the per-image 64-bit checksums of the rendered batch, in
+                      image order: equal for any N (tests/test_bench_multi_rank.py)
+  cpu_baseline        the oracle on this host's cores, one image per thread
 """
 import argparse
+import hashlib
 import importlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,6 +45,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FRAMES_PER_LAUNCH = 16  # lrp::kMaxBatch
 
 WORKLOADS = {
     # BASELINE.json configs[1] (the config the metric is quoted on).  The reference
@@ -45,22 +61,39 @@ WORKLOADS = {
     # BASELINE.json configs[0] shape at 4K (plumbing case, nearest).
     "equirect_to_rect_nearest": dict(in_lens="eqr", out_lens="rect", interp=0, rot=(0.0, 0.0, 0.0), channels=4,
                                      size=4096),
+    # BASELINE.json configs[3] shape (RGBA variant; the RGBAZ one is timed by tools/kbench).
+    "rect_to_equirect_bicubic": dict(in_lens="rect", out_lens="eqr", interp=2, rot=(0.0, 0.0, 0.0), channels=4,
+                                     size=4096),
 }
-
+INTERP_NAMES = {0: "nearest", 1: "bilinear", 2: "bicubic"}
 KERNEL_NAMES = {0: "reproject_tile_kernel (nearest)", 1: "reproject_tile_kernel (bilinear)",
                 2: "reproject_bicubic_win_kernel (LDS window)"}
+# sources whose contents decide what the kernels do: the PMC traffic file is only valid for them
+KERNEL_SOURCES = ["lrp_kernel_v2.h", "lrp_device.h", "lrp_math.h", "lrp_source_axes.h", "lrp_params.h", "lrp_tables.hip",
+                  "lrp_capi.cpp"]
+
+
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "image-lens-reproject_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def measured_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
-    summary (profiles/traffic_r01.json; made by tools/collect_traffic.sh on an MI355X)."""
-    path = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    """HBM bytes per single-frame launch of the dominant kernel from the committed rocprofv3 PMC
+    summary (profiles/traffic_r02.json; tools/collect_traffic.sh on an MI355X).  The file is stamped
+    with the hash of the kernel sources it was measured on; a stale file yields None."""
+    path = os.path.join(ROOT, "profiles", "traffic_r02.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload)
+            d = json.load(f)
     except (OSError, ValueError):
         return None
-
+    if d.get("_kernel_source_sha") != kernel_source_sha():
+        return None
+    return d.get(workload)
 
 
 def make_lens(pkg, kind, w, h):
@@ -91,80 +124,199 @@ def usable_cpus():
     return max(1, n)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(pkg, wl, seconds_target):
-    """The oracle (kind "port": our C restatement of the reference loop, built with
-    the reference's flags) timed on this host's cores.  The reference schedules
-    one image per pool thread (src/main.cpp:538-544) and its loop is
-    single-threaded per image; here every host thread renders its own row band
-    of each frame (rows are independent, src/reproject.cpp:284), which is the
-    same work per thread without needing one 256 MiB output per thread."""
+    """The oracle (kind "port": our C restatement of the reference loop, built with the
+    reference's flags) timed on this host's cores the way the reference schedules work
+    (SURVEY §8d): ONE IMAGE PER THREAD, -j = usable cores (src/main.cpp:538-544), each
+    thread with its own source and destination frame; plus the single-thread figure.
+    Bounded sample: every thread renders the first `rows` rows of its own frame."""
     import ctypes
-    from concurrent.futures import ThreadPoolExecutor
 
     import numpy as np
     import oracle_binding as oracle
 
     cores = usable_cpus()
-    size = wl["size"]
-    c = wl["channels"]
-    src = oracle.synth_frame(size, size, c, 0x5EED0000)
+    size, c = wl["size"], wl["channels"]
     lin, lout = make_lens(pkg, wl["in_lens"], size, size), make_lens(pkg, wl["out_lens"], size, size)
     rot = make_rot(pkg, wl["rot"])
-    out = np.empty((size, size, c), dtype=np.float32)
     L = oracle.lib()
-    cin = oracle._image(lin, size, size, c, src)
-    cout = oracle._image(lout, size, size, c, out)
     keep, rp = oracle._rot(rot)
-    bands = [(size * i // cores, size * (i + 1) // cores) for i in range(cores)]
 
-    def run(frames):
-        def work(b):
-            for _ in range(frames):
-                L.lrpo_reproject_rows(ctypes.byref(cin), ctypes.byref(cout), 1, wl["interp"], rp, b[0], b[1])
+    def run(n_threads, rows):
+        """n_threads images, one per thread; returns wall seconds of the slowest (all start together)."""
+        start = threading.Barrier(n_threads + 1)
+        done = [0.0] * n_threads
 
+        def work(t):
+            src = oracle.synth_frame(size, size, c, 0x5EED0000 + t)  # this thread's own image
+            out = np.empty((size, size, c), dtype=np.float32)
+            cin, cout = oracle._image(lin, size, size, c, src), oracle._image(lout, size, size, c, out)
+            start.wait()
+            L.lrpo_reproject_rows(ctypes.byref(cin), ctypes.byref(cout), 1, wl["interp"], rp, 0, rows)
+            done[t] = time.perf_counter()
+
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+        for th in threads:
+            th.start()
+        start.wait()
         t0 = time.perf_counter()
-        with ThreadPoolExecutor(cores) as ex:
-            list(ex.map(work, bands))
-        return time.perf_counter() - t0
+        for th in threads:
+            th.join()
+        return max(done) - t0
 
-    dt = run(1)  # calibration (also warms the pages)
-    frames = int(max(1, min(4096, seconds_target / max(dt, 1e-3))))
-    dt = run(frames)
+    probe_rows = max(16, size // 32)
+    dt_probe = run(1, probe_rows)  # calibration: rows per second of one thread
+    rows = int(min(size, max(probe_rows, probe_rows * (seconds_target / 2.0) / max(dt_probe, 1e-4))))
+    dt_one = run(1, rows)
+    dt_all = run(cores, rows)
     return {
-        "value": frames * size * size / dt / 1e6,
+        "value": cores * rows * size / dt_all / 1e6,
         "unit": "Mpix/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{frames} frames of {size}x{size}x{c}, each split into {cores} row bands (one per host thread = "
-                  f"one per usable CPU: affinity {len(os.sched_getaffinity(0))}, cgroup quota honoured), {dt:.1f} s wall",
+        "single_thread_value": rows * size / dt_one / 1e6,
+        "cpu_model": cpu_model(),
+        "sample": f"one image per thread like the reference's -j pool (src/main.cpp:538-544): {cores} threads = usable CPUs "
+                  f"(affinity {len(os.sched_getaffinity(0))}, cgroup quota honoured), each rendering the first {rows} rows of "
+                  f"its own {size}x{size}x{c} frame ({dt_all:.1f} s wall); single thread: same rows of one frame ({dt_one:.1f} s)",
+    }
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256,
+                    help="images per step: the whole job's batch (strong scaling, sharded over the ranks in static "
+                         "blocks) or every rank's own batch (--scaling weak)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="distinct resident source / destination frame pairs per GPU (0 = the rank's whole shard if it "
+                         "fits in 70 %% of the free HBM, else as many as fit, at least 16)")
+    ap.add_argument("--per-frame-launches", action="store_true",
+                    help="one kernel launch per frame (lrp_reproject_device) instead of one per 16 frames "
+                         "(lrp_reproject_batch_device: all frames of a step share one geometry)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the frames of a step round-robin over (--per-frame-launches only)")
+    ap.add_argument("--workload", default="fisheye_to_rect_bicubic", choices=sorted(WORKLOADS))
+    ap.add_argument("--secondary", default="equirect_to_rect_bicubic",
+                    help="comma-separated workloads measured (kernel timing only) in the same process; '' = none")
+    ap.add_argument("--size", type=int, default=0, help="override the frame size (tests; 0 = the workload's 4096)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the barrier / max-time reduction for --gpus > 1 (nccl = RCCL; "
+                         "gloo lets two ranks share one GPU in a smoke test of the multi-rank path)")
+    ap.add_argument("--checksums-file", default="", help="rank 0 writes the per-image checksum list (JSON) here")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD (this
+    process has not touched the GPU) and exit with its code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def time_launches(torch, stream, fn, reps):
+    """Average / min duration (ms) of `fn(i)` (one kernel launch each) by events on `stream`."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for i in range(reps):
+        ev[i][0].record(stream)
+        fn(i)
+        ev[i][1].record(stream)
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    return sum(ms) / len(ms), ms[0]
+
+
+def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name):
+    """Roofline figures of one workload's dominant kernel on resident frames: 16-frame launches and
+    single-frame launches, both with HIP events on the launch stream, cycling over the resident frames."""
+    c = wl["channels"]
+    lin, lout = make_lens(pkg, wl["in_lens"], size, size), make_lens(pkg, wl["out_lens"], size, size)
+    rot = make_rot(pkg, wl["rot"])
+    im_in = [pkg.Image(lin, size, size, c, s) for s in srcs]
+    im_out = [pkg.Image(lout, size, size, c, d) for d in dsts]
+    n_res = len(srcs)
+    nb = min(FRAMES_PER_LAUNCH, n_res)
+
+    def batched(i):
+        ids = [(i * nb + k) % n_res for k in range(nb)]
+        pkg.reproject_batch([im_in[j] for j in ids], [im_out[j] for j in ids], 1, wl["interp"], rot, stream=stream)
+
+    def single(i):
+        pkg.reproject(im_in[i % n_res], im_out[i % n_res], 1, wl["interp"], rot, stream=stream)
+
+    for i in range(3):  # table builds, clock
+        batched(i)
+    torch.cuda.synchronize()
+    b_avg, b_min = time_launches(torch, stream, batched, 24)
+    s_avg, s_min = time_launches(torch, stream, single, 64)
+    frame_bytes = size * size * c * 4
+    algo = 2 * frame_bytes * nb  # SURVEY §8d: (inW*inH + outW*outH)*C*4 per frame x frames per launch
+    achieved = algo / (b_avg * 1e-3) / 1e9
+    traffic = measured_traffic(name) if size == wl["size"] else None
+    return {
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "frac_read_only": frame_bytes * nb / (b_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "traffic": ((traffic or {}).get("hbm_bytes_per_launch") or 0) * nb or None,
+        "traffic_detail": traffic,
+        "kernel": KERNEL_NAMES[wl["interp"]],
+        "workload": name,
+        "kernel_ms_avg": b_avg,
+        "kernel_ms_min": b_min,
+        "frames_per_launch": nb,
+        "us_per_frame": b_avg * 1e3 / nb,
+        "algorithmic_bytes_per_launch": algo,
+        "single_launch_us": s_avg * 1e3,
+        "single_launch_us_min": s_min * 1e3,
+        "single_launch_frac": 2 * frame_bytes / (s_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "traffic_note": "PMC bytes measured per single-frame launch (traffic_detail) x frames_per_launch; null when "
+                        "profiles/traffic_r02.json was measured on other kernel sources",
     }
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
-    ap.add_argument("--distinct", type=int, default=16, help="distinct resident source / destination frames per GPU")
-    ap.add_argument("--per-frame-launches", action="store_true",
-                    help="one kernel launch per frame (lrp_reproject_device) instead of one per step "
-                         "(lrp_reproject_batch_device: all frames of a step share one geometry)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams the frames of a step round-robin over (one frame fills the chip; >1 only "
-                         "overlaps kernel tails and makes per-kernel durations in a profile overlap)")
-    ap.add_argument("--workload", default="fisheye_to_rect_bicubic", choices=sorted(WORKLOADS))
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend of the barrier / max-time reduction for --gpus > 1 (nccl = RCCL; "
-                         "gloo lets two ranks share one GPU in a smoke test of the multi-rank path)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if "WORLD_SIZE" in os.environ or args.gpus < 1:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with python -m "
+                             f"torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                             f"--master-port P bench.py --gpus {args.gpus} ...")
+        sys.exit(relaunch_under_torchrun(args))
 
     import torch
 
     pkg = importlib.import_module("image-lens-reproject_amd")
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    sharding = importlib.import_module("image-lens-reproject_amd.sharding")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -182,18 +334,32 @@ def main():
             dist.init_process_group(backend="gloo")
     dev = torch.device("cuda", dev_index)
 
-    wl = WORKLOADS[args.workload]
-    size, c = wl["size"], wl["channels"]
+    wl = dict(WORKLOADS[args.workload])
+    size = args.size or wl["size"]
+    c = wl["channels"]
     lin, lout = make_lens(pkg, wl["in_lens"], size, size), make_lens(pkg, wl["out_lens"], size, size)
     rot = make_rot(pkg, wl["rot"])
 
-    # resident frames: `distinct` sources and as many destinations, cycled, so the
-    # working set (distinct x 512 MiB) is far beyond the 256 MiB Infinity Cache.
-    n_res = max(1, min(args.distinct, args.batch))
+    # this rank's block of the sorted image list
+    if args.scaling == "strong":
+        first, last = sharding.my_block(args.batch, world, rank)
+        total_images = args.batch
+    else:
+        first, last = rank * args.batch, (rank + 1) * args.batch
+        total_images = args.batch * world
+    shard = list(range(first, last))
+
+    # resident frames: the whole shard when it fits (288 GB of HBM: 256 x 2 x 256 MiB = 128 GiB), else a
+    # ring of at least 16 pairs — far beyond the 256 MiB Infinity Cache either way
+    frame_bytes = size * size * c * 4
+    free_b, _total_b = torch.cuda.mem_get_info(dev)
+    fit = max(1, int(0.70 * free_b / (2 * frame_bytes)))
+    n_res = args.distinct if args.distinct > 0 else min(max(len(shard), 1), fit)
+    n_res = max(1, min(n_res, max(len(shard), 1)))
     srcs, dsts = [], []
-    for i in range(n_res):
+    for k in range(n_res):
         s = torch.empty((size, size, c), dtype=torch.float32, device=dev)
-        pkg.synth_fill(s, size, size, c, 0x5EED0000 + rank * args.batch + i)
+        pkg.synth_fill(s, size, size, c, 0x5EED0000 + (shard[k] if shard else 0))
         srcs.append(s)
         dsts.append(torch.empty((size, size, c), dtype=torch.float32, device=dev))
     im_in = [pkg.Image(lin, size, size, c, s) for s in srcs]
@@ -201,16 +367,16 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
     torch.cuda.synchronize()
 
-    batch_in = [im_in[i % n_res] for i in range(args.batch)]
-    batch_out = [im_out[i % n_res] for i in range(args.batch)]
-    launches_per_step = args.batch if args.per_frame_launches else (args.batch + 15) // 16
-    frames_per_launch = args.batch / launches_per_step
+    batch_in = [im_in[k % n_res] for k in range(len(shard))]
+    batch_out = [im_out[k % n_res] for k in range(len(shard))]
+    launches_per_step = len(shard) if args.per_frame_launches else -(-len(shard) // FRAMES_PER_LAUNCH)
 
     def step():
+        if not shard:
+            return
         if args.per_frame_launches:
-            for i in range(args.batch):
-                st = streams[i % len(streams)]
-                pkg.reproject(im_in[i % n_res], im_out[i % n_res], 1, wl["interp"], rot, stream=st)
+            for k in range(len(shard)):
+                pkg.reproject(batch_in[k], batch_out[k], 1, wl["interp"], rot, stream=streams[k % len(streams)])
         else:  # the frames of a step share one geometry: one launch per 16 frames
             pkg.reproject_batch(batch_in, batch_out, 1, wl["interp"], rot, stream=streams[0])
 
@@ -228,78 +394,62 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(elapsed, dist, dev if args.dist_backend == "nccl" else None)
 
-    # dominant kernel timed live with HIP events on the stream it is launched on
-    # (torch events recorded on that same stream), one frame per launch.
-    kst = streams[0]
-    reps = 40
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    if not args.per_frame_launches:
-        reps = 10
-        ev = ev[:reps]
-    for i in range(reps):
-        ev[i][0].record(kst)
-        if args.per_frame_launches:
-            pkg.reproject(im_in[i % n_res], im_out[i % n_res], 1, wl["interp"], rot, stream=kst)
-        else:
-            pkg.reproject_batch(batch_in[:16], batch_out[:16], 1, wl["interp"], rot, stream=kst)
-        ev[i][1].record(kst)
-    torch.cuda.synchronize()
-    k_ms = sorted(a.elapsed_time(b) for a, b in ev)
-    k_avg_ms = sum(k_ms) / len(k_ms)
+    # per-image checksums of what the timed steps rendered (only when every image of the shard has its
+    # own resident destination), gathered in image order — a reporting step, not on the data path
+    sums = pkg.checksums(dsts[: len(shard)]) if shard and n_res >= len(shard) else None
+    all_sums = [sums]
+    if dist is not None:
+        all_sums = [None] * world
+        dist.all_gather_object(all_sums, sums)
+    digest = None
+    if all(s is not None for s in all_sums):
+        flat = [v for s in all_sums for v in s]
+        digest = hashlib.sha256(",".join(f"{v:016x}" for v in flat).encode()).hexdigest()
+        if rank == 0 and args.checksums_file:
+            with open(args.checksums_file, "w") as f:
+                json.dump({"images": total_images, "n_gpus": world, "checksums": [f"{v:016x}" for v in flat]}, f)
 
     if rank == 0:
-        pix_per_step = world * args.batch * size * size
-        value = pix_per_step * args.steps / elapsed / 1e6
-        frames_in_timed_launch = 1 if args.per_frame_launches else min(16, args.batch)
-        # (inW*inH + outW*outH)*C*4 per frame x the frames one launch renders
-        algo_bytes = 2 * size * size * c * 4 * frames_in_timed_launch
-        traffic = measured_traffic(args.workload)
-        achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
+        res = min(n_res, 64)
+        roof = kernel_figures(torch, pkg, wl, size, srcs[:res], dsts[:res], streams[0], args.workload)
+        roof["note"] = ("the un-fused IEEE arithmetic of the reference makes this kernel VALU-bound, not HBM-bound "
+                        "(DESIGN.md section 5); frac is algorithmic bytes / kernel time / 8 TB/s as the contract asks")
+        secondary = {}
+        for name in [n for n in args.secondary.split(",") if n and n != args.workload]:
+            if WORKLOADS[name]["channels"] == c:
+                secondary[name] = kernel_figures(torch, pkg, WORKLOADS[name], size, srcs[:res], dsts[:res], streams[0], name)
+        value = total_images * size * size * args.steps / elapsed / 1e6
         out = {
-            "metric": "Mpix/s reprojected (4K RGBA float, bicubic)",
+            "metric": f"Mpix/s reprojected ({'4K' if size == 4096 else size} {'RGBA' if c == 4 else f'{c}-channel'} float, "
+                      f"{INTERP_NAMES[wl['interp']]})",
             "value": value,
             "unit": "Mpix/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "timed_region_s": elapsed,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: {size}x{size}x{c} f32 -> {size}x{size}x{c}, "
                             f"{wl['in_lens']}->{wl['out_lens']}, interp={wl['interp']}, num_samples=1",
-                "frames_per_gpu_per_step": args.batch,
-                "resident_distinct_frames": n_res,
+                "images_per_step": total_images,
+                "images_per_gpu_per_step": len(shard),
+                "resident_distinct_frames_per_gpu": n_res,
                 "streams": len(streams),
-                "launches_per_step": launches_per_step,
-                "frames_per_launch": frames_per_launch,
-                "parallelism": f"image-sharded x{world}, no collective",
+                "launches_per_step_per_gpu": launches_per_step,
+                "frames_per_launch": 1 if args.per_frame_launches else FRAMES_PER_LAUNCH,
+                "parallelism": f"image-sharded x{world} (static blocks of the sorted list), no collective",
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": ((traffic or {}).get("hbm_bytes_per_launch") or 0) * frames_in_timed_launch or None,
-                "traffic_detail": traffic,
-                "kernel": KERNEL_NAMES[wl["interp"]],
-                "kernel_ms_avg": k_avg_ms,
-                "kernel_ms_min": k_ms[0],
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "frames_per_launch": frames_in_timed_launch,
-                "traffic_note": "PMC bytes measured per single-frame launch (traffic_detail) x frames_per_launch",
-                "note": "the un-fused IEEE arithmetic of the reference makes this kernel VALU-bound, not HBM-bound "
-                        "(DESIGN.md section 5); frac is algorithmic bytes / kernel time / 8 TB/s as the contract asks",
-            },
+            "outputs_digest": digest,
+            "roofline": roof,
+            "secondary": secondary,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, wl, args.cpu_seconds)

@@ -341,3 +341,39 @@ def math_eval(func, a, b=None, stream=None):
     _check(lib.lrp_math_eval_device(int(func), a.data_ptr(), b.data_ptr() if b is not None else None, out.data_ptr(),
                                     a.numel(), a.device.index, _stream_handle(stream)))
     return out
+
+
+def checksums(tensors, stream=None):
+    """Order-independent 64-bit checksums (lrp_checksum_device) of float32 CUDA tensors, one
+    device pass per tensor and a single read-back: a list of Python ints."""
+    import torch
+
+    lib = _native.load()
+    if not tensors:
+        return []
+    dev = tensors[0].device
+    out = torch.zeros(len(tensors), dtype=torch.int64, device=dev)
+    for i, t in enumerate(tensors):
+        _check(lib.lrp_checksum_device(t.data_ptr(), t.numel(), out.data_ptr() + 8 * i, dev.index, _stream_handle(stream)))
+    return [int(v) & 0xFFFFFFFFFFFFFFFF for v in out.cpu().tolist()]
+
+
+def checksum_host(array):
+    """The same checksum evaluated with numpy on a host array (tests)."""
+    bits = np.ascontiguousarray(array, dtype=np.float32).reshape(-1).view(np.uint32)
+    idx = np.arange(bits.size, dtype=np.uint32)
+
+    def mix32(seed, index):
+        with np.errstate(over="ignore"):
+            h = index * np.uint32(0x9E3779B9) + seed
+            h ^= h >> np.uint32(16)
+            h *= np.uint32(0x7FEB352D)
+            h ^= h >> np.uint32(15)
+            h *= np.uint32(0x846CA68B)
+            h ^= h >> np.uint32(16)
+        return h
+
+    with np.errstate(over="ignore"):
+        lo = mix32(bits, idx).astype(np.uint64)
+        hi = mix32(bits ^ np.uint32(0xA5A5A5A5), idx * np.uint32(2) + np.uint32(0x7F4A7C15)).astype(np.uint64)
+        return int(np.sum((hi << np.uint64(32)) | lo, dtype=np.uint64))

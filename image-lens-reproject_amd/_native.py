@@ -104,6 +104,10 @@ SYMBOLS = {
         ctypes.c_int,
         [_FLOATP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
     ),
+    "lrp_checksum_device": (
+        ctypes.c_int,
+        [_FLOATP, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
+    ),
     "lrp_math_eval_device": (
         ctypes.c_int,
         [ctypes.c_int, _FLOATP, _FLOATP, _FLOATP, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p],

@@ -80,6 +80,24 @@ __global__ __launch_bounds__(kBlock) void math_eval_kernel(int func, const float
   }
 }
 
+// Order-independent 64-bit checksum of a float buffer's bit patterns: the sum (mod 2^64) over all
+// elements of a 64-bit hash of (bits, index).  Any association of the additions gives the same
+// value, so the grid shape does not matter; tests/bench compare per-image values across runs,
+// GPU counts and against the same sum evaluated on the host.
+__device__ __forceinline__ unsigned long long checksum_term(uint32_t bits, uint32_t index) {
+  const uint32_t lo = mix32(bits, index);
+  const uint32_t hi = mix32(bits ^ 0xA5A5A5A5u, index * 2u + 0x7F4A7C15u);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(kBlock) void checksum_kernel(const uint32_t *data, size_t n, unsigned long long *out) {
+  unsigned long long acc = 0;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+    acc += checksum_term(data[i], (uint32_t)i);
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63u) == 0) atomicAdd(out, acc);
+}
+
 inline unsigned grid_for(size_t n) {
   size_t g = (n + kBlock - 1) / kBlock;
   if (g > (size_t)kMaxBlocks) g = kMaxBlocks;
@@ -100,6 +118,14 @@ hipError_t launch_synth_fill(float *data, uint32_t n_elems, int channels, uint32
                              hipStream_t stream) {
   hipLaunchKernelGGL(synth_fill_kernel, dim3(grid_for(n_elems)), dim3(kBlock), 0, stream, data, n_elems, channels,
                      seed, depth_channel);
+  return hipGetLastError();
+}
+
+hipError_t launch_checksum(const float *data, size_t n, unsigned long long *out, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(checksum_kernel, dim3(grid_for(n)), dim3(kBlock), 0, stream, reinterpret_cast<const uint32_t *>(data), n,
+                     out);
   return hipGetLastError();
 }
 

@@ -32,6 +32,7 @@ hipError_t launch_post_process(float *data, uint32_t n_pixels, int channels, flo
 hipError_t launch_synth_fill(float *data, uint32_t n_elems, int channels, uint32_t seed, int depth_channel,
                              hipStream_t stream);
 hipError_t launch_math_eval(int func, const float *a, const float *b, float *out, size_t n, hipStream_t stream);
+hipError_t launch_checksum(const float *data, size_t n, unsigned long long *out, hipStream_t stream);
 } // namespace lrp
 
 namespace {
@@ -112,7 +113,6 @@ int validate(const lrp_image *in, const lrp_image *out, int interpolation, bool 
     return fail(LRP_ERR_INTERPOLATION, "Interpolation method not supported.");
   if (in->channels < 1 || in->channels != out->channels)
     return fail(LRP_ERR_CHANNELS, "in->channels must equal out->channels and be >= 1");
-  if (in->channels > 8 && in->channels != 4) return fail(LRP_ERR_CHANNELS, "more than 8 channels not supported");
   if (in->width < 1 || in->height < 1 || out->width < 1 || out->height < 1)
     return fail(LRP_ERR_BAD_DIMS, "image dimensions must be positive");
   const unsigned long long lim = 1ull << 32;
@@ -133,6 +133,7 @@ lrp::KParams make_params(const lrp_image *in, const lrp_image *out, int num_samp
   P.out_w = out->width;
   P.out_h = out->height;
   P.channels = out->channels;
+  P.ch_count = out->channels;
   P.num_samples = num_samples;
   P.normalize = 1.0f / (float)(num_samples * num_samples); // src/reproject.cpp:280
   P.in_lens = pack_lens(in->lens);
@@ -196,6 +197,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
   const int oi = out_lens_index(out->lens.type);
   const int im = in_lens_mode(in->lens);
   hipError_t e;
+  lrp::TableLease lease; // pins the cached tables until every launch of this call is enqueued (scope end)
   const bool tile_channels = out->channels >= 3 && out->channels <= 5;
   bool mirror = false; // the output-lens tables are symmetric about the image centre
   bool tile = kernel_choice() != 0 && tile_channels && in->width <= 65535 && in->height <= 32767 &&
@@ -204,8 +206,8 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     // separable output-lens terms (cached per device / lens / size / num_samples)
     const int out_kind = out->lens.type == LRP_RECTILINEAR ? lrp::kRect : lrp::kEquirect;
     bool plain = false;
-    e = lrp::get_output_tables(device, out_kind, P.out_lens, out->width, out->height, num_samples, &P.col_tab,
-                               &P.row_tab, &plain, &mirror);
+    e = lrp::get_output_tables(device, out_kind, P.out_lens, out->width, out->height, num_samples, stream, lease,
+                               &P.col_tab, &P.row_tab, &plain, &mirror);
     if (e == hipErrorOutOfMemory) {
       (void)hipGetLastError();
       tile = false; // no memory for the tables: per-pixel kernel
@@ -220,7 +222,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
       const bool rows_free = !P.has_rot || (P.rot[1] == 0.0f && P.rot[7] == 0.0f);
       if (xsep_enabled() && rows_free && im != lrp::kInEquidistant)
         P.xsep_tab = lrp::get_xsep_table(device, P.col_tab, out_kind, out->width, num_samples, P.in_lens, im, in->width,
-                                         P.in_lon_span, P.has_rot ? P.rot : nullptr);
+                                         P.in_lon_span, P.has_rot ? P.rot : nullptr, stream, lease);
     }
   }
   if (tile) {
@@ -264,16 +266,23 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
   } else {
     const int n = n_batch > 0 ? n_batch : 1;
     e = hipSuccess;
-    for (int i = 0; i < n && e == hipSuccess; ++i) {
-      P.src = in[i].data;
-      P.dst = out[i].data;
-      if (interpolation == LRP_NEAREST)
-        e = lrp::launch_nearest(P, oi, im, stream);
-      else if (interpolation == LRP_BILINEAR)
-        e = lrp::launch_bilinear(P, oi, im, stream);
-      else
-        e = lrp::launch_bicubic(P, oi, im, stream);
-    }
+    // The run-time channel path holds up to 8 channels of a pixel in registers; wider texels (the
+    // reference loop is generic in C, src/reproject.cpp:50,76,134) are rendered 8 channels per launch.
+    // post_process touches channels 0-2 only (:423-434): they are all in the first group.
+    const int C = out->channels, group = C == 4 ? 4 : 8;
+    for (int i = 0; i < n && e == hipSuccess; ++i)
+      for (int c0 = 0; c0 < C && e == hipSuccess; c0 += group) {
+        P.src = in[i].data + c0;
+        P.dst = out[i].data + c0;
+        P.ch_count = std::min(group, C - c0);
+        P.has_post = post != nullptr && c0 == 0;
+        if (interpolation == LRP_NEAREST)
+          e = lrp::launch_nearest(P, oi, im, stream);
+        else if (interpolation == LRP_BILINEAR)
+          e = lrp::launch_bilinear(P, oi, im, stream);
+        else
+          e = lrp::launch_bicubic(P, oi, im, stream);
+      }
   }
   if (e != hipSuccess) return hip_fail(e, "reproject kernel launch");
   return LRP_OK;
@@ -589,6 +598,16 @@ int lrp_synth_fill_device(float *data, int width, int height, int channels, uint
   if (st != LRP_OK) return st;
   hipError_t e = lrp::launch_synth_fill(data, (uint32_t)n, channels, seed, depth_channel, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "synth_fill kernel launch");
+  return LRP_OK;
+}
+
+int lrp_checksum_device(const float *data, size_t n, uint64_t *out, int device, void *stream) {
+  if (!data || !out) return fail(LRP_ERR_NULL, "null array");
+  if (n >= (1ull << 32)) return fail(LRP_ERR_BAD_DIMS, "buffer too large");
+  int st = select_device(device);
+  if (st != LRP_OK) return st;
+  hipError_t e = lrp::launch_checksum(data, n, reinterpret_cast<unsigned long long *>(out), (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "checksum kernel launch");
   return LRP_OK;
 }
 

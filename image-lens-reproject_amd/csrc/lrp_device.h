@@ -214,7 +214,7 @@ __device__ __forceinline__ Texel<CH> sample_nearest(const KParams &P, float sx, 
   const int lx = column<Loop>(trunc_x86(sx + 0.5f), P.in_w);
   const int ly = clamp_index(trunc_x86(sy + 0.5f), P.in_h - 1);
   const uint32_t off = ((uint32_t)ly * (uint32_t)P.in_w + (uint32_t)lx) * (uint32_t)P.channels;
-  return load_texel<CH>(P.src, off, P.channels);
+  return load_texel<CH>(P.src, off, P.ch_count);
 }
 
 // sample_bilinear, src/reproject.cpp:55-90
@@ -230,10 +230,10 @@ __device__ __forceinline__ Texel<CH> sample_bilinear(const KParams &P, float sx,
   const float cfx = 1.0f - fx;
   const float cfy = 1.0f - fy;
   const uint32_t row_l = (uint32_t)ly * (uint32_t)w, row_u = (uint32_t)uy * (uint32_t)w;
-  const Texel<CH> ll = load_texel<CH>(P.src, (row_l + lx) * C, C);
-  const Texel<CH> lu = load_texel<CH>(P.src, (row_l + ux) * C, C);
-  const Texel<CH> ul = load_texel<CH>(P.src, (row_u + lx) * C, C);
-  const Texel<CH> uu = load_texel<CH>(P.src, (row_u + ux) * C, C);
+  const Texel<CH> ll = load_texel<CH>(P.src, (row_l + lx) * C, P.ch_count);
+  const Texel<CH> lu = load_texel<CH>(P.src, (row_l + ux) * C, P.ch_count);
+  const Texel<CH> ul = load_texel<CH>(P.src, (row_u + lx) * C, P.ch_count);
+  const Texel<CH> uu = load_texel<CH>(P.src, (row_u + ux) * C, P.ch_count);
   Texel<CH> r;
 #pragma unroll
   for (int c = 0; c < texel_lanes<CH>(); ++c) {
@@ -267,10 +267,10 @@ __device__ __forceinline__ Texel<CH> sample_bicubic(const KParams &P, float sx, 
   Texel<CH> col[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const Texel<CH> p0 = load_texel<CH>(P.src, (rows[0] + xs[i]) * C, C);
-    const Texel<CH> p1 = load_texel<CH>(P.src, (rows[1] + xs[i]) * C, C);
-    const Texel<CH> p2 = load_texel<CH>(P.src, (rows[2] + xs[i]) * C, C);
-    const Texel<CH> p3 = load_texel<CH>(P.src, (rows[3] + xs[i]) * C, C);
+    const Texel<CH> p0 = load_texel<CH>(P.src, (rows[0] + xs[i]) * C, P.ch_count);
+    const Texel<CH> p1 = load_texel<CH>(P.src, (rows[1] + xs[i]) * C, P.ch_count);
+    const Texel<CH> p2 = load_texel<CH>(P.src, (rows[2] + xs[i]) * C, P.ch_count);
+    const Texel<CH> p3 = load_texel<CH>(P.src, (rows[3] + xs[i]) * C, P.ch_count);
 #pragma unroll
     for (int c = 0; c < texel_lanes<CH>(); ++c)
       col[i].v[c] = catmull_rom(p0.v[c], p1.v[c], p2.v[c], p3.v[c], fy, hfy);

@@ -63,10 +63,10 @@ __global__ __launch_bounds__(kThreads) void reproject_kernel(const KParams P) {
     // fused post_process: first min(C,3) channels (src/reproject.cpp:423-434)
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-      if (c < texel_lanes<CH>() && c < P.channels) acc.v[c] = tonemap(acc.v[c], P.exposure, P.reinhard);
+      if (c < texel_lanes<CH>() && c < P.ch_count) acc.v[c] = tonemap(acc.v[c], P.exposure, P.reinhard);
   }
   const uint32_t off = ((uint32_t)y * (uint32_t)P.out_w + (uint32_t)x) * (uint32_t)P.channels;
-  store_texel<CH>(P.dst, off, acc, P.channels);
+  store_texel<CH>(P.dst, off, acc, P.ch_count);
 }
 
 using KernelFn = void (*)(const KParams);

@@ -26,7 +26,8 @@ struct KParams {
   float *dst;
   int32_t in_w, in_h;
   int32_t out_w, out_h;
-  int32_t channels;
+  int32_t channels;    // floats per texel (the stride)
+  int32_t ch_count;    // pixel kernel, run-time channel path: channels rendered by this launch (<= 8; src / dst point at the first)
   int32_t num_samples;
   float normalize;     // 1.0f / (num_samples * num_samples), src/reproject.cpp:280
   LensP in_lens;

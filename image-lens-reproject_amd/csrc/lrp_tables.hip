@@ -23,7 +23,9 @@
 // pixel is left with the vertical half of the projection.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -155,13 +157,16 @@ struct Entry {
   int device;
   TableArgs key; // tab = device pointer of the finished tables
   int flags;     // as left by build_tables_kernel
+  std::atomic<int> pins{0}; // leases handed out and not yet released (see TableLease)
 };
 
 struct XsepEntry {
   int device;
   XsepArgs key;  // tab = device pointer of the finished table (null: the rotation does not separate)
+  std::atomic<int> pins{0};
 };
-std::vector<XsepEntry> g_xsep;
+// unique_ptr: a lease holds the address of an entry's pin counter across vector growth
+std::vector<std::unique_ptr<XsepEntry>> g_xsep;
 
 bool same_xsep(const XsepArgs &a, const XsepArgs &b) {
   return a.col_tab == b.col_tab && a.out_lens == b.out_lens && a.n == b.n && a.in_mode == b.in_mode && a.in_w == b.in_w &&
@@ -171,36 +176,63 @@ bool same_xsep(const XsepArgs &a, const XsepArgs &b) {
 }
 
 std::mutex g_mutex;
-std::vector<Entry> g_entries;
+std::vector<std::unique_ptr<Entry>> g_entries;
 constexpr size_t kMaxEntries = 256;
 
-// Cache full: wait for the devices' work (kernels in flight may still read the tables), then
-// drop the older half of the output tables together with the column tables built on them.
-// A table build blocks the calling thread anyway; a process that keeps producing new output
-// geometries pays one device synchronisation per 128 of them.  (hipGraphs captured earlier
-// keep pointing at freed tables — same contract as lrp_release_cached_tables.)
+// Table lifetime.  A lookup pins the entry it returns (under g_mutex); the caller releases the
+// pin once the kernel that reads the table has been ENQUEUED (TableLease, lrp_tables.h).
+// Eviction — under g_mutex, so no new pin can appear meanwhile — only considers entries
+// whose pin count is zero: every launch that ever used such an entry is already in some
+// stream's queue, and the device synchronisation that precedes the hipFree waits for it.
+// A pinned entry (a launch is about to be enqueued by another thread) is never freed.
+// A pinned column table implies a pinned output table: both pins belong to one lease.
+// (hipGraphs captured earlier keep pointing at freed tables — same contract as
+// lrp_release_cached_tables.)
+void sync_device(int device) {
+  (void)hipSetDevice(device);
+  (void)hipDeviceSynchronize();
+}
+
+void drop_xsep_where(const std::vector<const float *> *parents, size_t max_drop) { // g_mutex held
+  size_t dropped = 0;
+  for (size_t i = 0; i < g_xsep.size() && dropped < max_drop;) {
+    XsepEntry &x = *g_xsep[i];
+    bool match = parents == nullptr;
+    if (parents)
+      for (const float *t : *parents) match = match || x.key.col_tab == t;
+    if (match && x.pins.load(std::memory_order_acquire) == 0) {
+      if (x.key.tab) {
+        sync_device(x.device);
+        (void)hipFree(x.key.tab);
+      }
+      g_xsep.erase(g_xsep.begin() + (long)i);
+      ++dropped;
+    } else {
+      ++i;
+    }
+  }
+}
+
+// Cache full: drop the older half of the (unpinned) output tables together with the column
+// tables built on them.  A table build blocks the calling thread anyway; a process that keeps
+// producing new output geometries pays one device synchronisation per 128 of them.
 void evict_older_half() { // g_mutex held
   int cur = 0;
   (void)hipGetDevice(&cur);
   const size_t n_drop = g_entries.size() / 2;
   std::vector<const float *> dropped;
-  for (size_t i = 0; i < n_drop; ++i) {
-    (void)hipSetDevice(g_entries[i].device);
-    (void)hipDeviceSynchronize();
-    dropped.push_back(g_entries[i].key.tab);
-    (void)hipFree(g_entries[i].key.tab);
-  }
-  g_entries.erase(g_entries.begin(), g_entries.begin() + (long)n_drop);
-  for (size_t i = 0; i < g_xsep.size();) {
+  for (size_t i = 0; i < g_entries.size() && dropped.size() < n_drop; ++i)
+    if (g_entries[i]->pins.load(std::memory_order_acquire) == 0) dropped.push_back(g_entries[i]->key.tab);
+  // column tables first (they were built from, and are keyed on, the output tables)
+  drop_xsep_where(&dropped, g_xsep.size());
+  for (size_t i = 0; i < g_entries.size();) {
+    Entry &en = *g_entries[i];
     bool gone = false;
-    for (const float *t : dropped) gone = gone || g_xsep[i].key.col_tab == t;
+    for (const float *t : dropped) gone = gone || en.key.tab == t;
     if (gone) {
-      if (g_xsep[i].key.tab) {
-        (void)hipSetDevice(g_xsep[i].device);
-        (void)hipDeviceSynchronize();
-        (void)hipFree(g_xsep[i].key.tab);
-      }
-      g_xsep.erase(g_xsep.begin() + (long)i);
+      sync_device(en.device);
+      (void)hipFree(en.key.tab);
+      g_entries.erase(g_entries.begin() + (long)i);
     } else {
       ++i;
     }
@@ -211,14 +243,7 @@ void evict_older_half() { // g_mutex held
 void evict_older_xsep_half() { // g_mutex held
   int cur = 0;
   (void)hipGetDevice(&cur);
-  const size_t n_drop = g_xsep.size() / 2;
-  for (size_t i = 0; i < n_drop; ++i)
-    if (g_xsep[i].key.tab) {
-      (void)hipSetDevice(g_xsep[i].device);
-      (void)hipDeviceSynchronize();
-      (void)hipFree(g_xsep[i].key.tab);
-    }
-  g_xsep.erase(g_xsep.begin(), g_xsep.begin() + (long)n_drop);
+  drop_xsep_where(nullptr, g_xsep.size() / 2);
   (void)hipSetDevice(cur);
 }
 
@@ -227,10 +252,24 @@ bool same_key(const TableArgs &a, const TableArgs &b) { // tab / flags are resul
          std::memcmp(&a.lens, &b.lens, sizeof(LensP)) == 0;
 }
 
+// The build runs on the caller's stream (no implicit synchronisation with other streams of the
+// device through the legacy default stream); the host waits for the flag word, i.e. once per new
+// output-lens configuration.  Do this before capturing a hipGraph.
+hipError_t read_flag(const int *d_flag, int *flag, hipStream_t stream) {
+  hipError_t e = hipMemcpyAsync(flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  return e;
+}
+
 } // namespace
 
-hipError_t get_output_tables(int device, int out_lens, const LensP &lens, int out_w, int out_h, int ns,
-                             const float **col_tab, const float **row_tab, bool *plain, bool *mirror) {
+void TableLease::release() {
+  for (int i = 0; i < n; ++i) pins[i]->fetch_sub(1, std::memory_order_release);
+  n = 0;
+}
+
+hipError_t get_output_tables(int device, int out_lens, const LensP &lens, int out_w, int out_h, int ns, hipStream_t stream,
+                             TableLease &lease, const float **col_tab, const float **row_tab, bool *plain, bool *mirror) {
   *col_tab = *row_tab = nullptr;
   *plain = *mirror = false;
   TableArgs want;
@@ -242,44 +281,45 @@ hipError_t get_output_tables(int device, int out_lens, const LensP &lens, int ou
   want.ns = ns;
   const size_t n_col = (size_t)out_w * ns, n_row = (size_t)out_h * ns;
   std::lock_guard<std::mutex> lock(g_mutex);
-  for (const Entry &e : g_entries)
-    if (e.device == device && same_key(e.key, want)) {
-      *col_tab = e.key.tab;
-      *row_tab = e.key.tab + 2 * n_col;
-      *plain = !(e.flags & 1);
-      *mirror = ns == 1 && !(e.flags & 6);
+  auto hand_out = [&](Entry &e) {
+    e.pins.fetch_add(1, std::memory_order_acq_rel);
+    lease.pins[lease.n++] = &e.pins;
+    *col_tab = e.key.tab;
+    *row_tab = e.key.tab + 2 * n_col;
+    *plain = !(e.flags & 1);
+    *mirror = ns == 1 && !(e.flags & 6);
+  };
+  for (const auto &e : g_entries)
+    if (e->device == device && same_key(e->key, want)) {
+      hand_out(*e);
       return hipSuccess;
     }
   if (g_entries.size() >= kMaxEntries) evict_older_half();
-  // Miss: build synchronously on the legacy default stream (host blocks once per
-  // new output-lens configuration; do this before capturing a hipGraph).
   float *tab = nullptr;
   hipError_t e = hipMalloc(&tab, (2 * n_col + n_row + 1) * sizeof(float)); // + one flag word
   if (e != hipSuccess) return e;
   want.tab = tab;
   want.flags = reinterpret_cast<int *>(tab + 2 * n_col + n_row);
   int flag = 7;
-  e = hipMemsetAsync(want.flags, 0, sizeof(int), 0);
+  e = hipMemsetAsync(want.flags, 0, sizeof(int), stream);
   const unsigned blocks = (unsigned)((n_col + n_row + 255) / 256);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(build_tables_kernel, dim3(blocks), dim3(256), 0, 0, want);
+    hipLaunchKernelGGL(build_tables_kernel, dim3(blocks), dim3(256), 0, stream, want);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpy(&flag, want.flags, sizeof(int), hipMemcpyDeviceToHost); // also waits for the build
+  if (e == hipSuccess) e = read_flag(want.flags, &flag, stream); // also waits for the build
   if (e != hipSuccess) {
     (void)hipFree(tab);
     return e;
   }
-  g_entries.push_back(Entry{device, want, flag});
-  *col_tab = tab;
-  *row_tab = tab + 2 * n_col;
-  *plain = !(flag & 1);
-  *mirror = ns == 1 && !(flag & 6);
+  g_entries.emplace_back(new Entry{device, want, flag});
+  hand_out(*g_entries.back());
   return hipSuccess;
 }
 
 const float *get_xsep_table(int device, const float *col_tab, int out_lens, int out_w, int ns, const LensP &in_lens,
-                            int in_mode, int in_w, float in_lon_span, const float *rot) {
+                            int in_mode, int in_w, float in_lon_span, const float *rot, hipStream_t stream,
+                            TableLease &lease) {
   XsepArgs want;
   std::memset(&want, 0, sizeof(want));
   want.col_tab = col_tab;
@@ -295,8 +335,14 @@ const float *get_xsep_table(int device, const float *col_tab, int out_lens, int 
     std::memcpy(want.rz, rot + 6, sizeof(want.rz));
   }
   std::lock_guard<std::mutex> lock(g_mutex);
-  for (const XsepEntry &e : g_xsep)
-    if (e.device == device && same_xsep(e.key, want)) return e.key.tab;
+  auto hand_out = [&](XsepEntry &e) -> const float * {
+    if (!e.key.tab) return nullptr; // "does not separate": nothing to keep alive
+    e.pins.fetch_add(1, std::memory_order_acq_rel);
+    lease.pins[lease.n++] = &e.pins;
+    return e.key.tab;
+  };
+  for (const auto &e : g_xsep)
+    if (e->device == device && same_xsep(e->key, want)) return hand_out(*e);
   if (g_xsep.size() >= kMaxEntries) evict_older_xsep_half();
   float *tab = nullptr;
   if (hipMalloc(&tab, (3 * (size_t)want.n + 1) * sizeof(float)) != hipSuccess) {
@@ -306,12 +352,12 @@ const float *get_xsep_table(int device, const float *col_tab, int out_lens, int 
   want.tab = tab;
   want.flags = reinterpret_cast<int *>(tab + 3 * (size_t)want.n);
   int flag = 1;
-  hipError_t e = hipMemsetAsync(want.flags, 0, sizeof(int), 0);
+  hipError_t e = hipMemsetAsync(want.flags, 0, sizeof(int), stream);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(build_xsep_kernel, dim3((unsigned)((want.n + 255) / 256)), dim3(256), 0, 0, want);
+    hipLaunchKernelGGL(build_xsep_kernel, dim3((unsigned)((want.n + 255) / 256)), dim3(256), 0, stream, want);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpy(&flag, want.flags, sizeof(int), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = read_flag(want.flags, &flag, stream);
   if (e != hipSuccess || flag != 0) { // failed, or the sign of vy matters in some column: remember "does not separate"
     (void)hipGetLastError();
     (void)hipFree(tab);
@@ -319,26 +365,29 @@ const float *get_xsep_table(int device, const float *col_tab, int out_lens, int 
     want.flags = nullptr;
     if (e != hipSuccess) return nullptr;
   }
-  g_xsep.push_back(XsepEntry{device, want});
-  return want.tab;
+  g_xsep.emplace_back(new XsepEntry{device, want});
+  return hand_out(*g_xsep.back());
 }
 
+// Frees every table no lease pins (callers: tests, shutdown paths; not concurrently with launches
+// that are being enqueued — those keep their tables, which stay cached).
 void release_output_tables() {
   std::lock_guard<std::mutex> lock(g_mutex);
   int cur = 0;
   (void)hipGetDevice(&cur);
-  for (const XsepEntry &e : g_xsep) {
-    (void)hipSetDevice(e.device);
-    (void)hipDeviceSynchronize();
-    if (e.key.tab) (void)hipFree(e.key.tab);
+  drop_xsep_where(nullptr, g_xsep.size());
+  for (size_t i = 0; i < g_entries.size();) {
+    Entry &en = *g_entries[i];
+    bool child = false;
+    for (const auto &x : g_xsep) child = child || x->key.col_tab == en.key.tab;
+    if (en.pins.load(std::memory_order_acquire) == 0 && !child) {
+      sync_device(en.device);
+      (void)hipFree(en.key.tab);
+      g_entries.erase(g_entries.begin() + (long)i);
+    } else {
+      ++i;
+    }
   }
-  g_xsep.clear();
-  for (const Entry &e : g_entries) {
-    (void)hipSetDevice(e.device);
-    (void)hipDeviceSynchronize();
-    (void)hipFree(e.key.tab);
-  }
-  g_entries.clear();
   (void)hipSetDevice(cur);
 }
 

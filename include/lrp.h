@@ -190,6 +190,13 @@ int lrp_context_wait(lrp_context *ctx);
 int lrp_synth_fill_device(float *data, int width, int height, int channels, uint32_t seed,
                           int depth_channel, int device, void *stream);
 
+/* Order-independent 64-bit checksum of the bit patterns of n floats on the device, written to
+ * the device word *out (asynchronous on `stream`): sum mod 2^64 of h(bits[i], i) with
+ * h = mix32(bits ^ 0xA5A5A5A5, 2 i + 0x7F4A7C15) << 32 | mix32(bits, i), mix32 as in the
+ * synthetic generator.  bench.py and the multi-GPU tests compare per-image values between
+ * 1-rank and N-rank runs without moving the images. */
+int lrp_checksum_device(const float *data, size_t n, uint64_t *out, int device, void *stream);
+
 /* Evaluate the device math routines on device arrays (lets tests prove the
  * device build of the math matches the host libm): func 0 sinf, 1 cosf,
  * 2 sincosf.sin, 3 sincosf.cos, 4 atanf, 5 asinf, 6 atan2f(a, b), 7 a / b,

@@ -2,7 +2,8 @@
 // usage: binding_driver <case>
 //   out_lens | in_lens | interp : unsupported dispatch -> reference message + exit(1)
 //   nodevice : a valid call; without a GPU the binding must throw (no CPU fallback)
-//   run      : a valid call on the GPU; prints a checksum of the output
+//   run [file] : a valid call on the GPU; writes the raw output floats to `file` (the test compares
+//                every bit with the oracle) and prints a checksum
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -42,6 +43,14 @@ int main(int argc, char **argv) {
   } catch (const std::exception &e) { // the reference worker's catch (src/main.cpp:617-619)
     std::printf("Error: %s\n", e.what());
     return 3;
+  }
+  if (argc > 2) {
+    std::FILE *f = std::fopen(argv[2], "wb");
+    if (!f || std::fwrite(dst.data(), sizeof(float), dst.size(), f) != dst.size()) {
+      std::printf("Error: cannot write %s\n", argv[2]);
+      return 4;
+    }
+    std::fclose(f);
   }
   double sum = 0;
   for (float v : dst) sum += v;

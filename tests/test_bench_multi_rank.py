@@ -1,0 +1,96 @@
+"""The N > 1 path of bench.py itself ("multi-GPU evidence is hollow").
+
+bench.py shards ONE sorted list of images in static contiguous blocks over the ranks
+(image-lens-reproject_amd/sharding.py — the reference's one-file-per-pool-thread split,
+src/main.cpp:538-544,624-655) with no collective on the data path and reports per-image
+checksums.  -m gpu: the same 24-image batch rendered by 1 rank and by 2 ranks (two fresh
+child processes started by torch.distributed.run, gloo for the barrier / timing reduce so
+that both may share one GPU) must give identical per-image checksums, and they must be the
+oracle's.  CPU: launcher argument checks."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+SIZE, BATCH = 512, 24
+
+
+def run_bench(n, tmp_path, extra=()):
+    out = tmp_path / f"sums_{n}.json"
+    args = ["--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", str(BATCH), "--size", str(SIZE),
+            "--no-cpu-baseline", "--secondary", "", "--dist-backend", "gloo", "--checksums-file", str(out), *extra]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    # N > 1: bench.py starts torch.distributed.run itself (as a child, before touching the GPU)
+    r = subprocess.run([sys.executable, BENCH, *args], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line), json.load(open(out))
+
+
+@pytest.mark.gpu
+def test_one_rank_and_two_ranks_render_identical_images(lrp, oracle, torch_cuda, tmp_path):
+    one, sums1 = run_bench(1, tmp_path)
+    two, sums2 = run_bench(2, tmp_path)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert one["scaling"] == two["scaling"] == "strong"
+    assert one["config"]["images_per_gpu_per_step"] == BATCH and two["config"]["images_per_gpu_per_step"] == BATCH // 2
+    assert len(sums1["checksums"]) == len(sums2["checksums"]) == BATCH
+    assert sums1["checksums"] == sums2["checksums"]
+    assert one["outputs_digest"] == two["outputs_digest"] is not None
+    # ... and they are the oracle's images (first, one from the second rank's block, last)
+    import bench
+
+    wl = bench.WORKLOADS["fisheye_to_rect_bicubic"]
+    lin, lout = bench.make_lens(lrp, wl["in_lens"], SIZE, SIZE), bench.make_lens(lrp, wl["out_lens"], SIZE, SIZE)
+    for i in (0, BATCH // 2 + 1, BATCH - 1):
+        src = oracle.synth_frame(SIZE, SIZE, 4, 0x5EED0000 + i)
+        want = oracle.reproject(lin, src, lout, SIZE, SIZE, 1, wl["interp"], None)
+        assert f"{lrp.checksum_host(want):016x}" == sums2["checksums"][i], f"image {i}"
+    for rec in (one, two):
+        assert rec["roofline"]["frac"] > 0 and rec["roofline"]["single_launch_us"] > 0
+        assert 0 < rec["roofline"]["frac_read_only"] < rec["roofline"]["frac"]
+
+
+@pytest.mark.gpu
+def test_weak_scaling_mode_and_uneven_shards(lrp, torch_cuda, tmp_path):
+    """--scaling weak: every rank renders its own --batch images; strong with a batch that does not
+    divide: ceil blocks (13 + 12)."""
+    rec, sums = run_bench(2, tmp_path, extra=("--scaling", "weak"))
+    assert rec["scaling"] == "weak" and rec["config"]["images_per_step"] == 2 * BATCH
+    assert len(sums["checksums"]) == 2 * BATCH
+    odd, sums_odd = run_bench(2, tmp_path, extra=("--batch", "25"))
+    assert len(sums_odd["checksums"]) == 25 and sums_odd["checksums"][:BATCH] == sums["checksums"][:BATCH]
+
+
+def test_gpus_flag_must_match_the_launcher():
+    """`--gpus 2` inside a 1-rank launch is an error with the torchrun command line, not a silent 1-GPU run."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode != 0
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node 2" in r.stderr
+
+
+def test_checksum_host_matches_its_definition(lrp):
+    a = np.array([0.0, -0.0, 1.5, np.nan], dtype=np.float32)
+    bits = a.view(np.uint32)
+
+    def mix32(seed, index):
+        h = (index * 0x9E3779B9 + seed) & 0xFFFFFFFF
+        h ^= h >> 16
+        h = (h * 0x7FEB352D) & 0xFFFFFFFF
+        h ^= h >> 15
+        h = (h * 0x846CA68B) & 0xFFFFFFFF
+        h ^= h >> 16
+        return h
+
+    want = 0
+    for i, b in enumerate(int(v) for v in bits):
+        want += (mix32(b ^ 0xA5A5A5A5, (2 * i + 0x7F4A7C15) & 0xFFFFFFFF) << 32) | mix32(b, i)
+    assert lrp.checksum_host(a) == want & 0xFFFFFFFFFFFFFFFF

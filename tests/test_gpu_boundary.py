@@ -144,3 +144,62 @@ def test_batched_launch_rejects_mixed_geometries(lrp, torch_cuda):
         lrp.reproject_batch([lrp.Image(L.equirectangular(), 64, 64, 4, a), lrp.Image(L.equirectangular(), 48, 64, 4, b)],
                             [lrp.Image(L.rectilinear(18.0, 36.0, 32, 32), 32, 32, 4, o1),
                              lrp.Image(L.rectilinear(18.0, 36.0, 32, 32), 32, 32, 4, o2)], 1, 2, None)
+
+
+@pytest.mark.parametrize("channels,interp,ns", [(9, 2, 1), (12, 1, 2), (17, 0, 1), (16, 2, 1)])
+def test_wide_texels_are_rendered_in_channel_groups(lrp, oracle, torch_cuda, channels, interp, ns):
+    """The reference loop is generic in the channel count (src/reproject.cpp:50,76,134); texels wider
+    than 8 floats go through the per-pixel kernel 8 channels per launch, with the fused post_process
+    on channels 0-2 only."""
+    torch = torch_cuda
+    in_w, in_h, out_w, out_h = 97, 61, 83, 59
+    lin = cases.lenses(lrp, in_w, in_h)["eqr_full"]
+    lout = cases.lenses(lrp, out_w, out_h)["rect"]
+    rot = cases.rotation(lrp, (30.0, -15.0, 5.0))
+    src = cases.hash_noise(in_h, in_w, channels, seed=40 + channels)
+    want = oracle.reproject(lin, src, lout, out_w, out_h, ns, interp, rot)
+    oracle.post_process(want, 2.0, 4.0)
+    d_in = torch.from_numpy(src).cuda()
+    d_out = torch.full((out_h, out_w, channels), -1.0, dtype=torch.float32, device="cuda")
+    lrp.reproject(lrp.Image(lin, in_w, in_h, channels, d_in), lrp.Image(lout, out_w, out_h, channels, d_out), ns, interp,
+                  rot, post=(2.0, 4.0))
+    torch.cuda.synchronize()
+    cases.assert_same_bits(d_out.cpu().numpy(), want, f"C={channels}")
+
+
+def test_table_cache_eviction_while_other_threads_launch(lrp, oracle, torch_cuda):
+    """More output geometries than the 256-entry table cache holds, from 4 threads at once: an entry
+    handed to a caller is pinned until its kernel is enqueued and eviction synchronises the device
+    before it frees unpinned entries, so no launch ever reads a freed (or re-used) table."""
+    torch = torch_cuda
+    in_w, in_h = 64, 48
+    lin = cases.lenses(lrp, in_w, in_h)["eqr_full"]
+    src = cases.hash_noise(in_h, in_w, 4, seed=11)
+    d_in = torch.from_numpy(src).cuda()
+    errors = []
+
+    def worker(t):
+        try:
+            stream = torch.cuda.Stream()
+            for i in range(110):
+                out_w, out_h = 24 + (i % 7), 16 + (i % 5)
+                # a distinct output lens per (thread, i): 440 table builds, > 256 cache slots
+                lout = lrp.LensInfo.rectilinear(18.0 + t + 0.01 * i, 36.0, out_w, out_h)
+                rot = cases.rotation(lrp, (90.0, 0.0, 0.0)) if i % 2 else None  # pan only: a column table too
+                with torch.cuda.stream(stream):
+                    d_out = torch.full((out_h, out_w, 4), -1.0, dtype=torch.float32, device="cuda")
+                    lrp.reproject(lrp.Image(lin, in_w, in_h, 4, d_in), lrp.Image(lout, out_w, out_h, 4, d_out), 1, 2, rot)
+                stream.synchronize()
+                if i % 10 == 0:
+                    cases.assert_same_bits(d_out.cpu().numpy(), oracle.reproject(lin, src, lout, out_w, out_h, 1, 2, rot),
+                                           f"thread {t} geometry {i}")
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    lrp._native.load().lrp_release_cached_tables()
+    assert not errors, errors[0]

@@ -176,3 +176,26 @@ def test_batch_context_full_size_equals_single_calls(lrp, torch_cuda):
         ctx.wait()
     for i, (o, s) in enumerate(zip(outs, singles)):
         cases.assert_same_bits(o, s, f"batch frame {i}")
+
+
+@pytest.mark.parametrize("in_kind,deg", [("eqd180", None), ("eqr_full", (0.0, 0.0, 0.0))])
+def test_bench_launch_shape_16_frames_of_4k_against_oracle(lrp, oracle, torch_cuda, in_kind, deg):
+    """Exactly the launch bench.py times: lrp_reproject_batch_device with 16 distinct 4096^2 RGBA frames
+    (blockIdx.y = frame), bicubic, fisheye -> rect (configs[1]) and equirect -> rect (north_star).
+    Three frames of the batch (first, middle, last) are checked on sampled rows against the oracle;
+    every frame must equal the same frame rendered by a single-frame launch."""
+    torch = torch_cuda
+    n, nb = 4096, 16
+    lin, lout = cases.lenses(lrp, n, n)[in_kind], cases.lenses(lrp, n, n)["rect"]
+    rot = cases.rotation(lrp, deg)
+    srcs = [gpu_frame(lrp, torch, n, n, 4, 0x5EED0000 + i) for i in range(nb)]
+    dsts = [torch.full((n, n, 4), -7.0, dtype=torch.float32, device="cuda") for _ in range(nb)]
+    lrp.reproject_batch([lrp.Image(lin, n, n, 4, s) for s in srcs], [lrp.Image(lout, n, n, 4, d) for d in dsts], 1, BICUBIC,
+                        rot)
+    torch.cuda.synchronize()
+    for i in (0, 7, 15):
+        check_rows(oracle, lin, srcs[i].cpu().numpy(), lout, n, n, 1, BICUBIC, rot, dsts[i], f"batched frame {i}", n=4)
+    for i in range(nb):
+        single = render(lrp, torch, lin, srcs[i], lout, n, n, 1, BICUBIC, rot)
+        assert same_bytes(torch, single, dsts[i]), f"frame {i}: batched launch differs from the single-frame launch"
+        del single
