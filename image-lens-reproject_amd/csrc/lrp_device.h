@@ -36,7 +36,12 @@ __device__ __forceinline__ int wrap_index(int i, int w) {
   if ((unsigned)t < (unsigned)w) return t;
   int t2 = t - w;
   if ((unsigned)t2 < (unsigned)w) return t2;
-  int r = t % w;
+  // rare (coordinates beyond one image width outside the frame).  The divisor is made opaque so that the
+  // reciprocal the division expands to is computed here, not hoisted into a VGPR that then lives — and
+  // spills — across the whole kernel.
+  int wv = w;
+  asm volatile("" : "+v"(wv));
+  int r = t % wv;
   return (r < 0) ? 0 : r;
 }
 

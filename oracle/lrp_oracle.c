@@ -249,7 +249,7 @@ static void source_position(const lrpo_image *in, const lrpo_image *out, const f
   *sy = (py - 0.5f) + in->height * 0.5f;
 }
 
-#define LRPO_MAX_STACK_CHANNELS 16
+#define LRPO_MAX_STACK_CHANNELS 64 /* the reference allocates 2 * C floats (src/reproject.cpp:281) */
 
 int lrpo_reproject_rows(const lrpo_image *in, lrpo_image *out, int num_samples, int interpolation,
                         const float *rotation, int y_begin, int y_end) {
