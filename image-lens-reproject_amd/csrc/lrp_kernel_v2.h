@@ -881,12 +881,27 @@ __device__ unsigned g_tier_stats[4];
 struct WinBlock {
   float sx[4], sy[4];
   int x_lo, y_lo, bw, bh, pitch; // window origin, size and row pitch in texels (wave-uniform)
-  int spitch, org;               // slot distance from window row r to r + 1 (+-pitch) and slot of window row 0
-  bool staged;                   // taps come from the LDS window (wave-uniform)
+  // slot distance from window row r to r + 1 (+-pitch) and slot of window row 0; without the signed-pitch
+  // knob they are `pitch` and 0 and occupy no SGPRs (the kernel is at the SGPR limit: every wave-uniform
+  // word held across the block loop for `cur` and `nxt` pushes another one into a VGPR lane)
+#if LRP_WIN_SIGNED_PITCH != 0
+  int spitch_, org_;
+  __device__ __forceinline__ int spitch() const { return spitch_; }
+  __device__ __forceinline__ int org() const { return org_; }
+#else
+  __device__ __forceinline__ int spitch() const { return pitch; }
+  __device__ __forceinline__ int org() const { return 0; }
+#endif
+  // Wave-uniform flags are ints, not bools: a bool that crosses the block loop gets materialised
+  // through a VGPR (v_cndmask 0/1 + v_cmp) at every use; an int stays in an SGPR (s_cmp).
+  int staged;                    // taps come from the LDS window
   // coefficient tier (wave-uniform): per half of the block (passes 0-1, 2-3) the first
   // int(sy) and the number of distinct int(sy) rows; a coefficient row has the window's pitch
   int iy0[2], iyn[2], c_plane, c_base; // plane size and first slot of plane 0 (behind the raw window + a margin)
-  bool coef, whole;                    // whole: one set of planes for the block (iy0 / iyn equal for both halves)
+  int coef, whole;                     // whole: one set of planes for the block (iy0 / iyn equal for both halves)
+  // slot of texel (int(sx) - 1, int(sy)) in the raw window = tap_base + int(sy) * spitch + int(sx); the slot of the pixel's
+  // first coefficient vector in plane 0 of half h lies c_delta[h] slots further
+  int tap_base, c_delta[2];
 };
 
 // One wavefront walks its strip of `blocks_per_wave` blocks (plain: top to bottom; mirrored: a
@@ -991,8 +1006,10 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
       if (LRP_WIN_MIN_PITCH > 0 && b.pitch < LRP_WIN_MIN_PITCH &&
           LRP_WIN_MIN_PITCH * (b.bh + kPlanes * (y_last - y_first + 1)) <= kWinCap)
         b.pitch = LRP_WIN_MIN_PITCH;
-      b.spitch = b.pitch;
-      b.org = 0;
+#if LRP_WIN_SIGNED_PITCH != 0
+      b.spitch_ = b.pitch;
+      b.org_ = 0;
+#endif
       if constexpr (LRP_WIN_SIGNED_PITCH != 0) {
         // slant of the block from the two ends of its first row (lanes of columns 0 and 15 of pass row 0)
         constexpr int kLaneC15 = LRP_WIN_LANEMAP != 0 ? 27 : 15;
@@ -1003,11 +1020,13 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
         const bool down = (xb - xa) * (yb - ya) > 0.0f; // the source row grows with the source column
         const bool suits_up = (b.pitch & 15) > 8;
         if (down == suits_up) {
-          b.spitch = -b.pitch;
-          b.org = (b.bh - 1) * b.pitch;
+#if LRP_WIN_SIGNED_PITCH != 0
+          b.spitch_ = -b.pitch;
+          b.org_ = (b.bh - 1) * b.pitch;
+#endif
         }
       }
-      b.staged = b.bw <= 64 && raw_slots(b) <= kWinCap;
+      b.staged = (b.bw <= 64 && raw_slots(b) <= kWinCap) ? 1 : 0;
       // coefficient tier: three planes of pitch x iyn[h] tap-column origins behind the raw window
       b.iy0[0] = ya_first;
       b.iyn[0] = ya_last - ya_first + 1;
@@ -1015,22 +1034,31 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
       b.iyn[1] = yb_last - yb_first + 1;
       // strongly magnified blocks have room for the planes of ALL their origin rows: one
       // precompute per block (fuller lanes: e.g. 132 origins in 3 trips instead of 2 x 77 in 4)
-      b.whole = raw_slots(b) + kPlanes * b.pitch * (y_last - y_first + 1) <= kWinCap;
+      b.whole = (raw_slots(b) + kPlanes * b.pitch * (y_last - y_first + 1) <= kWinCap) ? 1 : 0;
       if (b.whole) {
         b.iy0[0] = b.iy0[1] = y_first;
         b.iyn[0] = b.iyn[1] = y_last - y_first + 1;
       }
       b.c_plane = b.pitch * max(b.iyn[0], b.iyn[1]);
-      b.coef = kWinCoef && P.win_coef != 0 && b.staged && raw_slots(b) + kPlanes * b.c_plane <= kWinCap;
+      b.coef = (kWinCoef && P.win_coef != 0 && b.staged != 0 && raw_slots(b) + kPlanes * b.c_plane <= kWinCap) ? 1 : 0;
       // planes behind the raw window plus, where there is room, one row and one column of slack:
       // the next block's (slightly different) window can then be requested while this block's
       // planes are still being read (see next_window)
       b.c_base = min(raw_slots(b) + b.pitch + b.bh + 1, kWinCap - kPlanes * b.c_plane);
+      b.tap_base = b.org() - b.y_lo * b.spitch() - (1 + b.x_lo);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c_org = b.c_base + (b.spitch() < 0 ? (b.iyn[h] - 1) * b.pitch : 0); // plane slot of the first origin row
+        b.c_delta[h] = c_org - b.iy0[h] * b.spitch() - (1 + b.x_lo) - b.tap_base;
+      }
     }
   };
   auto clear_block = [](WinBlock &b) {
-    b.staged = b.coef = b.whole = false;
-    b.x_lo = b.y_lo = b.bw = b.bh = b.pitch = b.spitch = b.org = b.c_plane = b.c_base = 0;
+    b.staged = b.coef = b.whole = 0;
+#if LRP_WIN_SIGNED_PITCH != 0
+    b.spitch_ = b.org_ = 0;
+#endif
+    b.x_lo = b.y_lo = b.bw = b.bh = b.pitch = b.c_plane = b.c_base = b.tap_base = b.c_delta[0] = b.c_delta[1] = 0;
     b.iy0[0] = b.iy0[1] = b.iyn[0] = b.iyn[1] = 0;
   };
   // One pixel's contribution to the extremes.  Per pixel only the exactness half of interior()
@@ -1168,8 +1196,8 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
       // the reads of the window issued so far have returned before anything overwrites it
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane < b.bw) {
-        uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win + (uint32_t)b.org * 16u;
-        const uint32_t lds_step = (uint32_t)(b.spitch * 16); // dwordx3 too writes one 16-byte slot per lane
+        uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win + (uint32_t)b.org() * 16u;
+        const uint32_t lds_step = (uint32_t)(b.spitch() * 16); // dwordx3 too writes one 16-byte slot per lane
         for (int r = 0; r < b.bh; ++r) {
           if constexpr (CH == 4)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
@@ -1200,14 +1228,14 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
     const int n = b.pitch * b.iyn[h]; // origins: every window column x every first tap row of this half
     // Origins are enumerated over their contiguous slot range from its lowest slot (bottom-up storage
     // puts the LAST origin row there); an origin's four taps are spitch slots apart either way.
-    const float4 *const raw = win0 + (b.org + (b.iy0[h] - 1 - b.y_lo) * b.spitch + (b.spitch < 0 ? (b.iyn[h] - 1) * b.spitch : 0));
+    const float4 *const raw = win0 + (b.org() + (b.iy0[h] - 1 - b.y_lo) * b.spitch() + (b.spitch() < 0 ? (b.iyn[h] - 1) * b.spitch() : 0));
     float4 *const planes = win0 + b.c_base;
     auto load4 = [&](int idx, Rgba t[4]) { // origin idx = row * pitch + column reads the window texels idx + {0, 1, 2, 3} * pitch
       const float4 *q = raw + (idx < n ? idx : n - 1); // (origins in the pad column of an odd pitch compute unused values from stale slots)
       t[0] = as_rgba(q[0]);
-      t[1] = as_rgba(q[b.spitch]);
-      t[2] = as_rgba(q[2 * b.spitch]);
-      t[3] = as_rgba(q[3 * b.spitch]);
+      t[1] = as_rgba(q[b.spitch()]);
+      t[2] = as_rgba(q[2 * b.spitch()]);
+      t[3] = as_rgba(q[3 * b.spitch()]);
     };
     auto emit = [&](int idx, const Rgba t[4]) {
       Rgba inner, m0, cma;
@@ -1286,13 +1314,11 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
           const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
           const float fx = psx - tx_, fy = psy - ty_;
           const float hfx = 0.5f * fx, hfy = 0.5f * fy;
-          const int ix = (int)tx_ - 1 - cur.x_lo, iy = (int)ty_;
-          const int c_org = cur.c_base + (cur.spitch < 0 ? (cur.iyn[h] - 1) * cur.pitch : 0); // plane slot of the first origin row
-          // one 24-bit multiply per pixel (a 32-bit v_mul_lo_u32 issues at quarter rate); the plane
-          // address differs from the window address by a wave-uniform amount
-          const int rowoff = __mul24(iy - cur.y_lo, cur.spitch) + ix;
-          const float4 *tb = win + (cur.org + rowoff);
-          const float4 *ci = win + ((c_org - (cur.iy0[h] - cur.y_lo) * cur.spitch) + rowoff);
+          // one 24-bit multiply per pixel (a 32-bit v_mul_lo_u32 issues at quarter rate); every other term
+          // of the two addresses is wave-uniform and folded into tap_base / c_delta when the block is planned
+          const int tap = __mul24((int)ty_, cur.spitch()) + (int)tx_ + cur.tap_base; // window slot of (int(sx) - 1, int(sy)): the second tap row
+          const float4 *tb = win + tap;
+          const float4 *ci = win + (tap + cur.c_delta[h]);
           const float4 *cm = ci + cur.c_plane, *cc = cm + cur.c_plane;
           // the only reads of the raw window: the second tap row.  In the last pass they are the
           // block's last reads of it, and the next window's DMA goes right behind them
@@ -1315,9 +1341,9 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
         } else if (cur.staged) {
           const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
           const float fx = psx - tx_, fy = psy - ty_;
-          const float4 *t = win + (cur.org + __mul24((int)ty_ - 1 - cur.y_lo, cur.spitch) + ((int)tx_ - 1 - cur.x_lo));
+          const float4 *t = win + (cur.org() + __mul24((int)ty_ - 1 - cur.y_lo, cur.spitch()) + ((int)tx_ - 1 - cur.x_lo));
           const float hfx = 0.5f * fx, hfy = 0.5f * fy;
-          const float4 *t1 = t + cur.spitch, *t2 = t1 + cur.spitch, *t3 = t2 + cur.spitch;
+          const float4 *t1 = t + cur.spitch(), *t2 = t1 + cur.spitch(), *t3 = t2 + cur.spitch();
 #if LRP_ABLATE == 1 // timing experiment: taps loaded, no cubic arithmetic
           Rgba z = as_rgba(t[0]);
           for (int i = 0; i < 4; ++i) {
