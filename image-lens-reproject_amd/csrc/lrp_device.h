@@ -12,6 +12,15 @@
 
 namespace lrp {
 
+// Workgroup -> tile (see kXcdBand in lrp_params.h); false: surplus workgroup.
+__device__ __forceinline__ bool xcd_tile(int tiles_x, int tiles_y, int &tx, int &ty) {
+  const int xcd = (int)(blockIdx.x % kXcds), j = (int)(blockIdx.x / kXcds); // j: index within the XCD
+  const int row = j / tiles_x; // row of tiles among this XCD's
+  tx = j - row * tiles_x;
+  ty = ((row / kXcdBand) * kXcds + xcd) * kXcdBand + row % kXcdBand;
+  return ty < tiles_y;
+}
+
 // ---- scalar semantics inherited from the reference's x86-64 build ---------
 
 // int(float) as cvttss2si executes it: truncation; NaN / inf / out of range

@@ -6,10 +6,10 @@
 // output pixels; each 64-lane wavefront owns two contiguous 32-pixel row
 // segments of it, one pixel per lane, so a wavefront's RGBA stores are two
 // contiguous 512-byte runs and its source taps stay inside a compact window
-// (L1/L2 friendly).  Tiles are numbered in raster order and handed out so that
-// the workgroups the dispatcher places on one XCD (blockIdx % 8 equal) walk a
-// contiguous band of the output: neighbouring tiles share source rows, which
-// then hit in that XCD's private 4 MiB L2.
+// (L1/L2 friendly).  Tiles are handed out so that the workgroups the dispatcher
+// places on one XCD (blockIdx % 8 equal) walk bands of neighbouring tile rows
+// (xcd_tile(), lrp_params.h): neighbouring tiles share source rows, which then
+// hit in that XCD's private 4 MiB L2.
 #pragma once
 
 #include "lrp_device.h"
@@ -23,14 +23,8 @@ constexpr int kThreads = kTileW * kTileH; // 256 = 4 wavefronts
 template <int OutLens, int InMode, int Interp, int CH>
 __global__ __launch_bounds__(kThreads) void reproject_kernel(const KParams P) {
   constexpr bool Loop = (InMode == kInEquirectLoop);
-  // XCD-aware tile numbering: blocks b, b+8, b+16, ... share an XCD and get
-  // consecutive tiles.  chunk = ceil(n_tiles / 8); surplus blocks exit.
-  const int n_tiles = P.tiles_x * P.tiles_y;
-  const int chunk = (n_tiles + kXcds - 1) / kXcds;
-  const int tile = (int)(blockIdx.x % kXcds) * chunk + (int)(blockIdx.x / kXcds);
-  if (tile >= n_tiles) return;
-  const int ty = tile / P.tiles_x;
-  const int tx = tile - ty * P.tiles_x;
+  int tx, ty;
+  if (!xcd_tile(P.tiles_x, P.tiles_y, tx, ty)) return;
   const int x = tx * kTileW + (int)(threadIdx.x % kTileW);
   const int y = P.y_offset + ty * kTileH + (int)(threadIdx.x / kTileW);
   if (x >= P.out_w || y >= P.out_h) return;
@@ -96,8 +90,7 @@ hipError_t launch_interp(KParams P, int out_idx, int in_mode, hipStream_t stream
   P.tiles_y = (rows + kTileH - 1) / kTileH;
   const int n_tiles = P.tiles_x * P.tiles_y;
   if (n_tiles <= 0) return hipSuccess;
-  const int chunk = (n_tiles + kXcds - 1) / kXcds;
-  const dim3 grid((unsigned)(chunk * kXcds)), block(kThreads);
+  const dim3 grid((unsigned)(kXcds * xcd_rows(P.tiles_y) * P.tiles_x)), block(kThreads);
   KernelFn fn = (P.channels == 4) ? KernelTable<Interp, 4>::get(out_idx, in_mode)
                                   : KernelTable<Interp, 0>::get(out_idx, in_mode);
   hipLaunchKernelGGL(fn, grid, block, 0, stream, P);

@@ -7,8 +7,9 @@
 //     contiguous rows Rw .. Rw+R-1, so each of its stores is one contiguous 1 KiB
 //     run (64 lanes x float4) and every per-row quantity is wave-uniform.
 //   * Tiles are numbered so that the workgroups the dispatcher deals to one XCD
-//     (blockIdx % 8 equal) walk a contiguous band of the output: neighbouring
-//     tiles read neighbouring source rows, which then hit in that XCD's 4 MiB L2.
+//     (blockIdx % 8 equal) walk bands of neighbouring tile rows (xcd_tile()): neighbouring
+//     tiles read neighbouring source rows, which then hit in that XCD's 4 MiB L2, and
+//     every XCD gets its share of every part of the frame.
 //
 // Instruction diet (the reference loop is VALU-bound on this chip, not HBM-bound: every
 // packed, SGPR-operand, compare / select / convert / divide-helper instruction costs 4 issue
@@ -655,12 +656,8 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
   constexpr bool Loop = (InMode == kInEquirectLoop);
   const KParams P = batch_frame(Pk);
 
-  const int n_tiles = P.tiles_x * P.tiles_y;
-  const int chunk = (n_tiles + kXcds - 1) / kXcds;
-  const int tile = (int)(blockIdx.x % kXcds) * chunk + (int)(blockIdx.x / kXcds);
-  if (tile >= n_tiles) return; // whole workgroup
-  const int ty = tile / P.tiles_x;
-  const int tx = tile - ty * P.tiles_x;
+  int tx, ty;
+  if (!xcd_tile(P.tiles_x, P.tiles_y, tx, ty)) return; // whole workgroup
   const int lane = (int)(threadIdx.x & 63u);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int x = tx * kT2W + lane;
@@ -929,12 +926,8 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
   constexpr int kPlanes = 3;
   __shared__ float4 s_win[kWinWaves][kWinBuffers][kWinCap];
 
-  const int n_tiles = P.tiles_x * P.tiles_y;
-  const int chunk = (n_tiles + kXcds - 1) / kXcds;
-  const int tile = (int)(blockIdx.x % kXcds) * chunk + (int)(blockIdx.x / kXcds);
-  if (tile >= n_tiles) return; // whole workgroup
-  const int ty = tile / P.tiles_x;
-  const int tx = tile - ty * P.tiles_x;
+  int tx, ty;
+  if (!xcd_tile(P.tiles_x, P.tiles_y, tx, ty)) return; // whole workgroup
   const int lane = (int)(threadIdx.x & 63u);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int G = P.blocks_per_wave;
@@ -1459,11 +1452,10 @@ template <int Interp> hipError_t launch_tile_interp(KParams P, int out_idx, int 
   }
   const int n_tiles = P.tiles_x * P.tiles_y;
   if (n_tiles <= 0) return hipSuccess;
-  const int chunk = (n_tiles + kXcds - 1) / kXcds;
   const TileKernelFn fn = P.channels == 4   ? TileKernelTable<Interp, 4>::get(out_idx, in_mode)
                           : P.channels == 3 ? TileKernelTable<Interp, 3>::get(out_idx, in_mode)
                                             : TileKernelTable<Interp, 5>::get(out_idx, in_mode);
-  hipLaunchKernelGGL(fn, dim3((unsigned)(chunk * kXcds), (unsigned)(P.batch_n > 0 ? P.batch_n : 1)), dim3(kT2Threads), 0, stream, P);
+  hipLaunchKernelGGL(fn, dim3((unsigned)(kXcds * xcd_rows(P.tiles_y) * P.tiles_x), (unsigned)(P.batch_n > 0 ? P.batch_n : 1)), dim3(kT2Threads), 0, stream, P);
   return hipGetLastError();
 }
 
@@ -1503,9 +1495,8 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
   }
   const int n_tiles = P.tiles_x * P.tiles_y;
   if (n_tiles <= 0) return hipSuccess;
-  const int chunk = (n_tiles + kXcds - 1) / kXcds;
   const TileKernelFn fn = WinKernelTable<Quad, CH>::get(out_idx, in_mode);
-  hipLaunchKernelGGL(fn, dim3((unsigned)(chunk * kXcds), (unsigned)(P.batch_n > 0 ? P.batch_n : 1)), dim3(kWinThreads), 0, stream, P);
+  hipLaunchKernelGGL(fn, dim3((unsigned)(kXcds * xcd_rows(P.tiles_y) * P.tiles_x), (unsigned)(P.batch_n > 0 ? P.batch_n : 1)), dim3(kWinThreads), 0, stream, P);
   return hipGetLastError();
 }
 

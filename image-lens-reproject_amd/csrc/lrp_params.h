@@ -2,6 +2,7 @@
 // kernels.  Plain POD passed by value in kernarg (SGPR-resident, wave-uniform).
 #pragma once
 
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace lrp {
@@ -14,6 +15,18 @@ enum : int { kRect = 0, kEquidistant = 1, kEquirect = 4 };
 enum : int { kInRect = 0, kInEquidistant = 1, kInEquirect = 2, kInEquirectLoop = 3 };
 constexpr int kMaxBatch = 16; // frames of one geometry rendered by one launch (blockIdx.y = frame)
 constexpr int kXcds = 8; // XCDs (private L2s) of an MI355X; blockIdx % 8 labels the blocks that share one
+// XCD-aware tile numbering.  The dispatcher deals workgroup i to XCD i % 8.  The rows of tiles are cut
+// into bands of kXcdBand rows and the bands dealt round-robin to the XCDs: XCD k walks bands k, k + 8,
+// k + 16 ... in raster order, so the tiles one XCD has in flight (two rows of a 4K frame) neighbour each
+// other and share source rows in its L2, while every XCD gets a share of every part of the frame.
+// (One contiguous eighth of the frame per XCD — the round-1 numbering — leaves half the chip idle when
+// the expensive tiles sit in one part of it: a rectilinear view inside an equirectangular panorama
+// covers the four middle eighths only, a pole face the first or the last.)
+constexpr int kXcdBand = 2;
+// Rows of tiles one XCD walks (grid = 8 x this x tiles_x workgroups; surplus workgroups exit).
+inline __host__ __device__ int xcd_rows(int tiles_y) {
+  return (tiles_y + kXcds * kXcdBand - 1) / (kXcds * kXcdBand) * kXcdBand;
+}
 
 struct LensP {
   float p[4];          // union payload of LensInfo (see include/lrp.h)
