@@ -155,8 +155,19 @@ struct Reader {
   const std::vector<uint8_t> &b;
   size_t pos = 0;
   explicit Reader(const std::vector<uint8_t> &bytes) : b(bytes) {}
+  // (written so that neither a huge n nor a pos beyond the end can wrap the comparison)
   void need(size_t n) const {
-    if (pos + n > b.size()) throw std::runtime_error("truncated EXR file");
+    if (n > b.size() || pos > b.size() - n) throw std::runtime_error("truncated EXR file");
+  }
+  // a size / count field of the file: 32-bit signed on disk, never negative
+  size_t get_size() {
+    const int32_t v = get<int32_t>();
+    if (v < 0) throw std::runtime_error("corrupt EXR file (negative size)");
+    return (size_t)v;
+  }
+  void skip(size_t n) {
+    need(n);
+    pos += n;
   }
   template <typename T> T get() {
     need(sizeof(T));
@@ -236,15 +247,15 @@ Frame read_exr(const std::string &path) {
     const std::string name = r.str();
     if (name.empty()) break;
     const std::string type = r.str();
-    const int32_t size = r.get<int32_t>();
-    r.need((size_t)size);
-    const size_t end = r.pos + (size_t)size;
+    const size_t size = r.get_size();
+    r.need(size);
+    const size_t end = r.pos + size;
     if (name == "channels") {
       for (;;) {
         const std::string cn = r.str();
         if (cn.empty()) break;
         Channel c{cn, r.get<int32_t>()};
-        r.pos += 4; // pLinear + reserved
+        r.skip(4); // pLinear + reserved
         const int32_t xs = r.get<int32_t>(), ys = r.get<int32_t>();
         if (xs != 1 || ys != 1) throw std::runtime_error(path + ": sub-sampled channels are not supported");
         channels.push_back(c);
@@ -260,6 +271,10 @@ Frame read_exr(const std::string &path) {
   }
   (void)line_order; // every chunk carries its own y
   if (channels.empty() || dw[2] < dw[0] || dw[3] < dw[1]) throw std::runtime_error(path + ": incomplete OpenEXR header");
+  // sizes from the file are bounded before anything is allocated or multiplied (64-bit, no int overflow)
+  const int64_t width64 = (int64_t)dw[2] - dw[0] + 1, height64 = (int64_t)dw[3] - dw[1] + 1;
+  if (width64 > 65535 || height64 > 65535 || channels.size() > 64)
+    throw std::runtime_error(path + ": OpenEXR data window or channel list too large");
   int lines_per_block;
   if (compression == 0 || compression == 2)
     lines_per_block = 1;
@@ -269,8 +284,8 @@ Frame read_exr(const std::string &path) {
     throw std::runtime_error(path + ": only NO / ZIPS / ZIP compression is supported (found type " +
                              std::to_string(compression) + ")");
   Frame f;
-  f.width = dw[2] - dw[0] + 1;
-  f.height = dw[3] - dw[1] + 1;
+  f.width = (int)width64;
+  f.height = (int)height64;
   f.channels = (int)channels.size();
   bool has_a = false, has_z = false;
   for (const Channel &c : channels) {
@@ -306,17 +321,19 @@ Frame read_exr(const std::string &path) {
   std::vector<uint8_t> raw;
   for (int bi = 0; bi < n_blocks; ++bi) {
     Reader c(bytes);
+    if (offsets[(size_t)bi] > bytes.size()) throw std::runtime_error(path + ": scanline block offset beyond the file");
     c.pos = (size_t)offsets[(size_t)bi];
     const int32_t y0 = c.get<int32_t>();
-    const int32_t size = c.get<int32_t>();
-    c.need((size_t)size);
-    const int row0 = y0 - dw[1];
-    if (row0 < 0 || row0 >= f.height) throw std::runtime_error(path + ": scanline block outside the data window");
+    const size_t size = c.get_size();
+    c.need(size);
+    const int64_t row0_64 = (int64_t)y0 - dw[1];
+    if (row0_64 < 0 || row0_64 >= f.height) throw std::runtime_error(path + ": scanline block outside the data window");
+    const int row0 = (int)row0_64;
     const int n_lines = std::min(lines_per_block, f.height - row0);
     const size_t want = line_bytes * (size_t)n_lines;
     raw.resize(want);
-    if (compression == 0 || (size_t)size == want) {
-      if ((size_t)size != want) throw std::runtime_error(path + ": bad uncompressed block size");
+    if (compression == 0 || size == want) {
+      if (size != want) throw std::runtime_error(path + ": bad uncompressed block size");
       std::memcpy(raw.data(), bytes.data() + c.pos, want);
     } else {
       std::vector<uint8_t> tmp(want);

@@ -10,7 +10,10 @@
 //               half first, as OpenEXR's HALF frame-buffer slices do), layout
 //               RGB / RGBA / RGBZ / RGBAZ from the presence of A and Z  (:208-303)
 //        write: HALF channels R, G, B, A, Z (first C of them), ZIP       (:305-345)
-//   Scanline single-part EXR with NO / ZIPS / ZIP compression only.
+//   JPEG read : three components, v = pow(p / 255, 2.2)                  (:26-77)
+//        write: uint8(255.9 * pow(clamp(v, 0, 1), 1 / 2.2)), quality 95  (:79-142)
+//   Scanline single-part EXR with NO / ZIPS / ZIP compression only; JPEG through the image's IJG
+//   libjpeg 9 runtime, opened with dlopen (cli/lrp_jpeg.cpp).
 #pragma once
 
 #include <cstdint>
@@ -30,6 +33,8 @@ Frame read_png(const std::string &path);
 void save_png(const Frame &f, const std::string &path);
 Frame read_exr(const std::string &path);
 void save_exr(const Frame &f, const std::string &path);
+Frame read_jpeg(const std::string &path);
+void save_jpeg(const Frame &f, const std::string &path);
 
 // binary16 <-> binary32, round to nearest even (what OpenEXR's `half` does)
 uint16_t float_to_half(float f);

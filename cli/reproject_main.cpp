@@ -267,6 +267,8 @@ void process_file(const Job &job, const fs::path &p, int device, std::atomic_int
       input = lrp_io::read_exr(p.string());
     } else if (ext == ".png") {
       input = lrp_io::read_png(p.string());
+    } else if (ext == ".jpeg" || ext == ".jpg") { // src/main.cpp:570-571
+      input = lrp_io::read_jpeg(p.string());
     } else {
       std::printf("Input format not supported: %s\n", ext.c_str());
       return; // the reference carries on with an uninitialised image here

@@ -237,7 +237,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     P.quad = quad_enabled() && kernel_choice() != 3 && num_samples == 1 && !P.has_rot && sym_out &&
              (!in_eqr || P.xsep_tab != nullptr);
     const bool window = interpolation == LRP_BICUBIC && kernel_choice() >= 2 && num_samples == 1 &&
-                        (out->channels == 4 || out->channels == 3);
+                        (out->channels == 4 || out->channels == 3 || out->channels == 5);
     // Equidistant target, rotated (or an equirectangular source): the four mirror pixels still
     // share the ray through the output lens (tile kernels only).
     if (!P.quad && !window && quad_enabled() && kernel_choice() != 3 && num_samples == 1 &&

@@ -920,7 +920,8 @@ struct WinBlock {
 // arithmetic (no traps are enabled) and is never stored.
 template <int OutLens, int InMode, bool Quad, int CH>
 __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicubic_win_kernel(const KParams Pk) {
-  static_assert(CH == 3 || CH == 4, "window kernel: RGB or RGBA");
+  static_assert(CH == 3 || CH == 4 || CH == 5, "window kernel: RGB, RGBA or RGBAZ");
+  static_assert(CH != 5 || LRP_WIN_SIGNED_PITCH == 0, "the RGBAZ depth plane assumes top-down window rows");
   const KParams P = batch_frame(Pk);
   constexpr bool Loop = (InMode == kInEquirectLoop);
   constexpr int kPlanes = 3;
@@ -975,7 +976,12 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
   };
 
   // 16-byte LDS slots of the raw window
-  auto raw_slots = [](const WinBlock &b) { return b.pitch * b.bh; };
+  // RGBAZ (CH == 5): the window is two planes of the same pitch x bh geometry — colour (one 16-byte slot
+  // per texel, fetched with global_load_lds_dwordx4 from the texel's first four floats, 20-byte texel
+  // stride) and, right behind it, depth (one float per texel, global_load_lds_dword from its fifth).
+  // Everything written for RGBA then serves the colour channels unchanged; depth reads its 16 taps from
+  // the float plane and runs the five cubics as scalar instructions.
+  auto raw_slots = [](const WinBlock &b) { return CH == 5 ? b.pitch * b.bh + ((b.pitch * b.bh + 3) >> 2) : b.pitch * b.bh; };
   // Window of a block from the wave-wide extremes of its source coordinates (float bits, see below):
   // x range of the block, y ranges of its two halves.
   auto plan_window = [&](WinBlock &b, int w_lo_x, int w_hi_x, int w_lo_ya, int w_hi_ya, int w_lo_yb, int w_hi_yb) {
@@ -1182,6 +1188,7 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
       float4 *const win = win0 + (g & (kWinBuffers - 1)) * kWinCap;
       const float4 *gp = src4 + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane));
       const float *gp3 = P.src + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane)) * 3u;
+      const float *gp5 = P.src + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane)) * 5u;
       // Issued as inline assembly: the compiler's wait-count insertion then does not know
       // that LDS is being written and puts no vmcnt(0) in front of later LDS reads (of the
       // coefficient planes, which the DMA does not touch); the one wait that IS needed sits
@@ -1197,7 +1204,20 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
                          :
                          : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(gp + (size_t)r * in_w)
                          : "memory", "m0");
-          else
+          else if constexpr (CH == 5) {
+            // colour into the 16-byte slots of the row, depth into the row of the float plane behind the colour plane
+            const uint32_t lds_d = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win +
+                                   (uint32_t)(b.pitch * b.bh) * 16u + (uint32_t)(r * b.pitch) * 4u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                         :
+                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(gp5 + (size_t)r * in_w * 5)
+                         : "memory", "m0");
+            // (an instruction offset would move the LDS address as well as the global one: the fifth float is addressed in the VGPR)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
+                         :
+                         : "s"(__builtin_amdgcn_readfirstlane(lds_d)), "v"(gp5 + (size_t)r * in_w * 5 + 4)
+                         : "memory", "m0");
+          } else
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, off"
                          :
                          : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(gp3 + (size_t)r * in_w * 3)
@@ -1273,6 +1293,24 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
     dma_early = g_loop + 1 < G && (!(kWinCoef && cur.coef) || raw_slots(nxt) <= cur.c_base);
     if (dma_early) issue(g_loop + 1, nxt);
   };
+  // RGBAZ: the depth channel of one pixel from the float plane behind the colour window.  `slot` is the
+  // window slot of the pixel's first tap (int(sx) - 1, int(sy) - 1); bicubicInterpolate's order: four
+  // vertical cubics, then the horizontal one (src/reproject.cpp:100-107).  In the last pass these are the
+  // block's last reads of the window: the next window's DMA goes behind them.
+  auto depth_from_window = [&](const float4 *win, int slot, float fx, float fy, float hfx, float hfy, bool last_pass) {
+    const float *d = reinterpret_cast<const float *>(win + cur.pitch * cur.bh) + slot;
+    float t[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j][r] = d[r * cur.pitch + j];
+    if (last_pass) next_window();
+    const float k0 = catmull_rom(t[0][0], t[0][1], t[0][2], t[0][3], fy, hfy);
+    const float k1 = catmull_rom(t[1][0], t[1][1], t[1][2], t[1][3], fy, hfy);
+    const float k2 = catmull_rom(t[2][0], t[2][1], t[2][2], t[2][3], fy, hfy);
+    const float k3 = catmull_rom(t[3][0], t[3][1], t[3][2], t[3][3], fy, hfy);
+    return catmull_rom(k0, k1, k2, k3, fx, hfx);
+  };
 #pragma unroll 1
   for (int g = 0; g < G; ++g) {
     g_loop = g;
@@ -1316,7 +1354,7 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
           // the only reads of the raw window: the second tap row.  In the last pass they are the
           // block's last reads of it, and the next window's DMA goes right behind them
           const Rgba b0 = as_rgba(tb[0]), b1 = as_rgba(tb[1]), b2 = as_rgba(tb[2]), b3 = as_rgba(tb[3]);
-          if (last_pass) next_window();
+          if (last_pass && CH != 5) next_window();
           auto vert = [&](int j, const Rgba bj) {
 #if defined(LRP_SKIP_TAP_READS) // timing experiment (wrong results): no LDS reads of the planes
             const Rgba inner{f2{fx, fy} * (float)j, f2{hfx, fy}, 0.0f}, m0{f2{fy, fx} + (float)j, f2{fx, hfy}, 0.0f}, cma{f2{hfx, hfy}, f2{fy, fx} - (float)j, 0.0f};
@@ -1331,10 +1369,12 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
           };
           const Rgba k0 = vert(0, b0), k1 = vert(1, b1), k2 = vert(2, b2), k3 = vert(3, b3);
           s = cubic4(k0, k1, k2, k3, fx, hfx);
+          if constexpr (CH == 5) s.e = depth_from_window(win, tap - cur.spitch(), fx, fy, hfx, hfy, last_pass);
         } else if (cur.staged) {
           const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
           const float fx = psx - tx_, fy = psy - ty_;
-          const float4 *t = win + (cur.org() + __mul24((int)ty_ - 1 - cur.y_lo, cur.spitch()) + ((int)tx_ - 1 - cur.x_lo));
+          const int slot0 = cur.org() + __mul24((int)ty_ - 1 - cur.y_lo, cur.spitch()) + ((int)tx_ - 1 - cur.x_lo);
+          const float4 *t = win + slot0;
           const float hfx = 0.5f * fx, hfy = 0.5f * fy;
           const float4 *t1 = t + cur.spitch(), *t2 = t1 + cur.spitch(), *t3 = t2 + cur.spitch();
 #if LRP_ABLATE == 1 // timing experiment: taps loaded, no cubic arithmetic
@@ -1379,21 +1419,28 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
             q[j][2] = as_rgba(t2[j]);
             q[j][3] = as_rgba(t3[j]);
           }
-          if (last_pass) next_window();
+          if (last_pass && CH != 5) next_window();
           const Rgba k0 = cubic4(q[0][0], q[0][1], q[0][2], q[0][3], fy, hfy);
           const Rgba k1 = cubic4(q[1][0], q[1][1], q[1][2], q[1][3], fy, hfy);
           const Rgba k2 = cubic4(q[2][0], q[2][1], q[2][2], q[2][3], fy, hfy);
           const Rgba k3 = cubic4(q[3][0], q[3][1], q[3][2], q[3][3], fy, hfy);
           s = cubic4(k0, k1, k2, k3, fx, hfx);
+          if constexpr (CH == 5) s.e = depth_from_window(win, slot0, fx, fy, hfx, hfy, last_pass);
 #endif
         } else {
           if (last_pass) next_window(); // nothing staged: no tap of this block reads the window
-          s = sample_direct<2, Loop, 4, false, 4 * CH>(P, src, psx, psy);
+          if constexpr (CH == 5) {
+            const Px<5> s5 = sample_direct<2, Loop, 5, true>(P, src, psx, psy); // LowReg: two tap columns at a time
+            s = Rgba{s5.lo, s5.hi, s5.e};
+          } else {
+            s = sample_direct<2, Loop, 4, false, 4 * CH>(P, src, psx, psy);
+          }
         }
         // num_samples == 1: (0.0f + s) * normalize (src/reproject.cpp:334-341)
         Rgba a4 = px_zero<4>();
         px_add<4>(a4, s);
-        const Px<CH> a{a4.lo, CH == 4 ? a4.hi : f2{0.0f, 0.0f}, CH == 4 ? 0.0f : a4.hi.x};
+        if constexpr (CH == 5) a4.e = 0.0f + s.e;
+        const Px<CH> a{a4.lo, CH >= 4 ? a4.hi : f2{0.0f, 0.0f}, CH == 3 ? a4.hi.x : a4.e};
         // Every lane stores: lanes / rows beyond the image have recomputed the pixel they were
         // clamped to (xe, ye) and write that same value to that same address again, so the
         // store is issued by every wavefront (the vmcnt(1) above counts on it).

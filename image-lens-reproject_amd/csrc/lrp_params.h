@@ -22,7 +22,10 @@ constexpr int kXcds = 8; // XCDs (private L2s) of an MI355X; blockIdx % 8 labels
 // (One contiguous eighth of the frame per XCD — the round-1 numbering — leaves half the chip idle when
 // the expensive tiles sit in one part of it: a rectilinear view inside an equirectangular panorama
 // covers the four middle eighths only, a pole face the first or the last.)
-constexpr int kXcdBand = 2;
+#ifndef LRP_XCD_BAND
+#define LRP_XCD_BAND 2
+#endif
+constexpr int kXcdBand = LRP_XCD_BAND;
 // Rows of tiles one XCD walks (grid = 8 x this x tiles_x workgroups; surplus workgroups exit).
 inline __host__ __device__ int xcd_rows(int tiles_y) {
   return (tiles_y + kXcds * kXcdBand - 1) / (kXcds * kXcdBand) * kXcdBand;

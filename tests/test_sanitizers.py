@@ -1,0 +1,91 @@
+"""CPU sanitizer job (-fsanitize=address,undefined on the CPU build only — GPU
+AddressSanitizer is not available on this pool): the oracle, the host-side producers of hot-path
+inputs (lrp_host_util.cpp) and the CLI's codecs / JSON / lens-config code, compiled with ASan + UBSan
+and driven through round trips, every lens pair x sampler x channel count of the oracle, and a few
+hundred truncated / corrupted EXR, PNG and JPEG files (the advisor's finding on the EXR reader:
+file-supplied sizes and offsets must never reach memcpy / uncompress unchecked)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "tests", "native", "_build")
+PNG_LIB = os.environ.get("PNG_LIB", "/usr/lib/x86_64-linux-gnu/libpng16.so.16")
+SOURCES = ["tests/native/codec_driver.cpp", "cli/lrp_image_io.cpp", "cli/lrp_jpeg.cpp", "cli/lrp_config.cpp",
+           "image-lens-reproject_amd/csrc/lrp_host_util.cpp"]
+
+
+def build(name, extra):
+    os.makedirs(BUILD, exist_ok=True)
+    out = os.path.join(BUILD, name)
+    obj = os.path.join(BUILD, name + "_oracle.o")
+    subprocess.run(["gcc", "-std=gnu11", "-D_USE_MATH_DEFINES", "-O1", "-g", "-ffp-contract=off", *extra, "-c", os.path.join(ROOT, "oracle", "lrp_oracle.c"),
+                    "-o", obj], check=True, cwd=ROOT)
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-Wall", *extra, "-Iinclude", "-Icli", "-Ioracle", "-idirafter",
+                    "/opt/conda/include", *SOURCES, obj, PNG_LIB, "-lz", "-ldl", "-lm", "-o", out], check=True, cwd=ROOT)
+    return out
+
+
+@pytest.fixture(scope="module")
+def plain_driver():
+    return build("codec_driver", [])
+
+
+@pytest.fixture(scope="module")
+def sanitized_driver():
+    return build("codec_driver_asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"])
+
+
+def test_selftest_under_asan_and_ubsan(sanitized_driver, tmp_path):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([sanitized_driver, "selftest", str(tmp_path)], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "selftest ok" in r.stdout
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+def test_jpeg_decode_follows_the_reference_convention(plain_driver, tmp_path):
+    """read_jpeg: v = pow(p / 255, 2.2) per component of the decoded 8-bit samples (src/image_formats.cpp:64-66).
+    Pillow brings its own JPEG decoder (another IDCT), so samples may differ by a step or two."""
+    from PIL import Image
+
+    rng = np.random.default_rng(3)
+    # smooth content: what JPEG is for, and where two decoders agree to within a step
+    yy, xx = np.mgrid[0:48, 0:64]
+    img = np.stack([(xx * 3) % 256, (yy * 5) % 256, (xx + yy) * 2 % 256], axis=-1).astype(np.uint8)
+    img = (img.astype(np.int32) + rng.integers(-2, 3, size=img.shape)).clip(0, 255).astype(np.uint8)
+    path = tmp_path / "in.jpg"
+    Image.fromarray(img, "RGB").save(path, quality=95)
+    r = subprocess.run([plain_driver, "decode", str(path), str(tmp_path / "out.f32")], capture_output=True, text=True)
+    if r.returncode == 3 and "JPEG support unavailable" in r.stdout:
+        pytest.skip(r.stdout.strip())
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.split() == ["64", "48", "3", "0"]
+    got = np.fromfile(tmp_path / "out.f32", dtype=np.float32).reshape(48, 64, 3)
+    pil = np.asarray(Image.open(path).convert("RGB")).astype(np.float32)
+    want = np.power(pil / np.float32(255.0), np.float32(2.2))
+    back = np.rint(np.power(got.astype(np.float64), 1 / 2.2) * 255.0)  # the 8-bit samples libjpeg 9 decoded
+    assert np.abs(back - pil).max() <= 3
+    assert np.allclose(got, want, atol=0.03)
+    # exactly pow(k / 255, 2.2) for integer k
+    k = back.astype(np.float32)
+    assert np.array_equal(got, np.power(k / np.float32(255.0), np.float32(2.2)).astype(np.float32))
+
+
+def test_jpeg_encode_quantiser(plain_driver, tmp_path):
+    """save_jpeg: uint8(255.9 * pow(clamp(v, 0, 1), 1 / 2.2)), quality 95 (src/image_formats.cpp:125-131)."""
+    from PIL import Image
+
+    yy, xx = np.mgrid[0:32, 0:40]
+    v = np.stack([xx / 40.0, yy / 32.0, (xx + yy) / 72.0], axis=-1).astype(np.float32) * np.float32(1.2) - np.float32(0.1)
+    raw = tmp_path / "in.f32"
+    v.tofile(raw)
+    r = subprocess.run([plain_driver, "encode", str(tmp_path / "o.jpg"), "40", "32", "3", str(raw)], capture_output=True, text=True)
+    if r.returncode == 3 and "JPEG support unavailable" in r.stdout:
+        pytest.skip(r.stdout.strip())
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.asarray(Image.open(tmp_path / "o.jpg").convert("RGB")).astype(np.int32)
+    want = (np.float32(255.9) * np.power(np.clip(v, 0, 1), np.float32(1 / 2.2))).astype(np.uint8).astype(np.int32)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 6  # quality-95 JPEG of a smooth ramp
