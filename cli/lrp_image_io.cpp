@@ -62,6 +62,34 @@ uint16_t float_to_half(float f) {
 }
 
 // ---------------------------------------------------------------- PNG
+namespace {
+// to 8-bit RGBA the way lodepng's default decode does: 16-bit samples keep their
+// high byte, palettes and grey levels expand, tRNS becomes alpha, no gamma handling
+bool png_header(png_structp png, png_infop info, FILE *fp, unsigned *w, unsigned *h) {
+  if (setjmp(png_jmpbuf(png))) return false;
+  png_init_io(png, fp);
+  png_read_info(png, info);
+  *w = png_get_image_width(png, info);
+  *h = png_get_image_height(png, info);
+  const int color = png_get_color_type(png, info), depth = png_get_bit_depth(png, info);
+  if (depth == 16) png_set_strip_16(png);
+  if (color == PNG_COLOR_TYPE_PALETTE) png_set_palette_to_rgb(png);
+  if (color == PNG_COLOR_TYPE_GRAY && depth < 8) png_set_expand_gray_1_2_4_to_8(png);
+  if (png_get_valid(png, info, PNG_INFO_tRNS)) png_set_tRNS_to_alpha(png);
+  if (color == PNG_COLOR_TYPE_GRAY || color == PNG_COLOR_TYPE_GRAY_ALPHA) png_set_gray_to_rgb(png);
+  png_set_filler(png, 0xff, PNG_FILLER_AFTER);
+  png_set_interlace_handling(png);
+  png_read_update_info(png, info);
+  return true;
+}
+bool png_rows(png_structp png, png_bytep *rows) {
+  if (setjmp(png_jmpbuf(png))) return false;
+  png_read_image(png, rows);
+  png_read_end(png, nullptr);
+  return true;
+}
+} // namespace
+
 Frame read_png(const std::string &path) {
   FILE *fp = std::fopen(path.c_str(), "rb");
   if (!fp) throw std::runtime_error("cannot open " + path);
@@ -71,35 +99,21 @@ Frame read_png(const std::string &path) {
     std::fclose(fp);
     throw std::runtime_error("libpng initialisation failed");
   }
-  std::vector<uint8_t> rgba;
+  // libpng reports errors by longjmp: the two frames that call into it (png_header / png_rows below) hold
+  // plain data only, the buffers live here and are released by ordinary unwinding.
   unsigned w = 0, h = 0;
-  if (setjmp(png_jmpbuf(png))) {
+  if (!png_header(png, info, fp, &w, &h) || w > 65535u || h > 65535u) {
     png_destroy_read_struct(&png, &info, nullptr);
     std::fclose(fp);
     throw std::runtime_error("cannot decode PNG " + path);
   }
-  png_init_io(png, fp);
-  png_read_info(png, info);
-  w = png_get_image_width(png, info);
-  h = png_get_image_height(png, info);
-  const int color = png_get_color_type(png, info), depth = png_get_bit_depth(png, info);
-  // to 8-bit RGBA the way lodepng's default decode does: 16-bit samples keep their
-  // high byte, palettes and grey levels expand, tRNS becomes alpha, no gamma handling
-  if (depth == 16) png_set_strip_16(png);
-  if (color == PNG_COLOR_TYPE_PALETTE) png_set_palette_to_rgb(png);
-  if (color == PNG_COLOR_TYPE_GRAY && depth < 8) png_set_expand_gray_1_2_4_to_8(png);
-  if (png_get_valid(png, info, PNG_INFO_tRNS)) png_set_tRNS_to_alpha(png);
-  if (color == PNG_COLOR_TYPE_GRAY || color == PNG_COLOR_TYPE_GRAY_ALPHA) png_set_gray_to_rgb(png);
-  png_set_filler(png, 0xff, PNG_FILLER_AFTER);
-  png_set_interlace_handling(png);
-  png_read_update_info(png, info);
-  rgba.resize((size_t)w * h * 4);
+  std::vector<uint8_t> rgba((size_t)w * h * 4);
   std::vector<png_bytep> rows(h);
   for (unsigned y = 0; y < h; ++y) rows[y] = rgba.data() + (size_t)y * w * 4;
-  png_read_image(png, rows.data());
-  png_read_end(png, nullptr);
+  const bool ok = png_rows(png, rows.data());
   png_destroy_read_struct(&png, &info, nullptr);
   std::fclose(fp);
+  if (!ok) throw std::runtime_error("cannot decode PNG " + path);
 
   Frame f;
   f.width = (int)w;
