@@ -919,7 +919,10 @@ struct WinBlock {
 // DMA is therefore the RGBA code; the fourth component carries stale LDS contents through the
 // arithmetic (no traps are enabled) and is never stored.
 template <int OutLens, int InMode, bool Quad, int CH>
-__global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicubic_win_kernel(const KParams Pk) {
+#ifndef LRP_WIN_MINWAVES5
+#define LRP_WIN_MINWAVES5 3 // RGBAZ: 168 VGPRs (the 80 registers of a direct-path tap set do not fit 128 without spilling)
+#endif
+__global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_MINWAVES) void reproject_bicubic_win_kernel(const KParams Pk) {
   static_assert(CH == 3 || CH == 4 || CH == 5, "window kernel: RGB, RGBA or RGBAZ");
   static_assert(CH != 5 || LRP_WIN_SIGNED_PITCH == 0, "the RGBAZ depth plane assumes top-down window rows");
   const KParams P = batch_frame(Pk);
@@ -1430,7 +1433,7 @@ __global__ __launch_bounds__(kWinThreads, LRP_WIN_MINWAVES) void reproject_bicub
         } else {
           if (last_pass) next_window(); // nothing staged: no tap of this block reads the window
           if constexpr (CH == 5) {
-            const Px<5> s5 = sample_direct<2, Loop, 5, true>(P, src, psx, psy); // LowReg: two tap columns at a time
+            const Px<5> s5 = sample_direct<2, Loop, 5, LRP_WIN_MINWAVES5 >= 4>(P, src, psx, psy); // (LowReg at 128 VGPRs)
             s = Rgba{s5.lo, s5.hi, s5.e};
           } else {
             s = sample_direct<2, Loop, 4, false, 4 * CH>(P, src, psx, psy);
