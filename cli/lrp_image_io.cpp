@@ -1,37 +1,24 @@
 // lrp_image_io.cpp — see lrp_image_io.h.
 #include "lrp_image_io.h"
 
+#include "lrp_half.h"
+
 #include <png.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
 namespace lrp_io {
 
 // ---------------------------------------------------------------- half <-> float
+// (one implementation for the host codecs and the device kernels: include/lrp_half.h)
 float half_to_float(uint16_t h) {
-  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
-  uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, bits;
-  if (exp == 0) {
-    if (man == 0) {
-      bits = sign;
-    } else { // subnormal half -> normal float
-      int e = -1;
-      do {
-        ++e;
-        man <<= 1;
-      } while (!(man & 0x400u));
-      bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
-    }
-  } else if (exp == 31) {
-    bits = sign | 0x7f800000u | (man << 13);
-  } else {
-    bits = sign | ((exp + 112u) << 23) | (man << 13);
-  }
+  const uint32_t bits = lrp_half_to_float_bits(h);
   float f;
   std::memcpy(&f, &bits, 4);
   return f;
@@ -40,25 +27,70 @@ float half_to_float(uint16_t h) {
 uint16_t float_to_half(float f) {
   uint32_t x;
   std::memcpy(&x, &f, 4);
-  const uint32_t sign = (x >> 16) & 0x8000u;
-  x &= 0x7fffffffu;
-  if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? (0x200u | ((x >> 13) & 0x3ffu)) : 0u)); // inf / NaN
-  if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                                            // rounds to inf (>= 65520)
-  if (x < 0x33000001u) return (uint16_t)sign;                                                                        // < 2^-25 (or exactly): +-0
-  if (x < 0x38800000u) { // subnormal half
-    const int e = (int)(x >> 23);
-    uint32_t m = (x & 0x7fffffu) | 0x800000u;
-    const int shift = 126 - e; // 14 .. 24
-    const uint32_t lost = m & ((1u << shift) - 1u), half_ulp = 1u << (shift - 1);
-    m >>= shift;
-    if (lost > half_ulp || (lost == half_ulp && (m & 1u))) ++m;
-    return (uint16_t)(sign | m);
+  return lrp_float_bits_to_half(x);
+}
+
+// ---------------------------------------------------------------- packed frames
+Allocator heap_allocator() { return Allocator{[](size_t n) { return std::malloc(n ? n : 1); }, [](void *p) { std::free(p); }}; }
+
+Packed &Packed::operator=(Packed &&o) noexcept {
+  if (this != &o) {
+    if (bytes && allocator.release) allocator.release(bytes);
+    width = o.width;
+    height = o.height;
+    channels = o.channels;
+    packed_channels = o.packed_channels;
+    data_layout = o.data_layout;
+    format = o.format;
+    bytes = o.bytes;
+    size = o.size;
+    allocator = o.allocator;
+    o.bytes = nullptr;
+    o.size = 0;
   }
-  uint32_t m = x - 0x38000000u; // re-bias exponent
-  const uint32_t lost = m & 0x1fffu;
-  m >>= 13;
-  if (lost > 0x1000u || (lost == 0x1000u && (m & 1u))) ++m;
-  return (uint16_t)(sign | m);
+  return *this;
+}
+Packed::~Packed() {
+  if (bytes && allocator.release) allocator.release(bytes);
+}
+void Packed::allocate(const Allocator &a, size_t n) {
+  if (bytes && allocator.release) allocator.release(bytes);
+  allocator = a;
+  bytes = static_cast<uint8_t *>(a.alloc(n));
+  size = n;
+  if (!bytes) throw std::runtime_error("out of memory for an image buffer");
+}
+
+Frame unpack(const Packed &p) {
+  Frame f;
+  f.width = p.width;
+  f.height = p.height;
+  f.channels = p.channels;
+  f.data_layout = p.data_layout;
+  const size_t n = (size_t)p.width * p.height;
+  f.data.resize(n * p.channels);
+  if (p.format == 1) {
+    const uint16_t *h = reinterpret_cast<const uint16_t *>(p.bytes);
+    for (size_t i = 0; i < n; ++i)
+      for (int c = 0; c < p.channels; ++c) f.data[i * p.channels + c] = half_to_float(h[i * p.packed_channels + c]);
+  } else {
+    // 256-entry table of the reference's per-sample conversion pow(float(p) / 255.0f, 2.2f)
+    // (src/image_formats.cpp:64-66, 196-198)
+    float lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = std::pow(float(i) / 255.0f, 2.2f);
+    for (size_t i = 0; i < n; ++i)
+      for (int c = 0; c < p.channels; ++c) f.data[i * p.channels + c] = lut[p.bytes[i * p.packed_channels + c]];
+  }
+  return f;
+}
+
+Packed read_packed(const std::string &path, const Allocator &alloc) {
+  const size_t dot = path.rfind('.');
+  const std::string ext = dot == std::string::npos ? std::string() : path.substr(dot);
+  if (ext == ".exr") return read_exr_packed(path, alloc);
+  if (ext == ".png") return read_png_packed(path, alloc);
+  if (ext == ".jpg" || ext == ".jpeg") return read_jpeg_packed(path, alloc);
+  throw std::runtime_error("Input format not supported: " + ext);
 }
 
 // ---------------------------------------------------------------- PNG
@@ -90,47 +122,49 @@ bool png_rows(png_structp png, png_bytep *rows) {
 }
 } // namespace
 
-Frame read_png(const std::string &path) {
+Packed read_png_packed(const std::string &path, const Allocator &alloc) {
   FILE *fp = std::fopen(path.c_str(), "rb");
   if (!fp) throw std::runtime_error("cannot open " + path);
   png_structp png = png_create_read_struct(PNG_LIBPNG_VER_STRING, nullptr, nullptr, nullptr);
   png_infop info = png ? png_create_info_struct(png) : nullptr;
   if (!png || !info) {
+    if (png) png_destroy_read_struct(&png, nullptr, nullptr);
     std::fclose(fp);
     throw std::runtime_error("libpng initialisation failed");
   }
-  // libpng reports errors by longjmp: the two frames that call into it (png_header / png_rows below) hold
+  // libpng reports errors by longjmp: the two frames that call into it (png_header / png_rows above) hold
   // plain data only, the buffers live here and are released by ordinary unwinding.
   unsigned w = 0, h = 0;
-  if (!png_header(png, info, fp, &w, &h) || w > 65535u || h > 65535u) {
+  if (!png_header(png, info, fp, &w, &h) || w == 0 || h == 0 || w > 65535u || h > 65535u) {
     png_destroy_read_struct(&png, &info, nullptr);
     std::fclose(fp);
     throw std::runtime_error("cannot decode PNG " + path);
   }
-  std::vector<uint8_t> rgba((size_t)w * h * 4);
-  std::vector<png_bytep> rows(h);
-  for (unsigned y = 0; y < h; ++y) rows[y] = rgba.data() + (size_t)y * w * 4;
-  const bool ok = png_rows(png, rows.data());
+  Packed p;
+  p.width = (int)w;
+  p.height = (int)h;
+  p.channels = 3; // alpha is decoded and dropped (src/image_formats.cpp:186-198)
+  p.packed_channels = 4;
+  p.data_layout = 0;
+  p.format = 2;
+  bool ok = false;
+  try {
+    p.allocate(alloc, (size_t)w * h * 4);
+    std::vector<png_bytep> rows(h);
+    for (unsigned y = 0; y < h; ++y) rows[y] = p.bytes + (size_t)y * w * 4;
+    ok = png_rows(png, rows.data());
+  } catch (...) {
+    png_destroy_read_struct(&png, &info, nullptr);
+    std::fclose(fp);
+    throw;
+  }
   png_destroy_read_struct(&png, &info, nullptr);
   std::fclose(fp);
   if (!ok) throw std::runtime_error("cannot decode PNG " + path);
-
-  Frame f;
-  f.width = (int)w;
-  f.height = (int)h;
-  f.channels = 3;
-  f.data_layout = 0;
-  f.data.resize((size_t)w * h * 3);
-  // 256-entry table of the reference's per-sample conversion (src/image_formats.cpp:196-198)
-  float lut[256];
-  for (int i = 0; i < 256; ++i) lut[i] = std::pow(float(i) / 255.0f, 2.2f);
-  for (size_t i = 0, n = (size_t)w * h; i < n; ++i) {
-    f.data[i * 3 + 0] = lut[rgba[i * 4 + 0]];
-    f.data[i * 3 + 1] = lut[rgba[i * 4 + 1]];
-    f.data[i * 3 + 2] = lut[rgba[i * 4 + 2]];
-  }
-  return f;
+  return p;
 }
+
+Frame read_png(const std::string &path) { return unpack(read_png_packed(path, heap_allocator())); }
 
 void save_png(const Frame &f, const std::string &path) {
   std::vector<uint8_t> buf((size_t)f.width * f.height * 4);
@@ -143,23 +177,31 @@ void save_png(const Frame &f, const std::string &path) {
     }
     if (f.channels != 4) buf[i * 4 + 3] = 255;
   }
+  save_png_rgba8(buf.data(), f.width, f.height, path);
+}
+
+namespace {
+bool png_write_all(png_structp png, png_infop info, FILE *fp, const uint8_t *rgba, int width, int height) {
+  if (setjmp(png_jmpbuf(png))) return false;
+  png_init_io(png, fp);
+  png_set_IHDR(png, info, (png_uint_32)width, (png_uint_32)height, 8, PNG_COLOR_TYPE_RGBA, PNG_INTERLACE_NONE,
+               PNG_COMPRESSION_TYPE_DEFAULT, PNG_FILTER_TYPE_DEFAULT);
+  png_write_info(png, info);
+  for (int y = 0; y < height; ++y) png_write_row(png, const_cast<png_bytep>(rgba + (size_t)y * width * 4));
+  png_write_end(png, nullptr);
+  return true;
+}
+} // namespace
+
+void save_png_rgba8(const uint8_t *rgba, int width, int height, const std::string &path) {
   FILE *fp = std::fopen(path.c_str(), "wb");
   if (!fp) throw std::runtime_error("cannot write " + path);
   png_structp png = png_create_write_struct(PNG_LIBPNG_VER_STRING, nullptr, nullptr, nullptr);
   png_infop info = png ? png_create_info_struct(png) : nullptr;
-  if (!png || !info || setjmp(png_jmpbuf(png))) {
-    if (png) png_destroy_write_struct(&png, &info);
-    std::fclose(fp);
-    throw std::runtime_error("cannot encode PNG " + path);
-  }
-  png_init_io(png, fp);
-  png_set_IHDR(png, info, (png_uint_32)f.width, (png_uint_32)f.height, 8, PNG_COLOR_TYPE_RGBA, PNG_INTERLACE_NONE,
-               PNG_COMPRESSION_TYPE_DEFAULT, PNG_FILTER_TYPE_DEFAULT);
-  png_write_info(png, info);
-  for (int y = 0; y < f.height; ++y) png_write_row(png, buf.data() + (size_t)y * f.width * 4);
-  png_write_end(png, nullptr);
-  png_destroy_write_struct(&png, &info);
+  const bool ok = png && info && png_write_all(png, info, fp, rgba, width, height);
+  if (png) png_destroy_write_struct(&png, &info);
   std::fclose(fp);
+  if (!ok) throw std::runtime_error("cannot encode PNG " + path);
 }
 
 // ---------------------------------------------------------------- EXR
@@ -247,7 +289,7 @@ std::vector<uint8_t> split_and_predict(const uint8_t *raw, size_t n) {
 
 } // namespace
 
-Frame read_exr(const std::string &path) {
+Packed read_exr_packed(const std::string &path, const Allocator &alloc) {
   const std::vector<uint8_t> bytes = read_file(path);
   Reader r(bytes);
   if (r.get<uint32_t>() != 20000630u) throw std::runtime_error(path + ": not an OpenEXR file");
@@ -297,10 +339,11 @@ Frame read_exr(const std::string &path) {
   else
     throw std::runtime_error(path + ": only NO / ZIPS / ZIP compression is supported (found type " +
                              std::to_string(compression) + ")");
-  Frame f;
+  Packed f;
   f.width = (int)width64;
   f.height = (int)height64;
-  f.channels = (int)channels.size();
+  f.channels = f.packed_channels = (int)channels.size();
+  f.format = 1;
   bool has_a = false, has_z = false;
   for (const Channel &c : channels) {
     has_a |= c.name == "A";
@@ -328,7 +371,9 @@ Frame read_exr(const std::string &path) {
     if (c.type != 1 && c.type != 2) throw std::runtime_error(path + ": UINT channels are not supported");
     line_bytes += (size_t)f.width * (c.type == 1 ? 2 : 4);
   }
-  f.data.assign((size_t)f.width * f.height * f.channels, 0.0f);
+  f.allocate(alloc, (size_t)f.width * f.height * f.channels * 2);
+  std::memset(f.bytes, 0, f.size);
+  uint16_t *const pixels = reinterpret_cast<uint16_t *>(f.bytes);
   const int n_blocks = (f.height + lines_per_block - 1) / lines_per_block;
   std::vector<uint64_t> offsets((size_t)n_blocks);
   for (auto &o : offsets) o = r.get<uint64_t>();
@@ -360,18 +405,14 @@ Frame read_exr(const std::string &path) {
     for (int l = 0; l < n_lines; ++l) {
       const int y = row0 + l;
       for (size_t ci = 0; ci < channels.size(); ++ci) {
-        float *out = f.data.data() + ((size_t)y * f.width) * f.channels + dst[ci];
+        uint16_t *out = pixels + ((size_t)y * f.width) * f.channels + dst[ci];
         if (channels[ci].type == 1) {
-          for (int x = 0; x < f.width; ++x, p += 2) {
-            uint16_t h;
-            std::memcpy(&h, p, 2);
-            out[(size_t)x * f.channels] = half_to_float(h);
-          }
+          for (int x = 0; x < f.width; ++x, p += 2) std::memcpy(&out[(size_t)x * f.channels], p, 2);
         } else {
           for (int x = 0; x < f.width; ++x, p += 4) {
             float v;
             std::memcpy(&v, p, 4);
-            out[(size_t)x * f.channels] = half_to_float(float_to_half(v)); // read through a HALF slice
+            out[(size_t)x * f.channels] = float_to_half(v); // read through a HALF slice
           }
         }
       }
@@ -380,9 +421,19 @@ Frame read_exr(const std::string &path) {
   return f;
 }
 
+Frame read_exr(const std::string &path) { return unpack(read_exr_packed(path, heap_allocator())); }
+
 void save_exr(const Frame &f, const std::string &path) {
-  static const char *kNames[5] = {"R", "G", "B", "A", "Z"};
   if (f.channels > 5) throw std::runtime_error("cannot save exr with more than 5 channels."); // :312
+  std::vector<uint16_t> h(f.data.size());
+  for (size_t i = 0; i < h.size(); ++i) h[i] = float_to_half(f.data[i]);
+  save_exr_half(h.data(), f.width, f.height, f.channels, path);
+}
+
+void save_exr_half(const uint16_t *half_pixels, int width, int height, int n_channels, const std::string &path) {
+  static const char *kNames[5] = {"R", "G", "B", "A", "Z"};
+  if (n_channels > 5) throw std::runtime_error("cannot save exr with more than 5 channels."); // :312
+  struct { int width, height, channels; } f{width, height, n_channels};
   // file order = alphabetical channel order
   std::vector<int> order;
   for (int c = 0; c < f.channels; ++c) order.push_back(c);
@@ -440,8 +491,7 @@ void save_exr(const Frame &f, const std::string &path) {
     for (int l = 0; l < n_lines; ++l)
       for (int c : order)
         for (int x = 0; x < f.width; ++x, p += 2) {
-          const uint16_t h = float_to_half(f.data[((size_t)(row0 + l) * f.width + x) * f.channels + c]);
-          std::memcpy(p, &h, 2);
+          std::memcpy(p, &half_pixels[((size_t)(row0 + l) * f.width + x) * f.channels + c], 2);
         }
     const std::vector<uint8_t> t = split_and_predict(raw.data(), raw.size());
     uLongf bound = compressBound((uLong)t.size());

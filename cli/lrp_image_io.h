@@ -16,7 +16,9 @@
 //   libjpeg 9 runtime, opened with dlopen (cli/lrp_jpeg.cpp).
 #pragma once
 
+#include <cstddef>
 #include <cstdint>
+#include <utility>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -28,6 +30,44 @@ struct Frame {
   int data_layout = 0; // reproject::DataLayout numbering: RGB 0, RGBA 1, RGBZ 2, RGBAZ 3
   std::vector<float> data;
 };
+
+// A frame in its FILE format — what crosses PCIe when the conversions run on the device
+// (lrp_context_submit_packed): RGBA8 / RGB8 samples of a PNG / JPEG (LRP_PIXEL_U8_GAMMA) or
+// interleaved binary16 samples of an EXR (LRP_PIXEL_F16).  `channels` is what the hot path
+// sees (PNG: 3 of the 4 decoded samples), `packed_channels` what the buffer holds per pixel.
+// The buffer comes from `alloc` (the CLI passes page-locked memory) and is released with it.
+struct Allocator {
+  void *(*alloc)(size_t bytes);
+  void (*release)(void *ptr);
+};
+Allocator heap_allocator();
+
+struct Packed {
+  int width = 0, height = 0, channels = 0, packed_channels = 0;
+  int data_layout = 0;
+  int format = 0; // lrp_pixel_format numbering: 1 binary16, 2 8-bit gamma
+  uint8_t *bytes = nullptr;
+  size_t size = 0;
+  Allocator allocator{nullptr, nullptr};
+  Packed() = default;
+  Packed(const Packed &) = delete;
+  Packed &operator=(const Packed &) = delete;
+  Packed(Packed &&o) noexcept { *this = std::move(o); }
+  Packed &operator=(Packed &&o) noexcept;
+  ~Packed();
+  void allocate(const Allocator &a, size_t n);
+};
+
+// by extension: .exr -> binary16, .png -> RGBA8, .jpg / .jpeg -> RGB8
+Packed read_packed(const std::string &path, const Allocator &alloc);
+Packed read_png_packed(const std::string &path, const Allocator &alloc);
+Packed read_exr_packed(const std::string &path, const Allocator &alloc);
+Packed read_jpeg_packed(const std::string &path, const Allocator &alloc);
+// RGBA8 with width x height x 4 bytes / binary16 with width x height x channels samples
+void save_png_rgba8(const uint8_t *rgba, int width, int height, const std::string &path);
+void save_exr_half(const uint16_t *half_pixels, int width, int height, int channels, const std::string &path);
+// the host-side conversions between the two representations (the device kernels' twins)
+Frame unpack(const Packed &p);
 
 Frame read_png(const std::string &path);
 void save_png(const Frame &f, const std::string &path);

@@ -127,15 +127,12 @@ int jpeg_open(const JpegApi &J, jpeg_decompress_struct *cinfo, ErrorTrap *trap, 
   return cinfo->output_components == 3 ? 0 : 3;
 }
 
-int jpeg_decode_rows(const JpegApi &J, jpeg_decompress_struct *cinfo, ErrorTrap *trap, JSAMPLE *row, float *out,
-                     const float *lut) {
+int jpeg_decode_rows(const JpegApi &J, jpeg_decompress_struct *cinfo, ErrorTrap *trap, JSAMPLE *out) {
   if (setjmp(trap->jump)) return 1;
   const size_t n = (size_t)cinfo->output_width * 3;
   while (cinfo->output_scanline < cinfo->output_height) {
-    JSAMPROW rows[1] = {row};
+    JSAMPROW rows[1] = {out + (size_t)cinfo->output_scanline * n};
     if (J.read_scanlines(cinfo, rows, 1) != 1) return 2;
-    float *o = out + (size_t)(cinfo->output_scanline - 1) * n;
-    for (size_t i = 0; i < n; ++i) o[i] = lut[row[i]];
   }
   J.finish_decompress(cinfo);
   return 0;
@@ -170,7 +167,7 @@ int jpeg_encode(const JpegApi &J, jpeg_compress_struct *cinfo, ErrorTrap *trap, 
 
 } // namespace
 
-Frame read_jpeg(const std::string &path) {
+Packed read_jpeg_packed(const std::string &path, const Allocator &alloc) {
   const JpegApi &J = api();
   FILE *fp = std::fopen(path.c_str(), "rb");
   if (!fp) throw std::runtime_error("cannot open " + path);
@@ -189,23 +186,30 @@ Frame read_jpeg(const std::string &path) {
   if (rc == 1) throw fail(trap.message);
   if (rc == 2) throw fail("cannot read the JPEG header");
   if (rc == 3) throw fail(std::to_string(cinfo.output_components) + "-component JPEG (three components expected)");
-  Frame f;
-  f.width = (int)cinfo.output_width;
-  f.height = (int)cinfo.output_height;
-  f.channels = 3;
-  f.data_layout = 0;
-  f.data.resize((size_t)f.width * f.height * 3);
-  std::vector<JSAMPLE> row((size_t)f.width * 3);
-  // pow(float(p) / 255.0f, 2.2f) has 256 possible arguments (src/image_formats.cpp:64-66)
-  float lut[256];
-  for (int i = 0; i < 256; ++i) lut[i] = std::pow((float)i / 255.0f, 2.2f);
-  rc = jpeg_decode_rows(J, &cinfo, &trap, row.data(), f.data.data(), lut);
+  Packed p;
+  p.width = (int)cinfo.output_width;
+  p.height = (int)cinfo.output_height;
+  p.channels = p.packed_channels = 3;
+  p.data_layout = 0;
+  p.format = 2;
+  try {
+    p.allocate(alloc, (size_t)p.width * p.height * 3);
+  } catch (...) {
+    J.destroy_decompress(&cinfo);
+    std::fclose(fp);
+    throw;
+  }
+  static_assert(sizeof(JSAMPLE) == 1, "8-bit libjpeg");
+  rc = jpeg_decode_rows(J, &cinfo, &trap, p.bytes);
   if (rc == 1) throw fail(trap.message);
   if (rc == 2) throw fail("cannot read a JPEG scanline");
   J.destroy_decompress(&cinfo);
   std::fclose(fp);
-  return f;
+  return p;
 }
+
+// v = pow(float(p) / 255.0f, 2.2f) per component (src/image_formats.cpp:64-66): unpack()'s table
+Frame read_jpeg(const std::string &path) { return unpack(read_jpeg_packed(path, heap_allocator())); }
 
 void save_jpeg(const Frame &f, const std::string &path) {
   const JpegApi &J = api();

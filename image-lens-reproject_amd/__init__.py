@@ -308,6 +308,27 @@ class BatchContext:
         _check(self._lib.lrp_context_submit(self._h, ctypes.byref(cin), ctypes.byref(cout), int(num_samples),
                                             int(interpolation), rot, ctypes.byref(cpost) if cpost else None))
 
+    def submit_packed(self, in_image, in_format, in_data, out_image, out_format, out_data, out_fill, num_samples,
+                      interpolation, rotation_matrix=None, post=None):
+        """lrp_context_submit_packed: `in_data` / `out_data` are C-contiguous numpy arrays of shape
+        (height, width, packed_channels) in the file formats (float16 / uint8 / float32); the images
+        describe the float geometry the kernels see.  Returns a ticket for wait_ticket()."""
+        cin, cout = in_image.to_c(), out_image.to_c()
+        cin.data = in_data.ctypes.data
+        cout.data = out_data.ctypes.data
+        keep, rot = _rotation_arg(rotation_matrix)
+        cpost = LrpPost(float(post[0]), float(post[1])) if post is not None else None
+        ticket = ctypes.c_int(-1)
+        self._keep.append((in_data, out_data, keep))
+        _check(self._lib.lrp_context_submit_packed(self._h, ctypes.byref(cin), int(in_format), int(in_data.shape[-1]),
+                                                   ctypes.byref(cout), int(out_format), int(out_data.shape[-1]),
+                                                   int(out_fill), int(num_samples), int(interpolation), rot,
+                                                   ctypes.byref(cpost) if cpost else None, ctypes.byref(ticket)))
+        return ticket.value
+
+    def wait_ticket(self, ticket):
+        _check(self._lib.lrp_context_wait_ticket(self._h, int(ticket)))
+
     def wait(self):
         st = self._lib.lrp_context_wait(self._h)
         self._keep.clear()
@@ -377,3 +398,34 @@ def checksum_host(array):
         lo = mix32(bits, idx).astype(np.uint64)
         hi = mix32(bits ^ np.uint32(0xA5A5A5A5), idx * np.uint32(2) + np.uint32(0x7F4A7C15)).astype(np.uint64)
         return int(np.sum((hi << np.uint64(32)) | lo, dtype=np.uint64))
+
+
+class PixelFormat(enum.IntEnum):  # include/lrp.h lrp_pixel_format
+    F32 = 0
+    F16 = 1
+    U8_GAMMA = 2
+
+
+def decode_pixels(src, src_format, dst, stream=None):
+    """lrp_decode_pixels_device: `src` a CUDA tensor (..., src_channels) of uint8 / int16 (half bits) / float16 /
+    float32 samples, `dst` a float32 CUDA tensor (..., dst_channels) with the same number of pixels."""
+    lib = _native.load()
+    n = dst.numel() // dst.shape[-1]
+    _check(lib.lrp_decode_pixels_device(src.data_ptr(), int(src_format), int(src.shape[-1]), dst.data_ptr(), int(dst.shape[-1]),
+                                        n, dst.device.index, _stream_handle(stream)))
+
+
+def encode_pixels(src, dst, dst_format, fill=0, stream=None):
+    """lrp_encode_pixels_device: float32 CUDA tensor (..., C) -> `dst` (..., dst_channels) in `dst_format`."""
+    lib = _native.load()
+    n = src.numel() // src.shape[-1]
+    _check(lib.lrp_encode_pixels_device(src.data_ptr(), int(src.shape[-1]), dst.data_ptr(), int(dst_format), int(dst.shape[-1]),
+                                        int(fill), n, src.device.index, _stream_handle(stream)))
+
+
+def pixel_tables():
+    """(decode[256], threshold[256]) of LRP_PIXEL_U8_GAMMA as the host's powf made them."""
+    dec = (ctypes.c_float * 256)()
+    thr = (ctypes.c_float * 256)()
+    _native.load().lrp_pixel_tables(dec, thr)
+    return np.frombuffer(dec, dtype=np.float32).copy(), np.frombuffer(thr, dtype=np.float32).copy()

@@ -100,6 +100,24 @@ SYMBOLS = {
         [ctypes.c_void_p, _P(LrpImage), _P(LrpImage), ctypes.c_int, ctypes.c_int, _FLOATP, _P(LrpPost)],
     ),
     "lrp_context_wait": (ctypes.c_int, [ctypes.c_void_p]),
+    "lrp_context_submit_packed": (
+        ctypes.c_int,
+        [ctypes.c_void_p, _P(LrpImage), ctypes.c_int, ctypes.c_int, _P(LrpImage), ctypes.c_int, ctypes.c_int, ctypes.c_uint,
+         ctypes.c_int, ctypes.c_int, _FLOATP, _P(LrpPost), _P(ctypes.c_int)],
+    ),
+    "lrp_context_wait_ticket": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "lrp_decode_pixels_device": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _FLOATP, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p],
+    ),
+    "lrp_encode_pixels_device": (
+        ctypes.c_int,
+        [_FLOATP, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_size_t, ctypes.c_int,
+         ctypes.c_void_p],
+    ),
+    "lrp_pixel_tables": (None, [_P(ctypes.c_float), _P(ctypes.c_float)]),
+    "lrp_host_alloc": (ctypes.c_int, [_P(ctypes.c_void_p), ctypes.c_size_t]),
+    "lrp_host_free": (None, [ctypes.c_void_p]),
     "lrp_synth_fill_device": (
         ctypes.c_int,
         [_FLOATP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
@@ -144,7 +162,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.lrp_abi_version() != 1:
+    if lib.lrp_abi_version() != 2:
         raise ImportError("liblrp_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -33,6 +33,12 @@ hipError_t launch_synth_fill(float *data, uint32_t n_elems, int channels, uint32
                              hipStream_t stream);
 hipError_t launch_math_eval(int func, const float *a, const float *b, float *out, size_t n, hipStream_t stream);
 hipError_t launch_checksum(const float *data, size_t n, unsigned long long *out, hipStream_t stream);
+size_t pixel_bytes(int format, int channels);
+hipError_t launch_decode_pixels(const void *src, int format, int src_channels, float *dst, int dst_channels,
+                                size_t n_pixels, int device, hipStream_t stream);
+hipError_t launch_encode_pixels(const float *src, int src_channels, void *dst, int format, int dst_channels,
+                                unsigned fill, size_t n_pixels, int device, hipStream_t stream);
+void pixel_tables_host(float decode[256], float threshold[256]);
 } // namespace lrp
 
 namespace {
@@ -321,6 +327,7 @@ struct Buffer {
 // from the upload stream to the compute stream to the download stream.
 struct Slot {
   Buffer d_in, d_out;
+  Buffer d_in_packed, d_out_packed; // the frame in its file format (lrp_context_submit_packed)
   hipEvent_t uploaded = nullptr, computed = nullptr, downloaded = nullptr;
   bool used = false;
 };
@@ -332,6 +339,7 @@ struct Slot {
 // both PCIe directions and the GPU at the same time (a stream per image does not:
 // its own H2D -> kernel -> D2H chain keeps one DMA direction idle).
 struct lrp_context {
+  std::mutex mutex; // submissions from several host threads are serialised
   int device = 0;
   hipStream_t up = nullptr, run = nullptr, down = nullptr;
   std::vector<Slot> slots;
@@ -464,47 +472,113 @@ void lrp_context_destroy(lrp_context *ctx) {
       if (ev) (void)hipEventDestroy(ev);
     s.d_in.release();
     s.d_out.release();
+    s.d_in_packed.release();
+    s.d_out_packed.release();
   }
   delete ctx;
 }
 
-int lrp_context_submit(lrp_context *ctx, const lrp_image *in, lrp_image *out, int num_samples, int interpolation,
-                       const float *rotation, const lrp_post *post) {
-  if (!ctx) return fail(LRP_ERR_NULL, "null context");
-  int st = validate(in, out, interpolation, true);
-  if (st != LRP_OK) return st;
-  st = select_device(ctx->device);
-  if (st != LRP_OK) return st;
-  if (num_samples <= 0) return LRP_OK;
-  Slot &s = ctx->slots[ctx->next];
+namespace {
+bool format_ok(int f) { return f == LRP_PIXEL_F32 || f == LRP_PIXEL_F16 || f == LRP_PIXEL_U8_GAMMA; }
+
+// One image through the three-stage pipeline.  Formats LRP_PIXEL_F32 with packed channels == image
+// channels: the host buffers are the kernels' own layout and are copied straight into / out of the
+// slot's float buffers; otherwise the frame is uploaded as it is and converted on the device.
+int submit_locked(lrp_context *ctx, const lrp_image *in, int in_format, int in_pch, lrp_image *out, int out_format,
+                  int out_pch, unsigned out_fill, int num_samples, int interpolation, const float *rotation,
+                  const lrp_post *post, int *ticket) {
+  const size_t index = ctx->next;
+  Slot &s = ctx->slots[index];
   ctx->next = (ctx->next + 1) % ctx->slots.size();
+  if (ticket) *ticket = (int)index;
+  const size_t in_px = (size_t)in->width * (size_t)in->height, out_px = (size_t)out->width * (size_t)out->height;
   const size_t in_bytes = image_bytes(*in), out_bytes = image_bytes(*out);
-  if (in_bytes > s.d_in.cap || out_bytes > s.d_out.cap) {
+  const bool in_plain = in_format == LRP_PIXEL_F32 && in_pch == in->channels;
+  const bool out_plain = out_format == LRP_PIXEL_F32 && out_pch == out->channels;
+  const size_t in_packed = in_plain ? 0 : in_px * lrp::pixel_bytes(in_format, in_pch);
+  const size_t out_packed = out_plain ? 0 : out_px * lrp::pixel_bytes(out_format, out_pch);
+  if (in_bytes > s.d_in.cap || out_bytes > s.d_out.cap || in_packed > s.d_in_packed.cap || out_packed > s.d_out_packed.cap) {
     // growing a buffer frees the old one: the slot's previous image must have drained
     if (s.used) LRP_HIP_TRY(hipEventSynchronize(s.downloaded));
-    st = s.d_in.reserve(in_bytes);
-    if (st != LRP_OK) return st;
-    st = s.d_out.reserve(out_bytes);
+    int st = s.d_in.reserve(in_bytes);
+    if (st == LRP_OK) st = s.d_out.reserve(out_bytes);
+    if (st == LRP_OK && in_packed) st = s.d_in_packed.reserve(in_packed);
+    if (st == LRP_OK && out_packed) st = s.d_out_packed.reserve(out_packed);
     if (st != LRP_OK) return st;
   }
-  // upload: the slot's source buffer is free once its previous kernel has run
+  // upload: the slot's source buffers are free once its previous kernels have run
   if (s.used) LRP_HIP_TRY(hipStreamWaitEvent(ctx->up, s.computed, 0));
-  LRP_HIP_TRY(hipMemcpyAsync(s.d_in.ptr, in->data, in_bytes, hipMemcpyHostToDevice, ctx->up));
+  LRP_HIP_TRY(hipMemcpyAsync(in_plain ? s.d_in.ptr : s.d_in_packed.ptr, in->data, in_plain ? in_bytes : in_packed,
+                             hipMemcpyHostToDevice, ctx->up));
   LRP_HIP_TRY(hipEventRecord(s.uploaded, ctx->up));
-  // kernel: after the upload, and after the previous download has read the destination buffer
+  // kernels: after the upload, and after the previous download has read the destination buffers
   LRP_HIP_TRY(hipStreamWaitEvent(ctx->run, s.uploaded, 0));
   if (s.used) LRP_HIP_TRY(hipStreamWaitEvent(ctx->run, s.downloaded, 0));
+  if (!in_plain) {
+    hipError_t e = lrp::launch_decode_pixels(s.d_in_packed.ptr, in_format, in_pch, (float *)s.d_in.ptr, in->channels, in_px,
+                                             ctx->device, ctx->run);
+    if (e != hipSuccess) return hip_fail(e, "pixel decode kernel launch");
+  }
   lrp_image din = *in, dout = *out;
   din.data = (float *)s.d_in.ptr;
   dout.data = (float *)s.d_out.ptr;
-  st = enqueue_reproject(&din, &dout, num_samples, interpolation, rotation, post, ctx->device, ctx->run);
+  int st = enqueue_reproject(&din, &dout, num_samples, interpolation, rotation, post, ctx->device, ctx->run);
   if (st != LRP_OK) return st;
+  if (!out_plain) {
+    hipError_t e = lrp::launch_encode_pixels((const float *)s.d_out.ptr, out->channels, s.d_out_packed.ptr, out_format, out_pch,
+                                             out_fill, out_px, ctx->device, ctx->run);
+    if (e != hipSuccess) return hip_fail(e, "pixel encode kernel launch");
+  }
   LRP_HIP_TRY(hipEventRecord(s.computed, ctx->run));
   // download
   LRP_HIP_TRY(hipStreamWaitEvent(ctx->down, s.computed, 0));
-  LRP_HIP_TRY(hipMemcpyAsync(out->data, s.d_out.ptr, out_bytes, hipMemcpyDeviceToHost, ctx->down));
+  LRP_HIP_TRY(hipMemcpyAsync(out->data, out_plain ? s.d_out.ptr : s.d_out_packed.ptr, out_plain ? out_bytes : out_packed,
+                             hipMemcpyDeviceToHost, ctx->down));
   LRP_HIP_TRY(hipEventRecord(s.downloaded, ctx->down));
   s.used = true;
+  return LRP_OK;
+}
+} // namespace
+
+int lrp_context_submit_packed(lrp_context *ctx, const lrp_image *in, int in_format, int in_packed_channels, lrp_image *out,
+                              int out_format, int out_packed_channels, unsigned out_fill, int num_samples,
+                              int interpolation, const float *rotation, const lrp_post *post, int *ticket) {
+  if (!ctx) return fail(LRP_ERR_NULL, "null context");
+  if (ticket) *ticket = -1;
+  int st = validate(in, out, interpolation, true);
+  if (st != LRP_OK) return st;
+  if (!format_ok(in_format) || !format_ok(out_format) || in_packed_channels < 1 || out_packed_channels < 1 ||
+      in_packed_channels > 64 || out_packed_channels > 64)
+    return fail(LRP_ERR_BAD_ARG, "bad pixel format or packed channel count");
+  st = select_device(ctx->device);
+  if (st != LRP_OK) return st;
+  if (num_samples <= 0) return LRP_OK; // reference loop body never runs: output untouched
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  return submit_locked(ctx, in, in_format, in_packed_channels, out, out_format, out_packed_channels, out_fill, num_samples,
+                       interpolation, rotation, post, ticket);
+}
+
+int lrp_context_submit(lrp_context *ctx, const lrp_image *in, lrp_image *out, int num_samples, int interpolation,
+                       const float *rotation, const lrp_post *post) {
+  if (!in || !out) return fail(LRP_ERR_NULL, "null image");
+  return lrp_context_submit_packed(ctx, in, LRP_PIXEL_F32, in->channels, out, LRP_PIXEL_F32, out->channels, 0u, num_samples,
+                                   interpolation, rotation, post, nullptr);
+}
+
+int lrp_context_wait_ticket(lrp_context *ctx, int ticket) {
+  if (!ctx) return fail(LRP_ERR_NULL, "null context");
+  if (ticket < 0) return LRP_OK; // nothing was enqueued (num_samples <= 0)
+  if ((size_t)ticket >= ctx->slots.size()) return fail(LRP_ERR_BAD_ARG, "bad ticket");
+  int st = select_device(ctx->device);
+  if (st != LRP_OK) return st;
+  hipEvent_t ev;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    ev = ctx->slots[(size_t)ticket].downloaded;
+  }
+  // (a later submission that re-used the slot has re-recorded the event behind this image's download
+  // on the same stream: waiting for it waits for this image too)
+  LRP_HIP_TRY(hipEventSynchronize(ev));
   return LRP_OK;
 }
 
@@ -513,6 +587,7 @@ int lrp_context_wait(lrp_context *ctx) {
   int st = select_device(ctx->device);
   if (st != LRP_OK) return st;
   int result = LRP_OK;
+  std::lock_guard<std::mutex> lock(ctx->mutex);
   for (hipStream_t stream : {ctx->up, ctx->run, ctx->down}) {
     hipError_t e = hipStreamSynchronize(stream);
     if (e != hipSuccess && result == LRP_OK) result = hip_fail(e, "hipStreamSynchronize");
@@ -586,6 +661,47 @@ int lrp_post_process(lrp_image *img, float exposure, float reinhard, int device)
   }();
   return_context(c);
   return st;
+}
+
+int lrp_decode_pixels_device(const void *src, int src_format, int src_channels, float *dst, int dst_channels, size_t n_pixels,
+                             int device, void *stream) {
+  if (!src || !dst) return fail(LRP_ERR_NULL, "null buffer");
+  if (!format_ok(src_format) || src_channels < 1 || dst_channels < 1 || src_channels > 64 || dst_channels > 64)
+    return fail(LRP_ERR_BAD_ARG, "bad pixel format or channel count");
+  int st = select_device(device);
+  if (st != LRP_OK) return st;
+  if (n_pixels == 0) return LRP_OK;
+  hipError_t e = lrp::launch_decode_pixels(src, src_format, src_channels, dst, dst_channels, n_pixels, device, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "pixel decode kernel launch");
+  return LRP_OK;
+}
+
+int lrp_encode_pixels_device(const float *src, int src_channels, void *dst, int dst_format, int dst_channels, unsigned fill,
+                             size_t n_pixels, int device, void *stream) {
+  if (!src || !dst) return fail(LRP_ERR_NULL, "null buffer");
+  if (!format_ok(dst_format) || src_channels < 1 || dst_channels < 1 || src_channels > 64 || dst_channels > 64)
+    return fail(LRP_ERR_BAD_ARG, "bad pixel format or channel count");
+  int st = select_device(device);
+  if (st != LRP_OK) return st;
+  if (n_pixels == 0) return LRP_OK;
+  hipError_t e = lrp::launch_encode_pixels(src, src_channels, dst, dst_format, dst_channels, fill, n_pixels, device, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "pixel encode kernel launch");
+  return LRP_OK;
+}
+
+void lrp_pixel_tables(float decode[256], float threshold[256]) { lrp::pixel_tables_host(decode, threshold); }
+
+int lrp_host_alloc(void **ptr, size_t bytes) {
+  if (!ptr) return fail(LRP_ERR_NULL, "null pointer");
+  *ptr = nullptr;
+  if (device_count_cached() == 0) return fail(LRP_ERR_NO_DEVICE, "no HIP device visible");
+  hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) return hip_fail(e, "hipHostMalloc");
+  return LRP_OK;
+}
+
+void lrp_host_free(void *ptr) {
+  if (ptr) (void)hipHostFree(ptr);
 }
 
 int lrp_synth_fill_device(float *data, int width, int height, int channels, uint32_t seed, int depth_channel,

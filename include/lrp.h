@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LRP_ABI_VERSION 1
+#define LRP_ABI_VERSION 2
 
 /* ---- enums: numbering identical to the reference's ------------------------ */
 
@@ -181,6 +181,51 @@ int lrp_context_submit(lrp_context *ctx, const lrp_image *in, lrp_image *out, in
                        int interpolation, const float *rotation, const lrp_post *post);
 /* Wait for everything submitted so far; returns the first error seen. */
 int lrp_context_wait(lrp_context *ctx);
+
+/* ---- pixel formats of the file path -------------- */
+
+/* What the reference's codecs do on the host between a file and the float buffers of the
+ * hot path, done on the device so that a frame crosses PCIe in its file format (8 or 4 bytes
+ * per RGBA pixel instead of 16):
+ *   LRP_PIXEL_F16       interleaved IEEE binary16 — an OpenEXR HALF channel; widened exactly,
+ *                       narrowed round-to-nearest-even like Imath's half
+ *                       (src/image_formats.cpp:266-295, 318-333);
+ *   LRP_PIXEL_U8_GAMMA  8-bit samples; decode v = pow(p / 255, 2.2) (read_png :196-198, read_jpeg
+ *                       :64-66), encode uint8(255.9 * pow(clamp(v, 0, 1), 1 / 2.2)) (save_png
+ *                       :155-158) — bit for bit what the host's powf gives (tables made by it).
+ * Channels: the first min(src_channels, dst_channels) are converted; extra destination
+ * channels are filled (decode: 0.0f; encode: `fill`, e.g. 255 for the alpha byte save_png
+ * writes when the image has no fourth channel). */
+typedef enum lrp_pixel_format { LRP_PIXEL_F32 = 0, LRP_PIXEL_F16 = 1, LRP_PIXEL_U8_GAMMA = 2 } lrp_pixel_format;
+
+/* Device buffers, asynchronous on `stream`. */
+int lrp_decode_pixels_device(const void *src, int src_format, int src_channels, float *dst, int dst_channels,
+                             size_t n_pixels, int device, void *stream);
+int lrp_encode_pixels_device(const float *src, int src_channels, void *dst, int dst_format, int dst_channels,
+                             unsigned fill, size_t n_pixels, int device, void *stream);
+/* The two 256-entry tables behind LRP_PIXEL_U8_GAMMA as the host's powf made them: decode[k] =
+ * pow(k / 255, 2.2), threshold[k] = smallest s in [0, 1] whose code is >= k.  No device needed. */
+void lrp_pixel_tables(float decode[256], float threshold[256]);
+
+/* Page-locked host memory for the buffers handed to a context (pageable buffers work too, but
+ * make every copy synchronous and half as fast).  lrp_host_free(NULL) is a no-op. */
+int lrp_host_alloc(void **ptr, size_t bytes);
+void lrp_host_free(void *ptr);
+
+/* lrp_context_submit with the host buffers in a file format: in->data holds in->width x
+ * in->height pixels of `in_packed_channels` samples in `in_format` (e.g. the RGBA8 libpng
+ * decodes to, of which in->channels = 3 are used; or in->channels HALF samples), out->data
+ * receives `out_packed_channels` samples per pixel in `out_format` (`out_fill` for channels
+ * beyond out->channels).  Upload, decode kernel, reproject (+ fused post_process), encode
+ * kernel, download — pipelined over the context's slots like lrp_context_submit.
+ * *ticket (may be NULL) identifies the submission for lrp_context_wait_ticket, which blocks
+ * until that image's output has landed while later submissions keep flowing.  A context may
+ * be shared by several host threads (submissions are serialised internally). */
+int lrp_context_submit_packed(lrp_context *ctx, const lrp_image *in, int in_format, int in_packed_channels,
+                              lrp_image *out, int out_format, int out_packed_channels, unsigned out_fill,
+                              int num_samples, int interpolation, const float *rotation, const lrp_post *post,
+                              int *ticket);
+int lrp_context_wait_ticket(lrp_context *ctx, int ticket);
 
 /* ---- synthetic frames (bench / tests) -------------------------------------- */
 

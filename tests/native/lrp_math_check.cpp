@@ -207,4 +207,46 @@ void lrp_eval_atan2(const float *y, const float *x, float *out_own, float *out_r
   }
 }
 
+// The 8-bit quantiser of save_png / save_jpeg, q(s) = uint8(255.9f * powf(s, 1 / 2.2f)) (reference
+// src/image_formats.cpp:125-131, 155-158), against a search in the 256-entry threshold table the device
+// encode kernel uses (lrp_pixel_tables): every float of [0, 1], i.e. bit patterns 0 .. 0x3f800000.
+// Returns the number of inputs whose two codes differ (0 also proves q is non-decreasing on [0, 1]).
+uint64_t lrp_check_u8_quantiser(const float *threshold, int threads, uint32_t *first_bad) {
+  std::atomic<uint64_t> bad{0};
+  std::atomic<uint64_t> first{~0ull};
+  if (threads < 1) threads = 1;
+  const uint64_t total = 0x3f800000ull + 1;
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) {
+    pool.emplace_back([&, t]() {
+      uint64_t local = 0;
+      const uint64_t b = total * (uint64_t)t / (uint64_t)threads, e = total * (uint64_t)(t + 1) / (uint64_t)threads;
+      for (uint64_t i = b; i < e; ++i) {
+        const uint32_t bits = (uint32_t)i;
+        float s;
+        memcpy(&s, &bits, 4);
+        const uint8_t direct = (uint8_t)(255.9f * powf(s, 1.0f / 2.2f));
+        int lo = 0, hi = 256;
+        for (int step = 0; step < 8; ++step) {
+          const int mid = (lo + hi) >> 1;
+          if (threshold[mid] <= s)
+            lo = mid;
+          else
+            hi = mid;
+        }
+        if ((uint8_t)lo != direct) {
+          ++local;
+          uint64_t cur = first.load();
+          while (i < cur && !first.compare_exchange_weak(cur, i)) {
+          }
+        }
+      }
+      bad += local;
+    });
+  }
+  for (auto &th : pool) th.join();
+  if (first_bad) *first_bad = (uint32_t)first.load();
+  return bad.load();
+}
+
 } // extern "C"

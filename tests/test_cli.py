@@ -324,3 +324,93 @@ def test_equisolid_is_rejected_like_the_reference(cli, torch_cuda, tmp_path):
     r = run(cli, "--single", tmp_path / "a.png", "-o", tmp_path / "o", "--png", "--no-configs", "8,8", "--i-equisolid",
             "10.5,36,3.14", "--rectilinear", "18,36")
     assert r.returncode == 1 and "Input lens type not supported." in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ext", ["png", "jpg"])
+def test_packed_u8_path_png_only_run_equals_oracle_pipeline(cli, lrp, oracle, torch_cuda, tmp_path, ext):
+    """One output format only: the frame goes to the GPU as the decoder's 8-bit samples (RGBA8 from libpng,
+    RGB8 from libjpeg) and comes back as the RGBA8 save_png writes — decode, reproject, tonemap and quantise
+    on the device (lrp_context_submit_packed) must equal the reference's host pipeline to the last bit."""
+    from PIL import Image
+
+    rng = np.random.default_rng(31)
+    w, h, ow, oh = 128, 64, 96, 56
+    if ext == "png":
+        rgb = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        Image.fromarray(rgb, "RGB").save(tmp_path / "pano.png")
+        decoded = rgb
+    else:
+        yy, xx = np.mgrid[0:h, 0:w]
+        rgb = np.stack([(xx * 2) % 256, (yy * 4) % 256, (xx + yy) % 256], axis=-1).astype(np.uint8)
+        Image.fromarray(rgb, "RGB").save(tmp_path / "pano.jpg", quality=95)
+        # what the image's libjpeg 9 decodes (Pillow's decoder may differ by a step): through the codec driver
+        import test_sanitizers
+
+        drv = test_sanitizers.build("codec_driver", [])
+        r = subprocess.run([drv, "decode", str(tmp_path / "pano.jpg"), str(tmp_path / "pano.f32")], capture_output=True, text=True)
+        if r.returncode == 3 and "JPEG support unavailable" in r.stdout:
+            pytest.skip(r.stdout.strip())
+        assert r.returncode == 0, r.stdout
+        floats = np.fromfile(tmp_path / "pano.f32", dtype=np.float32).reshape(h, w, 3)
+        decoded = np.searchsorted(DECODE, floats).astype(np.uint8)  # back to the 8-bit samples
+        assert np.array_equal(DECODE[decoded], floats)
+    out = tmp_path / "out"
+    r = run(cli, "--single", tmp_path / f"pano.{ext}", "-o", out, "--png", "--no-configs", f"{w},{h}", "--i-equirectangular",
+            "full", "--rectilinear", "18,36", "--output-resolution", f"{ow},{oh}", "--rotation", "30,-15,5", "--exposure", "1",
+            "--reinhard", "4")
+    assert r.returncode == 0, r.stdout + r.stderr
+    lin = lrp.LensInfo.equirectangular()
+    lout = lrp.LensInfo.rectilinear(18.0, 36.0, ow, oh)
+    d2r = lambda d: float(np.float32(d / 180.0 * math.pi))  # noqa: E731
+    rot = lrp.rotation_matrix(d2r(30.0), d2r(-15.0), d2r(5.0))
+    want = _oracle_pipeline(lrp, oracle, DECODE[decoded], lin, lout, ow, oh, 1, 2, rot, 1.0, 4.0)
+    got = np.array(Image.open(out / "pano.png"))
+    assert got.shape == (oh, ow, 4) and (got[..., 3] == 255).all()
+    assert (got[..., :3] == encode8(want)).all()
+
+
+@pytest.mark.gpu
+def test_gpus_flag_splits_the_sorted_list_into_blocks(cli, lrp, torch_cuda, tmp_path):
+    """--gpus 2: contiguous blocks of the sorted file list per GPU (no communication); the outputs are those of
+    a one-GPU run, file for file.  Needs two visible devices; with one the flag is clamped and the run must
+    still produce the same files."""
+    from PIL import Image
+
+    rng = np.random.default_rng(41)
+    w, h = 64, 32
+    for i in range(5):
+        Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8), "RGB").save(tmp_path / f"f{i}.png")
+    common = ["-i", tmp_path, "--png", "--no-configs", f"{w},{h}", "--i-equirectangular", "full", "--equidistant", "3.14159265",
+              "--bl", "-j", "4"]
+    r1 = run(cli, *common, "-o", tmp_path / "one")
+    r2 = run(cli, *common, "-o", tmp_path / "two", "--gpus", "2")
+    assert r1.returncode == 0 and r2.returncode == 0, r1.stdout + r2.stdout
+    for i in range(5):
+        assert (tmp_path / "one" / f"f{i}.png").read_bytes() == (tmp_path / "two" / f"f{i}.png").read_bytes()
+    if torch_cuda.cuda.device_count() < 2:
+        pytest.skip("one visible device: --gpus 2 was clamped to 1 (outputs verified)")
+
+
+@pytest.mark.gpu
+def test_bad_device_index_is_an_error_up_front(cli, torch_cuda, tmp_path):
+    from PIL import Image
+
+    Image.fromarray(np.zeros((8, 8, 3), dtype=np.uint8), "RGB").save(tmp_path / "a.png")
+    for dev in ("99", "-1"):
+        r = run(cli, "--single", tmp_path / "a.png", "-o", tmp_path / "o", "--png", "--no-configs", "8,8", "--i-equirectangular",
+                "full", "--rectilinear", "18,36", "--device", dev)
+        assert r.returncode == 1 and "is out of range" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_failed_files_make_the_exit_status_nonzero(cli, torch_cuda, tmp_path):
+    """A file that cannot be decoded prints `Error: ...` like the reference worker (src/main.cpp:617-619), the run
+    goes on with the next file, and the process ends with status 1."""
+    from PIL import Image
+
+    Image.fromarray(np.full((8, 8, 3), 90, dtype=np.uint8), "RGB").save(tmp_path / "a_good.png")
+    (tmp_path / "b_bad.png").write_bytes(b"\\x89PNG\\r\\n\\x1a\\nnot a png at all")
+    r = run(cli, "-i", tmp_path, "-o", tmp_path / "o", "--png", "--no-configs", "8,8", "--i-equirectangular", "full",
+            "--rectilinear", "18,36")
+    assert r.returncode == 1 and "Error: cannot decode PNG" in r.stdout and (tmp_path / "o" / "a_good.png").exists()

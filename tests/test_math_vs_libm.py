@@ -26,6 +26,8 @@ def chk():
     L.lrp_eval_atan2.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_uint64]
     L.lrp_check_odd.restype = ctypes.c_uint64
     L.lrp_check_odd.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]
+    L.lrp_check_u8_quantiser.restype = ctypes.c_uint64
+    L.lrp_check_u8_quantiser.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]
     return L
 
 
@@ -63,3 +65,23 @@ def test_atan2_special_grid(chk):
     chk.lrp_eval_atan2(y.ctypes.data, x.ctypes.data, own.ctypes.data, ref.ctypes.data, y.size)
     same = (own.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(own) & np.isnan(ref))
     assert same.all(), f"atan2f special grid: y={y[~same][:4]} x={x[~same][:4]}"
+
+
+def test_u8_quantiser_equals_its_threshold_table(chk, lrp):
+    """The device encode kernel of LRP_PIXEL_U8_GAMMA searches a 256-entry threshold table built with the
+    host's powf instead of evaluating a pow on the device: for all 2^30 floats of [0, 1] the search must give
+    uint8(255.9f * powf(s, 1 / 2.2f)), save_png's code (reference src/image_formats.cpp:155-158)."""
+    dec = (ctypes.c_float * 256)()
+    thr = (ctypes.c_float * 256)()
+    lrp._native.load().lrp_pixel_tables(dec, thr)
+    t = np.frombuffer(thr, dtype=np.float32)
+    assert t[0] == 0.0 and np.all(np.diff(t) >= 0) and t[255] <= 1.0
+    libm = ctypes.CDLL("libm.so.6")
+    libm.powf.restype = ctypes.c_float
+    libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    d = np.frombuffer(dec, dtype=np.float32)
+    for k in (0, 1, 2, 17, 128, 254, 255):  # read_png / read_jpeg: pow(float(p) / 255.0f, 2.2f)
+        assert d[k] == np.float32(libm.powf(np.float32(k) / np.float32(255.0), np.float32(2.2)))
+    first = ctypes.c_uint32(0)
+    bad = chk.lrp_check_u8_quantiser(ctypes.addressof(thr), THREADS, ctypes.byref(first))
+    assert bad == 0, f"{bad} floats of [0, 1] quantise differently, first bit pattern 0x{first.value:08x}"
