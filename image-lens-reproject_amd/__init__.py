@@ -249,6 +249,38 @@ def reproject_multi(in_image, out_images, num_samples, interpolation, rotation_m
     _check(st)
 
 
+def reproject_rows(in_image, out_image, num_samples, interpolation, row_first, row_count, rotation_matrix=None, post=None,
+                   device=None, stream=None):
+    """lrp_reproject_rows_device: rows [row_first, row_first + row_count) of the output only (device tensors)."""
+    lib = _native.load()
+    cin, cout = in_image.to_c(), out_image.to_c()
+    keep, rot = _rotation_arg(rotation_matrix)
+    cpost = LrpPost(float(post[0]), float(post[1])) if post is not None else None
+    dev = in_image.data.device.index if device is None else device
+    st = lib.lrp_reproject_rows_device(ctypes.byref(cin), ctypes.byref(cout), int(num_samples), int(interpolation), rot,
+                                       ctypes.byref(cpost) if cpost is not None else None, int(row_first), int(row_count), dev,
+                                       _stream_handle(stream))
+    del keep
+    _check(st)
+
+
+def reproject_multi_gpu(in_image, out_images, num_samples, interpolation, rotation_matrices=None, post=None, devices=(0,)):
+    """lrp_reproject_multi: one host source, several host outputs, row bands of every output on every listed GPU."""
+    lib = _native.load()
+    cin = in_image.to_c()
+    arr = (LrpImage * len(out_images))(*[o.to_c() for o in out_images])
+    rot, keep = None, None
+    if rotation_matrices is not None:
+        keep = np.ascontiguousarray(np.asarray(rotation_matrices, dtype=np.float32).reshape(len(out_images), 9))
+        rot = keep.ctypes.data
+    cpost = LrpPost(float(post[0]), float(post[1])) if post is not None else None
+    devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+    st = lib.lrp_reproject_multi(ctypes.byref(cin), arr, len(out_images), int(num_samples), int(interpolation), rot,
+                                 ctypes.byref(cpost) if cpost is not None else None, devs, len(devices))
+    del keep
+    _check(st)
+
+
 def reproject_batch(in_images, out_images, num_samples, interpolation, rotation_matrix=None, post=None, device=None,
                     stream=None):
     """n images of one geometry (same sizes, channels, lenses), device tensors only: one kernel

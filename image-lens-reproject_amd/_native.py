@@ -79,6 +79,15 @@ SYMBOLS = {
             ctypes.c_void_p,
         ],
     ),
+    "lrp_reproject_rows_device": (
+        ctypes.c_int,
+        [_P(LrpImage), _P(LrpImage), ctypes.c_int, ctypes.c_int, _FLOATP, _P(LrpPost), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+         ctypes.c_void_p],
+    ),
+    "lrp_reproject_multi": (
+        ctypes.c_int,
+        [_P(LrpImage), _P(LrpImage), ctypes.c_int, ctypes.c_int, ctypes.c_int, _FLOATP, _P(LrpPost), _P(ctypes.c_int), ctypes.c_int],
+    ),
     "lrp_reproject_batch_device": (
         ctypes.c_int,
         [

@@ -152,6 +152,7 @@ lrp::KParams make_params(const lrp_image *in, const lrp_image *out, int num_samp
     P.reinhard = post->reinhard;
   }
   P.y_offset = 0;
+  P.y_end = out->height;
   // lens-only constants of the tile kernel, same binary32 operations as the
   // reference performs per pixel (src/reproject.cpp:178,196,265-266)
   P.in_focal = in->lens.sensor_width / in->lens.u.fisheye_equidistant.fov;
@@ -196,10 +197,19 @@ bool xsep_enabled() {
 // n_batch > 0: `in` / `out` are arrays of n_batch images of one geometry (checked by the caller);
 // the tile / window kernels render them in launches of up to kMaxBatch frames, the per-pixel
 // kernels one launch per frame.
+// row_count > 0: only output rows [row_first, row_first + row_count) are rendered (the rows of the reference
+// loop are independent, src/reproject.cpp:284); the kernels that share work between mirrored rows need the
+// whole image and are not used for a band.
 int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int interpolation,
-                      const float *rotation, const lrp_post *post, int device, hipStream_t stream, int n_batch = 0) {
+                      const float *rotation, const lrp_post *post, int device, hipStream_t stream, int n_batch = 0,
+                      int row_first = 0, int row_count = 0) {
   if (num_samples <= 0) return LRP_OK; // reference loop body never runs: output untouched
   lrp::KParams P = make_params(in, out, num_samples, rotation, post);
+  const bool band = row_count > 0 && !(row_first == 0 && row_count == out->height);
+  if (band) {
+    P.y_offset = row_first;
+    P.y_end = row_first + row_count;
+  }
   const int oi = out_lens_index(out->lens.type);
   const int im = in_lens_mode(in->lens);
   hipError_t e;
@@ -240,13 +250,13 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     // Family 3 keeps every sharing path of the tile / window kernels off (cross-checks).
     const bool in_eqr = im == lrp::kInEquirect || im == lrp::kInEquirectLoop;
     const bool sym_out = out->lens.type == LRP_FISHEYE_EQUIDISTANT ? true : mirror;
-    P.quad = quad_enabled() && kernel_choice() != 3 && num_samples == 1 && !P.has_rot && sym_out &&
+    P.quad = !band && quad_enabled() && kernel_choice() != 3 && num_samples == 1 && !P.has_rot && sym_out &&
              (!in_eqr || P.xsep_tab != nullptr);
     const bool window = interpolation == LRP_BICUBIC && kernel_choice() >= 2 && num_samples == 1 &&
                         (out->channels == 4 || out->channels == 3 || out->channels == 5);
     // Equidistant target, rotated (or an equirectangular source): the four mirror pixels still
     // share the ray through the output lens (tile kernels only).
-    if (!P.quad && !window && quad_enabled() && kernel_choice() != 3 && num_samples == 1 &&
+    if (!band && !P.quad && !window && quad_enabled() && kernel_choice() != 3 && num_samples == 1 &&
         out->lens.type == LRP_FISHEYE_EQUIDISTANT)
       P.quad = 2;
     P.win_coef = kernel_choice() == 2;
@@ -387,6 +397,18 @@ int lrp_reproject_device(const lrp_image *in, lrp_image *out, int num_samples, i
   return enqueue_reproject(in, out, num_samples, interpolation, rotation, post, device, (hipStream_t)stream);
 }
 
+int lrp_reproject_rows_device(const lrp_image *in, lrp_image *out, int num_samples, int interpolation, const float *rotation,
+                              const lrp_post *post, int row_first, int row_count, int device, void *stream) {
+  int st = validate(in, out, interpolation, true);
+  if (st != LRP_OK) return st;
+  if (row_first < 0 || row_count < 0 || row_first > out->height - row_count)
+    return fail(LRP_ERR_BAD_ARG, "row band outside the output image");
+  st = select_device(device);
+  if (st != LRP_OK) return st;
+  if (row_count == 0) return LRP_OK;
+  return enqueue_reproject(in, out, num_samples, interpolation, rotation, post, device, (hipStream_t)stream, 0, row_first, row_count);
+}
+
 int lrp_reproject_multi_device(const lrp_image *in, lrp_image *outs, int n_out, int num_samples,
                                int interpolation, const float *rotations, const lrp_post *post, int device,
                                void *stream) {
@@ -403,6 +425,124 @@ int lrp_reproject_multi_device(const lrp_image *in, lrp_image *outs, int n_out, 
     if (st != LRP_OK) return st;
   }
   return LRP_OK;
+}
+
+namespace {
+// Per participant of lrp_reproject_multi: a stream and grow-only buffers, kept for the next call.
+struct MultiPeer {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t source_ready = nullptr;
+  Buffer src, out;
+};
+std::mutex g_multi_mutex; // one multi-GPU job at a time (it uses every GPU it is given)
+std::vector<MultiPeer> g_multi_peers;
+} // namespace
+
+int lrp_reproject_multi(const lrp_image *in, lrp_image *outs, int n_out, int num_samples, int interpolation,
+                        const float *rotations, const lrp_post *post, const int *devices, int n_devices) {
+  if (n_out < 0 || (n_out > 0 && !outs) || !devices || n_devices < 1 || n_devices > 64)
+    return fail(LRP_ERR_BAD_ARG, "bad output array or device list");
+  for (int i = 0; i < n_out; ++i) {
+    int st = validate(in, &outs[i], interpolation, true);
+    if (st != LRP_OK) return st;
+  }
+  for (int d = 0; d < n_devices; ++d) {
+    int st = select_device(devices[d]);
+    if (st != LRP_OK) return st;
+  }
+  if (n_out == 0 || num_samples <= 0) return LRP_OK;
+  std::lock_guard<std::mutex> lock(g_multi_mutex);
+  if (g_multi_peers.size() < (size_t)n_devices) g_multi_peers.resize((size_t)n_devices);
+  const size_t in_bytes = image_bytes(*in);
+  // every participant renders band d of every output: its output buffer holds its bands back to back
+  auto band = [&](const lrp_image &o, int d, int &first, int &count) {
+    first = (int)((long long)o.height * d / n_devices);
+    count = (int)((long long)o.height * (d + 1) / n_devices) - first;
+  };
+  for (int d = 0; d < n_devices; ++d) {
+    MultiPeer &p = g_multi_peers[(size_t)d];
+    LRP_HIP_TRY(hipSetDevice(devices[d]));
+    if (p.device != devices[d]) { // the slot served another GPU before: its buffers live there
+      if (p.device >= 0) {
+        (void)hipSetDevice(p.device);
+        p.src.release();
+        p.out.release();
+        if (p.stream) (void)hipStreamDestroy(p.stream);
+        if (p.source_ready) (void)hipEventDestroy(p.source_ready);
+        p.stream = nullptr;
+        p.source_ready = nullptr;
+        LRP_HIP_TRY(hipSetDevice(devices[d]));
+      }
+      p.device = devices[d];
+    }
+    if (!p.stream) LRP_HIP_TRY(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+    if (!p.source_ready) LRP_HIP_TRY(hipEventCreateWithFlags(&p.source_ready, hipEventDisableTiming));
+    size_t out_bytes = 0;
+    for (int i = 0; i < n_out; ++i) {
+      int first, count;
+      band(outs[i], d, first, count);
+      out_bytes += (size_t)count * (size_t)outs[i].width * (size_t)outs[i].channels * 4u;
+    }
+    int st = p.src.reserve(in_bytes);
+    if (st == LRP_OK) st = p.out.reserve(out_bytes ? out_bytes : 4);
+    if (st != LRP_OK) return st;
+  }
+  // the source: host -> devices[0] once, then device to device
+  MultiPeer &root = g_multi_peers[0];
+  LRP_HIP_TRY(hipSetDevice(root.device));
+  LRP_HIP_TRY(hipMemcpyAsync(root.src.ptr, in->data, in_bytes, hipMemcpyHostToDevice, root.stream));
+  LRP_HIP_TRY(hipEventRecord(root.source_ready, root.stream));
+  for (int d = 1; d < n_devices; ++d) {
+    MultiPeer &p = g_multi_peers[(size_t)d];
+    LRP_HIP_TRY(hipSetDevice(p.device));
+    int can = p.device == root.device ? 1 : 0;
+    if (!can) {
+      (void)hipDeviceCanAccessPeer(&can, p.device, root.device);
+      if (can) {
+        const hipError_t e = hipDeviceEnablePeerAccess(root.device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+        (void)hipGetLastError();
+      }
+    }
+    if (can) {
+      LRP_HIP_TRY(hipStreamWaitEvent(p.stream, root.source_ready, 0));
+      LRP_HIP_TRY(hipMemcpyPeerAsync(p.src.ptr, p.device, root.src.ptr, root.device, in_bytes, p.stream));
+    } else {
+      LRP_HIP_TRY(hipMemcpyAsync(p.src.ptr, in->data, in_bytes, hipMemcpyHostToDevice, p.stream));
+    }
+  }
+  // bands: render into the participant's buffer at the band's own row offset (the kernels address whole images),
+  // download each band to its rows of the host output
+  int result = LRP_OK;
+  for (int d = 0; d < n_devices && result == LRP_OK; ++d) {
+    MultiPeer &p = g_multi_peers[(size_t)d];
+    LRP_HIP_TRY(hipSetDevice(p.device));
+    size_t cursor = 0; // floats into p.out
+    for (int i = 0; i < n_out && result == LRP_OK; ++i) {
+      int first, count;
+      band(outs[i], d, first, count);
+      if (count == 0) continue;
+      const size_t row_floats = (size_t)outs[i].width * (size_t)outs[i].channels;
+      lrp_image din = *in, dout = outs[i];
+      din.data = (float *)p.src.ptr;
+      // a virtual whole image whose rows [first, first + count) are the buffer's [cursor, ...): only those are written
+      dout.data = (float *)p.out.ptr + cursor - (size_t)first * row_floats;
+      result = enqueue_reproject(&din, &dout, num_samples, interpolation, rotations ? rotations + 9 * i : nullptr, post, p.device,
+                                 p.stream, 0, first, count);
+      if (result != LRP_OK) break;
+      LRP_HIP_TRY(hipMemcpyAsync(outs[i].data + (size_t)first * row_floats, (float *)p.out.ptr + cursor, (size_t)count * row_floats * 4u,
+                                 hipMemcpyDeviceToHost, p.stream));
+      cursor += (size_t)count * row_floats;
+    }
+  }
+  for (int d = 0; d < n_devices; ++d) {
+    MultiPeer &p = g_multi_peers[(size_t)d];
+    (void)hipSetDevice(p.device);
+    const hipError_t e = hipStreamSynchronize(p.stream);
+    if (e != hipSuccess && result == LRP_OK) result = hip_fail(e, "hipStreamSynchronize");
+  }
+  return result;
 }
 
 int lrp_reproject_batch_device(const lrp_image *ins, lrp_image *outs, int n, int num_samples, int interpolation,

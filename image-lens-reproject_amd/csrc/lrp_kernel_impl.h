@@ -27,7 +27,7 @@ __global__ __launch_bounds__(kThreads) void reproject_kernel(const KParams P) {
   if (!xcd_tile(P.tiles_x, P.tiles_y, tx, ty)) return;
   const int x = tx * kTileW + (int)(threadIdx.x % kTileW);
   const int y = P.y_offset + ty * kTileH + (int)(threadIdx.x / kTileW);
-  if (x >= P.out_w || y >= P.out_h) return;
+  if (x >= P.out_w || y >= P.y_end) return;
 
   // pixel centre in image-centred coordinates (src/reproject.cpp:287-288)
   const float cx = ((float)x + 0.5f) - (float)P.out_w * 0.5f;
@@ -86,7 +86,7 @@ template <int Interp, int CH> struct KernelTable {
 template <int Interp>
 hipError_t launch_interp(KParams P, int out_idx, int in_mode, hipStream_t stream) {
   P.tiles_x = (P.out_w + kTileW - 1) / kTileW;
-  const int rows = P.out_h - P.y_offset;
+  const int rows = P.y_end - P.y_offset;
   P.tiles_y = (rows + kTileH - 1) / kTileH;
   const int n_tiles = P.tiles_x * P.tiles_y;
   if (n_tiles <= 0) return hipSuccess;

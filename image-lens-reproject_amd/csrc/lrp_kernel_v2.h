@@ -754,7 +754,7 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
 #pragma unroll
       for (int k = 0; k < kT2Rows; ++k) {
         const int yk = y_first + k;
-        const int ye = yk < P.out_h ? yk : P.out_h - 1; // wave-uniform
+        const int ye = yk < P.y_end ? yk : P.y_end - 1; // wave-uniform
         float sx, sy;
         pixel_source<OutLens, InMode>(P, col, ye, ssy, sx, sy);
         const Px<CH> s = sample_direct<Interp, Loop, CH>(P, src, sx, sy);
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
 #pragma unroll
     for (int k = 0; k < kT2Rows; ++k) {
       const int yk = y_first + k;
-      if (yk < P.out_h) {
+      if (yk < P.y_end) {
         if (ns == 1)
           store_px<CH, true>(P, (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x, acc[k]);
         else
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
   // the coordinate math (pixel_plane) runs once for the four of them.
   constexpr bool quad = Quad;
   const int qw = quad ? (P.out_w + 1) >> 1 : P.out_w; // columns / rows enumerated by the launch
-  const int qh = quad ? (P.out_h + 1) >> 1 : P.out_h;
+  const int qh = quad ? (P.out_h + 1) >> 1 : P.y_end; // (a row band: rows beyond it re-render its last row)
   // workgroup tile = 16 kWinWaves x 16G (x 16 of the quadrant when mirrored): one strip per wavefront
   int prow, pcol; // this lane's pixel of a pass
   win_lane_pixel(lane, prow, pcol);
@@ -1497,7 +1497,7 @@ template <int Interp> hipError_t launch_tile_interp(KParams P, int out_idx, int 
     P.tiles_y = ((P.out_h + 1) / 2 + tile_h - 1) / tile_h;
   } else {
     P.tiles_x = (P.out_w + kT2W - 1) / kT2W;
-    const int rows = P.out_h - P.y_offset;
+    const int rows = P.y_end - P.y_offset;
     P.tiles_y = (rows + tile_h - 1) / tile_h;
   }
   const int n_tiles = P.tiles_x * P.tiles_y;
@@ -1528,7 +1528,7 @@ template <bool Quad, int CH> struct WinKernelTable {
 // num_samples must be 1 (the pipeline keeps no accumulator across sub-samples).
 template <bool Quad, int CH>
 inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, hipStream_t stream) {
-  const int rows = P.out_h - P.y_offset;
+  const int rows = P.y_end - P.y_offset;
   if (Quad) {
     // the launch enumerates the top-left quadrant; a wavefront renders a block and its three mirror images
     P.tiles_x = ((P.out_w + 1) / 2 + kBlkW * kWinWaves - 1) / (kBlkW * kWinWaves);

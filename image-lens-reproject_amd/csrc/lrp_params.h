@@ -55,6 +55,7 @@ struct KParams {
   float reinhard;
   int32_t tiles_x, tiles_y; // output tiling of the launch
   int32_t y_offset;         // first output row of this launch (row-band launches)
+  int32_t y_end;            // one past the last output row of this launch (out_h for a whole image)
   // ---- tile kernel (lrp_kernel_v2.h) only ----------------------------------
   // Separable output-lens terms, one entry per (column, sub-sample) and per
   // (row, sub-sample), built by lrp_tables.hip with the same operations the

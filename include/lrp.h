@@ -153,6 +153,13 @@ int lrp_reproject_multi_device(const lrp_image *in, lrp_image *outs, int n_out, 
                                int interpolation, const float *rotations, const lrp_post *post,
                                int device, void *stream);
 
+/* Rows [row_first, row_first + row_count) of the output only (out->data is the whole image; the rows
+ * of the reference loop are independent, src/reproject.cpp:284): what a job that splits one output over
+ * several GPUs or streams launches.  The bytes are those of the same rows of a whole-image call. */
+int lrp_reproject_rows_device(const lrp_image *in, lrp_image *out, int num_samples, int interpolation,
+                              const float *rotation, const lrp_post *post, int row_first, int row_count,
+                              int device, void *stream);
+
 /* n images of ONE geometry (same sizes, channel count, lenses; one rotation, one
  * post setting — a directory of frames from one camera, src/main.cpp:540-622) on
  * device-resident buffers: rendered by one kernel launch per 16 images instead of
@@ -161,6 +168,19 @@ int lrp_reproject_multi_device(const lrp_image *in, lrp_image *outs, int n_out, 
 int lrp_reproject_batch_device(const lrp_image *ins, lrp_image *outs, int n, int num_samples,
                                int interpolation, const float *rotation, const lrp_post *post,
                                int device, void *stream);
+
+/* ---- one source, several outputs, several GPUs (BASELINE configs[4]) ---------- */
+
+/* One host source, n_out host outputs (lenses in outs[i].lens, rotations + 9 * i or none): the
+ * cubemap job — six reference invocations over one 8192^2 panorama — on `n_devices` GPUs.
+ * The source is uploaded ONCE, to devices[0], and copied to the other GPUs device to device
+ * (hipMemcpyPeerAsync over xGMI where peer access is available, a second upload where not);
+ * every GPU then renders band d of n_devices of EVERY output (rows are independent; a pole
+ * face costs three times a side face, bands of every face balance that) and downloads its bands
+ * straight into outs[i].data.  No collective, no exchange of results.  The bytes are those of
+ * n_out lrp_reproject calls on one GPU.  devices may name a GPU more than once. */
+int lrp_reproject_multi(const lrp_image *in, lrp_image *outs, int n_out, int num_samples, int interpolation,
+                        const float *rotations, const lrp_post *post, const int *devices, int n_devices);
 
 /* ---- batches of independent images (the reference's --input-dir path) ------ */
 
