@@ -305,6 +305,29 @@ def reproject_batch(in_images, out_images, num_samples, interpolation, rotation_
     _check(st)
 
 
+class PreparedBatch:
+    """The arguments of one lrp_reproject_batch_device call, marshalled once: launch() is then a single
+    foreign call (a directory of frames of one geometry is launched many times with the same descriptors)."""
+
+    def __init__(self, in_images, out_images, num_samples, interpolation, rotation_matrix=None, post=None, device=None):
+        if len(in_images) != len(out_images) or not in_images:
+            raise ValueError("in_images and out_images must be non-empty and of equal length")
+        self._lib = _native.load()
+        self._keep = (list(in_images), list(out_images))
+        self._n = len(in_images)
+        self._ins = (LrpImage * self._n)(*[i.to_c() for i in in_images])
+        self._outs = (LrpImage * self._n)(*[o.to_c() for o in out_images])
+        self._rot_keep, self._rot = _rotation_arg(rotation_matrix)
+        self._post = LrpPost(float(post[0]), float(post[1])) if post is not None else None
+        self._args = (int(num_samples), int(interpolation))
+        self._dev = in_images[0].data.device.index if device is None else device
+
+    def launch(self, stream=None):
+        _check(self._lib.lrp_reproject_batch_device(self._ins, self._outs, self._n, self._args[0], self._args[1], self._rot,
+                                                    ctypes.byref(self._post) if self._post is not None else None, self._dev,
+                                                    _stream_handle(stream)))
+
+
 def post_process(image, exposure, reinhard, device=None, stream=None):
     """reproject::post_process (src/reproject.cpp:421-437), in place."""
     lib = _native.load()
