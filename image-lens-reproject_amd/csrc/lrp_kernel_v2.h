@@ -320,6 +320,25 @@ __device__ __forceinline__ Px<CH> bicubic_taps(__amdgpu_buffer_rsrc_t rsrc, uint
 #pragma unroll
       for (int i = 0; i < 4; ++i) t[i][j] = tap(v[i], r[j]);
   }
+  if constexpr ((CH & 1) != 0) {
+    // the single (third / fifth) channel of two tap columns shares a packed vertical cubic: same operations, each
+    // half rounded like the scalar instruction; the paired channels go through cubic_px's packed path as before
+    Px<CH> k[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      k[i] = px_zero<CH>();
+      k[i].lo = catmull_rom2(t[i][0].lo, t[i][1].lo, t[i][2].lo, t[i][3].lo, fy, hfy);
+      if constexpr (CH >= 4) k[i].hi = catmull_rom2(t[i][0].hi, t[i][1].hi, t[i][2].hi, t[i][3].hi, fy, hfy);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+      const f2 e = catmull_rom2(f2{t[i][0].e, t[i + 1][0].e}, f2{t[i][1].e, t[i + 1][1].e}, f2{t[i][2].e, t[i + 1][2].e},
+                                f2{t[i][3].e, t[i + 1][3].e}, fy, hfy);
+      k[i].e = e.x;
+      k[i + 1].e = e.y;
+    }
+    return cubic_px<CH>(k[0], k[1], k[2], k[3], fx, hfx);
+  }
   const Px<CH> k0 = cubic_px<CH>(t[0][0], t[0][1], t[0][2], t[0][3], fy, hfy);
   const Px<CH> k1 = cubic_px<CH>(t[1][0], t[1][1], t[1][2], t[1][3], fy, hfy);
   const Px<CH> k2 = cubic_px<CH>(t[2][0], t[2][1], t[2][2], t[2][3], fy, hfy);
@@ -1308,11 +1327,11 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
 #pragma unroll
       for (int j = 0; j < 4; ++j) t[j][r] = d[r * cur.pitch + j];
     if (last_pass) next_window();
-    const float k0 = catmull_rom(t[0][0], t[0][1], t[0][2], t[0][3], fy, hfy);
-    const float k1 = catmull_rom(t[1][0], t[1][1], t[1][2], t[1][3], fy, hfy);
-    const float k2 = catmull_rom(t[2][0], t[2][1], t[2][2], t[2][3], fy, hfy);
-    const float k3 = catmull_rom(t[3][0], t[3][1], t[3][2], t[3][3], fy, hfy);
-    return catmull_rom(k0, k1, k2, k3, fx, hfx);
+    // the four vertical cubics as two packed ones (tap columns 0 | 1 and 2 | 3 in the halves of a register pair:
+    // each half of a v_pk_* rounds like the scalar instruction), then the horizontal one
+    const f2 k01 = catmull_rom2(f2{t[0][0], t[1][0]}, f2{t[0][1], t[1][1]}, f2{t[0][2], t[1][2]}, f2{t[0][3], t[1][3]}, fy, hfy);
+    const f2 k23 = catmull_rom2(f2{t[2][0], t[3][0]}, f2{t[2][1], t[3][1]}, f2{t[2][2], t[3][2]}, f2{t[2][3], t[3][3]}, fy, hfy);
+    return catmull_rom(k01.x, k01.y, k23.x, k23.y, fx, hfx);
   };
 #pragma unroll 1
   for (int g = 0; g < G; ++g) {

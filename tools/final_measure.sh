@@ -16,4 +16,5 @@ timeout 300 ./tools/staged_bench > $out/staged.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof_bench -- python3 $R/bench.py --no-cpu-baseline > $R/$out/prof_bench.log 2>&1; echo "rocprof rc=$?"
 cat $R/$out/prof_bench/*/*kernel_stats.csv
+bash $R/tools/collect_traffic.sh > $R/$out/traffic.log 2>&1; tail -2 $R/$out/traffic.log
 cat $R/$out/bench.json

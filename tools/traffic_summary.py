@@ -14,6 +14,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402  (kernel_source_sha: the stamp bench.py checks before it trusts this file)
+
 src_dir, out_path = sys.argv[1], sys.argv[2]
 KNOWN = 4096 * 4096 * 4 * 4
 
@@ -41,8 +44,10 @@ if cal:
 names = {"reproject_bicubic_win_kernel<0, 1,": "fisheye_to_rect_bicubic",
          "reproject_bicubic_win_kernel<0, 3,": "equirect_to_rect_bicubic",
          "reproject_tile_kernel<1, 3, 1, 4>": "equirect_to_fisheye_bilinear",
-         "reproject_tile_kernel<0, 3, 0, 4>": "equirect_to_rect_nearest"}
-result = {"_calibration": calibration,
+         "reproject_tile_kernel<0, 3, 0, 4>": "equirect_to_rect_nearest",
+         "reproject_bicubic_win_kernel<4, 0,": "rect_to_equirect_bicubic"}
+result = {"_kernel_source_sha": bench.kernel_source_sha(),
+          "_calibration": calibration,
           "_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/traffic_probe.py; KiB -> "
                      "bytes; reads scaled by the factor measured on the calibration kernel (guide: 2.0 for 16 B/lane "
                      "streams on gfx950), writes taken as reported"}
