@@ -234,6 +234,9 @@ def parse_args():
                     help="torch.distributed backend of the barrier / max-time reduction for --gpus > 1 (nccl = RCCL; "
                          "gloo lets two ranks share one GPU in a smoke test of the multi-rank path)")
     ap.add_argument("--checksums-file", default="", help="rank 0 writes the per-image checksum list (JSON) here")
+    ap.add_argument("--settle-seconds", type=float, default=2.0,
+                    help="untimed launches of the workload before the warm-up steps: the chip takes its sustained "
+                         "(power-limited) clock only after a while under load, and a first launch after idle is 10-25 %% slower")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -412,6 +415,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < args.settle_seconds:
+        step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -460,6 +467,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "timed_region_s": elapsed,
+            "settle_seconds": args.settle_seconds,
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,

@@ -23,7 +23,7 @@ SIZE, BATCH = 512, 24
 def run_bench(n, tmp_path, extra=()):
     out = tmp_path / f"sums_{n}.json"
     args = ["--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", str(BATCH), "--size", str(SIZE),
-            "--no-cpu-baseline", "--secondary", "", "--dist-backend", "gloo", "--checksums-file", str(out), *extra]
+            "--no-cpu-baseline", "--secondary", "", "--settle-seconds", "0", "--dist-backend", "gloo", "--checksums-file", str(out), *extra]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
