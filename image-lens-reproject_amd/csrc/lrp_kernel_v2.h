@@ -555,9 +555,39 @@ __device__ __forceinline__ Px<CH> sample_direct(const KParams &P, const SrcView 
       // (src/reproject.cpp:114-131 reduce to int(s) - 1 .. int(s) + 2, f = s - int(s))
       const float tx_ = __builtin_truncf(sx), ty_ = __builtin_truncf(sy);
       const float fx = sx - tx_, fy = sy - ty_;
-      const uint32_t v0 = __umul24((uint32_t)((int)ty_ - 1), row_bytes) + (uint32_t)((int)tx_ - 1) * T;
+      uint32_t v0 = __umul24((uint32_t)((int)ty_ - 1), row_bytes) + (uint32_t)((int)tx_ - 1) * T;
+#if defined(LRP_ABLATE_COOP) // timing experiment (wrong results): the tap loads in the access pattern of four lanes per pixel
+      {
+        // each instruction fetches, for 16 pixels, the 64 contiguous bytes of one tap row (lane = 4 * pixel + tap column)
+        Px<CH> acc = px_zero<CH>();
+        const int lane_ = (int)(threadIdx.x & 63u);
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          const uint32_t vb = (uint32_t)__shfl((int)v0, 16 * sub + (lane_ >> 2)) + (uint32_t)(lane_ & 3) * T;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) px_add<CH>(acc, texel_at<CH>(rsrc, vb, (uint32_t)j * row_bytes));
+        }
+        const float hfx_ = 0.5f * fx, hfy_ = 0.5f * fy;
+        const Px<CH> k0 = cubic_px<CH>(acc, acc, acc, acc, fy, hfy_);
+        Px<CH> k1 = k0, k2 = k0, k3 = k0;
+        k1.lo += fx; k2.lo += fy; k3.lo += hfx_;
+        s = cubic_px<CH>(cubic_px<CH>(k0, k1, k2, k3, fy, hfy_), cubic_px<CH>(k1, k2, k3, k0, fy, hfy_),
+                         cubic_px<CH>(k2, k3, k0, k1, fy, hfy_), cubic_px<CH>(k3, k0, k1, k2, fy, hfy_), fx, hfx_);
+      }
+#elif defined(LRP_ABLATE_ONETAP) // timing experiment (wrong results): one tap load per pixel, the arithmetic of all five cubics
+      {
+        const Px<CH> acc = texel_at<CH>(rsrc, v0, 0u);
+        const float hfx_ = 0.5f * fx, hfy_ = 0.5f * fy;
+        const Px<CH> k0 = cubic_px<CH>(acc, acc, acc, acc, fy, hfy_);
+        Px<CH> k1 = k0, k2 = k0, k3 = k0;
+        k1.lo += fx; k2.lo += fy; k3.lo += hfx_;
+        s = cubic_px<CH>(cubic_px<CH>(k0, k1, k2, k3, fy, hfy_), cubic_px<CH>(k1, k2, k3, k0, fy, hfy_),
+                         cubic_px<CH>(k2, k3, k0, k1, fy, hfy_), cubic_px<CH>(k3, k0, k1, k2, fy, hfy_), fx, hfx_);
+      }
+#else
       s = bicubic_taps<CH, true, LowReg>(rsrc, v0, v0 + T, v0 + 2u * T, v0 + 3u * T, 0u, row_bytes, 2u * row_bytes,
                                  3u * row_bytes, fx, fy);
+#endif
     } else {
       int xs[4], ys[4];
       bicubic_indices<Loop>(sx, sy, in_w, in_h, xs, ys);
@@ -885,6 +915,9 @@ __device__ __forceinline__ void win_lane_pixel(int lane, int &prow, int &pcol) {
 #define LRP_WIN_MIN_PITCH 0
 #endif
 
+#ifndef LRP_WIN_CORNER
+#define LRP_WIN_CORNER 1 // blocks wholly beyond one corner of the source: one evaluation per block (0: per pixel)
+#endif
 #ifndef LRP_WIN_STRIP_PLAN
 #define LRP_WIN_STRIP_PLAN 1 // mirrored strips: one reduction for the windows of all four mirror blocks (0: one per block)
 #endif
@@ -893,8 +926,11 @@ __device__ __forceinline__ void win_lane_pixel(int lane, int &prow, int &pcol) {
 __device__ unsigned g_tier_stats[4];
 #endif
 
-// Source coordinates and window of one 16 x 16 block (4 pixels per lane).
-struct WinBlock {
+// Source coordinates and window of one 16 x 16 block (4 pixels per lane).  Fat: the per-half plane offsets are
+// stored (two more wave-uniform words per block) instead of re-derived with a few scalar instructions in every
+// pass — the mirrored kernels have the SGPRs for that, the plain-block kernels, which also carry the next block's
+// coordinates, do not.
+template <bool Fat> struct WinBlockT {
   float sx[4], sy[4];
   int x_lo, y_lo, bw, bh, pitch; // window origin, size and row pitch in texels (wave-uniform)
   // slot distance from window row r to r + 1 (+-pitch) and slot of window row 0; without the signed-pitch
@@ -908,16 +944,30 @@ struct WinBlock {
   __device__ __forceinline__ int spitch() const { return pitch; }
   __device__ __forceinline__ int org() const { return 0; }
 #endif
-  // Wave-uniform flags are ints, not bools: a bool that crosses the block loop gets materialised
-  // through a VGPR (v_cndmask 0/1 + v_cmp) at every use; an int stays in an SGPR (s_cmp).
-  int staged;                    // taps come from the LDS window
-  // coefficient tier (wave-uniform): per half of the block (passes 0-1, 2-3) the first
-  // int(sy) and the number of distinct int(sy) rows; a coefficient row has the window's pitch
+  // Wave-uniform state is kept small and integral: the kernel sits at the SGPR limit (every word held across the
+  // block loop for `cur` and `nxt` pushes another one into a VGPR lane), and a bool that crosses the block loop
+  // gets materialised through a VGPR (v_cndmask 0/1 + v_cmp) at every use.
+  // tier: bit 0 staged (taps come from the LDS window), bit 1 coef (coefficient tier), bit 2 whole (one set of
+  // planes for the block: iy0 / iyn equal for both halves), bits 3-5 corner (0, or 1 + (x beyond the right edge)
+  // + 2 (y beyond the bottom edge): every pixel of the block lies beyond the same corner of the source — all its
+  // taps clamp to that one corner texel with weights 0 / 1)
+  int tier;
+  __device__ __forceinline__ int staged() const { return tier & 1; }
+  __device__ __forceinline__ int coef() const { return tier & 2; }
+  __device__ __forceinline__ int whole() const { return tier & 4; }
+  __device__ __forceinline__ int corner() const { return tier >> 3; }
+  // coefficient tier: per half of the block (passes 0-1, 2-3) the first int(sy) and the number of distinct
+  // int(sy) rows; a coefficient row has the window's pitch
   int iy0[2], iyn[2], c_plane, c_base; // plane size and first slot of plane 0 (behind the raw window + a margin)
-  int coef, whole;                     // whole: one set of planes for the block (iy0 / iyn equal for both halves)
-  // slot of texel (int(sx) - 1, int(sy)) in the raw window = tap_base + int(sy) * spitch + int(sx); the slot of the pixel's
-  // first coefficient vector in plane 0 of half h lies c_delta[h] slots further
-  int tap_base, c_delta[2];
+  // slot of texel (int(sx) - 1, int(sy)) in the raw window = tap_base + int(sy) * spitch + int(sx)
+  int tap_base;
+  // ... and the slot of the pixel's first coefficient vector in plane 0 of half h lies this much further
+  int c_delta_stored[2];
+  __device__ __forceinline__ int c_delta_value(int h) const {
+    const int c_org = c_base + (spitch() < 0 ? (iyn[h] - 1) * pitch : 0); // plane slot of the first origin row
+    return c_org - iy0[h] * spitch() - (1 + x_lo) - tap_base;
+  }
+  __device__ __forceinline__ int c_delta(int h) const { return Fat ? c_delta_stored[h] : c_delta_value(h); }
 };
 
 // One wavefront walks its strip of `blocks_per_wave` blocks (plain: top to bottom; mirrored: a
@@ -942,6 +992,7 @@ template <int OutLens, int InMode, bool Quad, int CH>
 #define LRP_WIN_MINWAVES5 3 // RGBAZ: 168 VGPRs (the 80 registers of a direct-path tap set do not fit 128 without spilling)
 #endif
 __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_MINWAVES) void reproject_bicubic_win_kernel(const KParams Pk) {
+  using WinBlock = WinBlockT<Quad>;
   static_assert(CH == 3 || CH == 4 || CH == 5, "window kernel: RGB, RGBA or RGBAZ");
   static_assert(CH != 5 || LRP_WIN_SIGNED_PITCH == 0, "the RGBAZ depth plane assumes top-down window rows");
   const KParams P = batch_frame(Pk);
@@ -1047,7 +1098,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
 #endif
         }
       }
-      b.staged = (b.bw <= 64 && raw_slots(b) <= kWinCap) ? 1 : 0;
+      b.tier = (b.bw <= 64 && raw_slots(b) <= kWinCap) ? 1 : 0;
       // coefficient tier: three planes of pitch x iyn[h] tap-column origins behind the raw window
       b.iy0[0] = ya_first;
       b.iyn[0] = ya_last - ya_first + 1;
@@ -1055,31 +1106,46 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
       b.iyn[1] = yb_last - yb_first + 1;
       // strongly magnified blocks have room for the planes of ALL their origin rows: one
       // precompute per block (fuller lanes: e.g. 132 origins in 3 trips instead of 2 x 77 in 4)
-      b.whole = (raw_slots(b) + kPlanes * b.pitch * (y_last - y_first + 1) <= kWinCap) ? 1 : 0;
-      if (b.whole) {
+      if (raw_slots(b) + kPlanes * b.pitch * (y_last - y_first + 1) <= kWinCap) b.tier |= 4;
+      if (b.whole()) {
         b.iy0[0] = b.iy0[1] = y_first;
         b.iyn[0] = b.iyn[1] = y_last - y_first + 1;
       }
       b.c_plane = b.pitch * max(b.iyn[0], b.iyn[1]);
-      b.coef = (kWinCoef && P.win_coef != 0 && b.staged != 0 && raw_slots(b) + kPlanes * b.c_plane <= kWinCap) ? 1 : 0;
+      if (kWinCoef && P.win_coef != 0 && b.staged() && raw_slots(b) + kPlanes * b.c_plane <= kWinCap) b.tier |= 2;
       // planes behind the raw window plus, where there is room, one row and one column of slack:
       // the next block's (slightly different) window can then be requested while this block's
       // planes are still being read (see next_window)
       b.c_base = min(raw_slots(b) + b.pitch + b.bh + 1, kWinCap - kPlanes * b.c_plane);
       b.tap_base = b.org() - b.y_lo * b.spitch() - (1 + b.x_lo);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int c_org = b.c_base + (b.spitch() < 0 ? (b.iyn[h] - 1) * b.pitch : 0); // plane slot of the first origin row
-        b.c_delta[h] = c_org - b.iy0[h] * b.spitch() - (1 + b.x_lo) - b.tap_base;
+      if constexpr (Quad) {
+        b.c_delta_stored[0] = b.c_delta_value(0);
+        b.c_delta_stored[1] = b.c_delta_value(1);
       }
+    } else if constexpr (!Loop) {
+      // Out of view beyond one CORNER of the source (most of a narrow view inside a panorama: 37 % of the blocks of
+      // rectilinear -> equirectangular).  s <= -2: the four tap indices int(s - 1) .. int(s + 2) clamp to 0 and the
+      // weight clamp(s - 0, 0, 1) is 0; extent + 1 <= s < 2^31: they clamp to extent - 1, the weight is 1
+      // (src/reproject.cpp:114-131; from 2^31 on cvttss2si gives INT_MIN and the index clamps to 0 instead).  Then
+      // every pixel of the block is the same function of the same corner texel: evaluated once per block.
+      // On the raw bits: negative floats order backwards as signed integers, -2.0 .. -inf is 0xC0000000 .. 0xFF800000
+      // (a negative NaN lies above that range, a positive one above 2^31).
+      auto side = [](int lo, int hi, int extent) { // 0: not beyond one side; 1: beyond the low side; 2: beyond the high side
+        if (lo >= (int)0xC0000000 && hi <= (int)0xFF800000) return 1;
+        if (lo >= (int)f2u((float)(extent + 1)) && hi < (int)f2u(2147483648.0f)) return 2;
+        return 0;
+      };
+      const int sx_side = side(w_lo_x, w_hi_x, P.in_w), sy_side = side(w_lo_y, w_hi_y, P.in_h);
+      if (LRP_WIN_CORNER != 0 && sx_side != 0 && sy_side != 0) b.tier = (1 + (sx_side - 1) + 2 * (sy_side - 1)) << 3;
     }
   };
   auto clear_block = [](WinBlock &b) {
-    b.staged = b.coef = b.whole = 0;
+    b.tier = 0;
 #if LRP_WIN_SIGNED_PITCH != 0
     b.spitch_ = b.org_ = 0;
 #endif
-    b.x_lo = b.y_lo = b.bw = b.bh = b.pitch = b.c_plane = b.c_base = b.tap_base = b.c_delta[0] = b.c_delta[1] = 0;
+    b.x_lo = b.y_lo = b.bw = b.bh = b.pitch = b.c_plane = b.c_base = b.tap_base = 0;
+    b.c_delta_stored[0] = b.c_delta_stored[1] = 0;
     b.iy0[0] = b.iy0[1] = b.iyn[0] = b.iyn[1] = 0;
   };
   // One pixel's contribution to the extremes.  Per pixel only the exactness half of interior()
@@ -1204,8 +1270,26 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
       plan_window(b, e.lo_x, e.hi_x, e.lo_y[0], e.hi_y[0], e.lo_y[1], e.hi_y[1]);
     }
   };
+  // the one value of a corner block: sample_bicubic with all 16 taps on the corner texel (sample_direct's
+  // one-column-and-one-row case, same operations)
+  auto corner_value = [&](const WinBlock &b) {
+    const int xh = (b.corner() - 1) & 1, yh = (b.corner() - 1) >> 1;
+    const float fx = xh ? 1.0f : 0.0f, fy = yh ? 1.0f : 0.0f; // the clamped weights (src/reproject.cpp:130-131)
+    const float hfx = 0.5f * fx, hfy = 0.5f * fy;
+    const uint32_t off = (uint32_t)(yh ? P.in_h - 1 : 0) * src.row_bytes + (uint32_t)(xh ? in_w - 1 : 0) * (4u * CH);
+    if constexpr (CH == 5) {
+      const Px<5> t = texel_at<5>(src.rsrc, off, 0u);
+      const Px<5> k = cubic_px<5>(t, t, t, t, fy, hfy);
+      const Px<5> r = cubic_px<5>(k, k, k, k, fx, hfx);
+      return Rgba{r.lo, r.hi, r.e};
+    } else {
+      const Px<4> t = texel_at<4>(src.rsrc, off, 0u); // (RGB: a 16-byte read of a 12-byte texel, fourth component unused)
+      const Px<4> k = cubic_px<4>(t, t, t, t, fy, hfy);
+      return cubic_px<4>(k, k, k, k, fx, hfx);
+    }
+  };
   auto issue = [&](int g, const WinBlock &b) {
-    if (b.staged) {
+    if (b.staged()) {
       // LDS-DMA, one window row per instruction, lanes beyond the width masked off
       float4 *const win = win0 + (g & (kWinBuffers - 1)) * kWinCap;
       const float4 *gp = src4 + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane));
@@ -1312,8 +1396,35 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
   bool dma_early = false; // the pending window was requested before its block's last store
   auto next_window = [&]() {
     // while this block's coefficient planes are still being read the next raw window must stay in front of them
-    dma_early = g_loop + 1 < G && (!(kWinCoef && cur.coef) || raw_slots(nxt) <= cur.c_base);
+    dma_early = g_loop + 1 < G && (!(kWinCoef && cur.coef()) || raw_slots(nxt) <= cur.c_base);
     if (dma_early) issue(g_loop + 1, nxt);
+  };
+  // The result of pass k of block g: num_samples == 1, (0.0f + s) * normalize (src/reproject.cpp:334-341), store.
+  auto emit = [&](int g, int k, const Rgba &s) {
+    Rgba a4 = px_zero<4>();
+    px_add<4>(a4, s);
+    if constexpr (CH == 5) a4.e = 0.0f + s.e;
+    const Px<CH> a{a4.lo, CH >= 4 ? a4.hi : f2{0.0f, 0.0f}, CH == 3 ? a4.hi.x : a4.e};
+    // Every lane stores: lanes / rows beyond the image have recomputed the pixel they were
+    // clamped to (xe, ye) and write that same value to that same address again, so the
+    // store is issued by every wavefront (the vmcnt(1) below counts on it).
+    // (the four clamped rows of a mirrored strip are loop-invariant; hoisted they occupy four VGPRs for the whole
+    // strip — which spilled — so the row is re-derived from an opaque copy here: an add and a min per pass)
+    int y_base = y_lane;
+    if constexpr (Quad && kInEqr) asm volatile("" : "+v"(y_base));
+    const int yk = y_base + (quad ? 0 : kBlkH * g) + kPassRows * k;
+    const int yc = yk < qh ? yk : qh - 1;
+    const int xo = (quad && (g & 1)) ? P.out_w - 1 - xe : xe; // mirrored blocks write the mirrored pixel
+    const int yo = (quad && (g >> 1)) ? P.out_h - 1 - yc : yc;
+#if defined(LRP_NO_STORE) // timing experiment: almost no output traffic
+    if (a.lo.x == 12345.678f) store_px<CH, true>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
+#elif defined(LRP_STORE_SMALL) // timing experiment (wrong results): every store issued, all of them into one 1 MiB region (stays in L2)
+    store_px<CH, true>(P, ((uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo) & 0xFFFFu, a);
+#elif defined(LRP_STORE_ROW) // timing experiment (wrong results): the four rows of a pass written as one contiguous 1 KiB run
+    store_px<CH, true>(P, ((uint32_t)(yo & ~3) * (uint32_t)P.out_w + (uint32_t)(xo & ~15) * 4u + (uint32_t)((yo & 3) * 16 + (xo & 15))), a);
+#else
+    store_px<CH, true>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
+#endif
   };
   // RGBAZ: the depth channel of one pixel from the float plane behind the colour window.  `slot` is the
   // window slot of the pixel's first tap (int(sx) - 1, int(sy) - 1); bicubicInterpolate's order: four
@@ -1347,13 +1458,27 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
 #endif
     if (kWinBuffers == 2 && g + 1 < G) issue(g + 1, nxt);
     const float4 *const win = win0 + (g & (kWinBuffers - 1)) * kWinCap;
+    if (cur.corner() != 0) {
+      // every pixel of this block is one value: no taps, no per-pixel arithmetic — four stores.  The next block's
+      // window is requested in front of the last store, as in the last pass of an ordinary block.
+      const Rgba cs = corner_value(cur);
+      if (Quad && g + 1 < G) coords(g + 1, nxt);
+      emit(g, 0, cs);
+      emit(g, 1, cs);
+      emit(g, 2, cs);
+      if (kWinBuffers == 1 && LRP_ABLATE == 0) next_window();
+      emit(g, 3, cs);
+      if (kWinBuffers == 1 && (LRP_ABLATE != 0 || !dma_early) && g + 1 < G) issue(g + 1, nxt);
+      cur = nxt;
+      continue;
+    }
 #if defined(LRP_TIER_STATS)
-    if (lane == 0) atomicAdd(&g_tier_stats[(kWinCoef && cur.coef) ? 0 : (cur.staged ? 1 : 2)], 1u);
+    if (lane == 0) atomicAdd(&g_tier_stats[(kWinCoef && cur.coef()) ? 0 : (cur.staged() ? 1 : 2)], 1u);
 #endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #if !defined(LRP_SKIP_PLANES) // timing experiment (wrong results): the coefficient phase removed
-      if (kWinCoef && cur.coef && (h == 0 || !cur.whole)) precompute(cur, h);
+      if (kWinCoef && cur.coef() && (h == 0 || !cur.whole())) precompute(cur, h);
 #endif
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -1363,7 +1488,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
         float psx = cur.sx[k], psy = cur.sy[k];
         if constexpr (Quad) quad_xy(g, k, psx, psy); // re-derived (2-4 instructions) instead of held in registers
         Rgba s;
-        if (kWinCoef && cur.coef) {
+        if (kWinCoef && cur.coef()) {
           const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
           const float fx = psx - tx_, fy = psy - ty_;
           const float hfx = 0.5f * fx, hfy = 0.5f * fy;
@@ -1371,7 +1496,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
           // of the two addresses is wave-uniform and folded into tap_base / c_delta when the block is planned
           const int tap = __mul24((int)ty_, cur.spitch()) + (int)tx_ + cur.tap_base; // window slot of (int(sx) - 1, int(sy)): the second tap row
           const float4 *tb = win + tap;
-          const float4 *ci = win + (tap + cur.c_delta[h]);
+          const float4 *ci = win + (tap + cur.c_delta(h));
           const float4 *cm = ci + cur.c_plane, *cc = cm + cur.c_plane;
           // the only reads of the raw window: the second tap row.  In the last pass they are the
           // block's last reads of it, and the next window's DMA goes right behind them
@@ -1392,7 +1517,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
           const Rgba k0 = vert(0, b0), k1 = vert(1, b1), k2 = vert(2, b2), k3 = vert(3, b3);
           s = cubic4(k0, k1, k2, k3, fx, hfx);
           if constexpr (CH == 5) s.e = depth_from_window(win, tap - cur.spitch(), fx, fy, hfx, hfy, last_pass);
-        } else if (cur.staged) {
+        } else if (cur.staged()) {
           const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
           const float fx = psx - tx_, fy = psy - ty_;
           const int slot0 = cur.org() + __mul24((int)ty_ - 1 - cur.y_lo, cur.spitch()) + ((int)tx_ - 1 - cur.x_lo);
@@ -1458,31 +1583,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
             s = sample_direct<2, Loop, 4, false, 4 * CH>(P, src, psx, psy);
           }
         }
-        // num_samples == 1: (0.0f + s) * normalize (src/reproject.cpp:334-341)
-        Rgba a4 = px_zero<4>();
-        px_add<4>(a4, s);
-        if constexpr (CH == 5) a4.e = 0.0f + s.e;
-        const Px<CH> a{a4.lo, CH >= 4 ? a4.hi : f2{0.0f, 0.0f}, CH == 3 ? a4.hi.x : a4.e};
-        // Every lane stores: lanes / rows beyond the image have recomputed the pixel they were
-        // clamped to (xe, ye) and write that same value to that same address again, so the
-        // store is issued by every wavefront (the vmcnt(1) above counts on it).
-        // (the four clamped rows of a mirrored strip are loop-invariant; hoisted they occupy four VGPRs for the whole
-        // strip — which spilled — so the row is re-derived from an opaque copy here: an add and a min per pass)
-        int y_base = y_lane;
-        if constexpr (Quad && kInEqr) asm volatile("" : "+v"(y_base));
-        const int yk = y_base + (quad ? 0 : kBlkH * g) + kPassRows * k;
-        const int yc = yk < qh ? yk : qh - 1;
-        const int xo = (quad && (g & 1)) ? P.out_w - 1 - xe : xe; // mirrored blocks write the mirrored pixel
-        const int yo = (quad && (g >> 1)) ? P.out_h - 1 - yc : yc;
-#if defined(LRP_NO_STORE) // timing experiment: almost no output traffic
-        if (a.lo.x == 12345.678f) store_px<CH, true>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
-#elif defined(LRP_STORE_SMALL) // timing experiment (wrong results): every store issued, all of them into one 1 MiB region (stays in L2)
-        store_px<CH, true>(P, ((uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo) & 0xFFFFu, a);
-#elif defined(LRP_STORE_ROW) // timing experiment (wrong results): the four rows of a pass written as one contiguous 1 KiB run
-        store_px<CH, true>(P, ((uint32_t)(yo & ~3) * (uint32_t)P.out_w + (uint32_t)(xo & ~15) * 4u + (uint32_t)((yo & 3) * 16 + (xo & 15))), a);
-#else
-        store_px<CH, true>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
-#endif
+        emit(g, k, s);
       }
     }
     if (kWinBuffers == 1 && (LRP_ABLATE != 0 || !dma_early) && g + 1 < G) issue(g + 1, nxt); // after the last read of the planes
