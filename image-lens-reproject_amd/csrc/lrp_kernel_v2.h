@@ -662,6 +662,7 @@ __device__ __forceinline__ Px<CH> sample_direct(const KParams &P, const SrcView 
   return s;
 }
 
+
 // src/reproject.cpp:338-341 + optional fused post_process (:421-437), one pixel.
 // UnitNorm: num_samples == 1, normalize == 1.0f: x * 1.0f is x for every float (the sum 0.0f + s
 // has already turned -0 into +0 and quieted a NaN), so the five multiplies are not issued.
@@ -988,6 +989,9 @@ template <bool Fat> struct WinBlockT {
 // DMA is therefore the RGBA code; the fourth component carries stale LDS contents through the
 // arithmetic (no traps are enabled) and is never stored.
 template <int OutLens, int InMode, bool Quad, int CH>
+#ifndef LRP_WIN_ALIAS_PAIRS
+#define LRP_WIN_ALIAS_PAIRS 1
+#endif
 #ifndef LRP_WIN_MINWAVES5
 #define LRP_WIN_MINWAVES5 3 // RGBAZ: 168 VGPRs (the 80 registers of a direct-path tap set do not fit 128 without spilling)
 #endif
@@ -1002,9 +1006,35 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
 
   int tx, ty;
   if (!xcd_tile(P.tiles_x, P.tiles_y, tx, ty)) return; // whole workgroup
+  // Alias pairs (LRP_WIN_ALIAS_PAIRS; mirrored strips of rectilinear -> equirectangular).  The reference has no
+  // hemisphere test: the ray of panorama pixel (x + W/2, H-1-y) is the ray of (x, y) with x and z negated, and a
+  // rectilinear projection divides by z — both pixels land on (nearly: different roundings) the same source
+  // texel, the view is rendered a second time behind the camera.  In quadrant terms the strip of tile column
+  // t and the strip of column tiles_x-1-t read the same four source windows, mirror image g of the one being
+  // image 3-g of the other.  Dealt in raster order the two are a quarter of a frame apart and the source is
+  // fetched from HBM twice; here consecutive workgroups of an XCD take the columns from
+  // both ends inwards (0, n-1, 1, n-2, ...) and the odd ones walk their mirror images in reverse, so the two
+  // strips run side by side on one L2 and ask for the same lines at the same time.
+  // Plain strips (the tables of a panorama are not mirror images bit for bit, so this is the kernel that runs):
+  // the strip of tile (t, r) and the strip of tile (t + tiles_x/2, tiles_y-1-r) are the pair, the second one
+  // walks its blocks bottom-up.
+  constexpr bool kAliasPairs = LRP_WIN_ALIAS_PAIRS != 0 && OutLens == kEquirect && InMode == kInRect && kWinWaves == 1;
+  int g_flip = 0;        // mirrored strips: the mirror image rendered by loop iteration g is g ^ g_flip
+  bool g_reverse = false; // plain strips: iteration g renders block G-1-g
+  if constexpr (kAliasPairs) {
+    if constexpr (Quad) {
+      g_flip = (tx & 1) ? 3 : 0;
+      tx = (tx & 1) ? P.tiles_x - 1 - (tx >> 1) : (tx >> 1);
+    } else if ((P.tiles_x & 1) == 0) {
+      g_reverse = (tx & 1) != 0;
+      tx = (tx >> 1) + (g_reverse ? P.tiles_x >> 1 : 0);
+      ty = g_reverse ? P.tiles_y - 1 - ty : ty;
+    }
+  }
   const int lane = (int)(threadIdx.x & 63u);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int G = P.blocks_per_wave;
+  auto block_row = [&](int g) { return (kAliasPairs && g_reverse) ? G - 1 - g : g; }; // block of a plain strip rendered by iteration g
   // Mirrored blocks (Quad instantiations, launched when P.quad).  Without a rotation the mapping is symmetric
   // about both image axes: the pixels (x, y), (W-1-x, y), (x, H-1-y), (W-1-x, H-1-y) have
   // rays that differ in the signs of vx / vy only, every operation between the ray and the
@@ -1209,14 +1239,15 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
   auto coords = [&](int g, WinBlock &b) {
     // the four row terms first, all loads in flight together (one exposed latency per
     // block instead of one in front of every pixel's coordinate chain)
-    const int mx = quad ? (g & 1) : 0, my = quad ? (g >> 1) : 0;
+    const int gm = g ^ g_flip; // (plain blocks: g_flip == 0)
+    const int mx = quad ? (gm & 1) : 0, my = quad ? (gm >> 1) : 0;
     (void)mx;
     (void)my;
     float row_v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (!quad || g == 0) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int yk = y_lane + (quad ? 0 : kBlkH * g) + kPassRows * k;
+        const int yk = y_lane + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
         row_v[k] = row_term<OutLens>(P, yk < qh ? yk : qh - 1, 0);
       }
     }
@@ -1250,12 +1281,12 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
     Extremes e;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int yk = y_lane + (quad ? 0 : kBlkH * g) + kPassRows * k;
+      const int yk = y_lane + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
       const int ye = yk < qh ? yk : qh - 1;
       if (!quad)
         pixel_source_rt<OutLens, InMode>(P, col, row_v[k], ye, 0, b.sx[k], b.sy[k]);
       else
-        quad_xy(g, k, b.sx[k], b.sy[k]);
+        quad_xy(gm, k, b.sx[k], b.sy[k]);
       note_pixel(e, k, b.sx[k], b.sy[k]);
     }
     bool all_exact = wave_all((e.exact_x & e.exact_y) != 0);
@@ -1412,10 +1443,11 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
     // strip — which spilled — so the row is re-derived from an opaque copy here: an add and a min per pass)
     int y_base = y_lane;
     if constexpr (Quad && kInEqr) asm volatile("" : "+v"(y_base));
-    const int yk = y_base + (quad ? 0 : kBlkH * g) + kPassRows * k;
+    const int yk = y_base + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
     const int yc = yk < qh ? yk : qh - 1;
-    const int xo = (quad && (g & 1)) ? P.out_w - 1 - xe : xe; // mirrored blocks write the mirrored pixel
-    const int yo = (quad && (g >> 1)) ? P.out_h - 1 - yc : yc;
+    const int gm = g ^ g_flip;
+    const int xo = (quad && (gm & 1)) ? P.out_w - 1 - xe : xe; // mirrored blocks write the mirrored pixel
+    const int yo = (quad && (gm >> 1)) ? P.out_h - 1 - yc : yc;
 #if defined(LRP_NO_STORE) // timing experiment: almost no output traffic
     if (a.lo.x == 12345.678f) store_px<CH, true>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
 #elif defined(LRP_STORE_SMALL) // timing experiment (wrong results): every store issued, all of them into one 1 MiB region (stays in L2)
@@ -1486,7 +1518,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
         const bool last_pass = kWinBuffers == 1 && LRP_ABLATE == 0 && k == 3;
         if (Quad && k == 3 && g + 1 < G) coords(g + 1, nxt); // only its box is kept
         float psx = cur.sx[k], psy = cur.sy[k];
-        if constexpr (Quad) quad_xy(g, k, psx, psy); // re-derived (2-4 instructions) instead of held in registers
+        if constexpr (Quad) quad_xy(g ^ g_flip, k, psx, psy); // re-derived (2-4 instructions) instead of held in registers
         Rgba s;
         if (kWinCoef && cur.coef()) {
           const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
@@ -1577,6 +1609,8 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
         } else {
           if (last_pass) next_window(); // nothing staged: no tap of this block reads the window
           if constexpr (CH == 5) {
+            // (colour and depth taps fetched one set after the other — 16 dwordx4 + 16 dword loads instead of 20 dwordx4, at
+            // three or at four waves per SIMD — is 18-26 % slower: this path is bound by the number of gather instructions)
             const Px<5> s5 = sample_direct<2, Loop, 5, LRP_WIN_MINWAVES5 >= 4>(P, src, psx, psy); // (LowReg at 128 VGPRs)
             s = Rgba{s5.lo, s5.hi, s5.e};
           } else {
