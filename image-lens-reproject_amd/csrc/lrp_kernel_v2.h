@@ -667,9 +667,13 @@ __device__ __forceinline__ Px<CH> sample_direct(const KParams &P, const SrcView 
 // UnitNorm: num_samples == 1, normalize == 1.0f: x * 1.0f is x for every float (the sum 0.0f + s
 // has already turned -0 into +0 and quieted a NaN), so the five multiplies are not issued.
 template <int CH, bool UnitNorm = false>
-__device__ __forceinline__ void store_px(const KParams &P, uint32_t pixel_index, Px<CH> a) {
+__device__ __forceinline__ void finish_px(const KParams &P, const Px<CH> &a, float c[5]) {
   const float n = UnitNorm ? 1.0f : P.normalize;
-  float c[5] = {a.lo.x, a.lo.y, (CH == 3 ? a.e : a.hi.x), a.hi.y, a.e};
+  c[0] = a.lo.x;
+  c[1] = a.lo.y;
+  c[2] = CH == 3 ? a.e : a.hi.x;
+  c[3] = a.hi.y;
+  c[4] = a.e;
   if constexpr (!UnitNorm) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) c[i] *= n;
@@ -679,6 +683,11 @@ __device__ __forceinline__ void store_px(const KParams &P, uint32_t pixel_index,
     c[1] = tonemap(c[1], P.exposure, P.reinhard);
     c[2] = tonemap(c[2], P.exposure, P.reinhard);
   }
+}
+template <int CH, bool UnitNorm = false>
+__device__ __forceinline__ void store_px(const KParams &P, uint32_t pixel_index, Px<CH> a) {
+  float c[5];
+  finish_px<CH, UnitNorm>(P, a, c);
   // Non-temporal stores: the output is written once and never read by this kernel;
   // keeping it out of the L2 leaves the cache to the source texels (measured on a 4K
   // frame: nearest 88 -> 63 us, bilinear 117 -> 95 us, bicubic 223 -> 214 us).
@@ -700,6 +709,58 @@ __device__ __forceinline__ void store_px(const KParams &P, uint32_t pixel_index,
   }
 }
 
+// RGBAZ output, a whole run of pixels per wavefront.  Stored per lane, a 20-byte pixel is a dwordx4 and a dword
+// at a 20-byte lane stride: two instructions that each touch every 64-byte segment of the run and fill it only
+// partly — measured at half the rate of whole segments (tools/microbench/store_stride.hip: 114 us against 62 us
+// for the 335 MB of a 4096^2 frame).  So the wavefront's 64 pixels (1280 bytes: one row of 64 pixels, Rows == 1,
+// or four rows of 16, Rows == 4, each row 320 contiguous bytes) are exchanged through 1.25 KiB of its own LDS
+// (no barrier: LDS operations of one wavefront execute in order) and leave as 80 sixteen-byte chunks: lane i
+// writes chunk i, lanes 0-15 chunks 64-79.  `slot`: this lane's pixel in run order (row * 16 + column for
+// Rows == 4); `first`: pixel index of the run's first pixel; `row_step`: pixels from one run row to the next.
+template <int Rows>
+__device__ __forceinline__ void store_rgbaz_run(const KParams &P, float *lds, int slot, uint32_t first, int row_step,
+                                                const float c[5]) {
+  static_assert(Rows == 1 || Rows == 4, "one row of 64 pixels or four rows of 16");
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
+  float *x = lds + slot * 5;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) x[i] = c[i];
+  const int lane = (int)(threadIdx.x & 63u);
+  const v4f q0 = *reinterpret_cast<const v4f *>(lds + 4 * lane);
+  float *const row0 = P.dst + (size_t)first * 5;
+  if constexpr (Rows == 1) {
+    __builtin_nontemporal_store(v4f_a4{q0.x, q0.y, q0.z, q0.w}, reinterpret_cast<v4f_a4 *>(row0 + 4 * lane));
+    if (lane < 16) {
+      const v4f q1 = *reinterpret_cast<const v4f *>(lds + 256 + 4 * lane);
+      __builtin_nontemporal_store(v4f_a4{q1.x, q1.y, q1.z, q1.w}, reinterpret_cast<v4f_a4 *>(row0 + 256 + 4 * lane));
+    }
+  } else {
+    const int r = (lane * 3277) >> 16, cc = lane - 20 * r; // chunk lane = chunk cc of run row r (20 chunks per row)
+    const ptrdiff_t step = (ptrdiff_t)row_step * 5;
+    __builtin_nontemporal_store(v4f_a4{q0.x, q0.y, q0.z, q0.w}, reinterpret_cast<v4f_a4 *>(row0 + r * step + 4 * cc));
+    if (lane < 16) { // chunks 64-79: run row 3, chunks 4-19
+      const v4f q1 = *reinterpret_cast<const v4f *>(lds + 256 + 4 * lane);
+      __builtin_nontemporal_store(v4f_a4{q1.x, q1.y, q1.z, q1.w}, reinterpret_cast<v4f_a4 *>(row0 + 3 * step + 16 + 4 * lane));
+    }
+  }
+}
+
+// One row of a tile kernel's 64 pixels: RGBAZ rows that lie in the image whole (wave-uniform) go out as a run.
+template <int CH, bool UnitNorm>
+__device__ __forceinline__ void store_tile_row(const KParams &P, float *run_lds, bool whole_run, bool lane_inside, int lane_slot,
+                                               uint32_t run_first, uint32_t pixel_index, const Px<CH> &a) {
+  if constexpr (CH == 5) {
+    if (whole_run) {
+      float c[5];
+      finish_px<5, UnitNorm>(P, a, c);
+      store_rgbaz_run<1>(P, run_lds, lane_slot, run_first, 0, c);
+      return;
+    }
+  }
+  if (lane_inside) store_px<CH, UnitNorm>(P, pixel_index, a);
+}
+
 // ---- the tile kernel (RGB / RGBA / RGBAZ float) ----------------------------------
 template <int OutLens, int InMode, int Interp, int CH>
 __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_kernel(const KParams Pk) {
@@ -711,6 +772,12 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
   const int lane = (int)(threadIdx.x & 63u);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int x = tx * kT2W + lane;
+  const int x0 = tx * kT2W; // first column of the tile (wave-uniform)
+  float *run_lds = nullptr; // RGBAZ: the wavefront's exchange buffer (store_rgbaz_run)
+  if constexpr (CH == 5) {
+    __shared__ __attribute__((aligned(16))) float s_run[kT2Waves][320];
+    run_lds = s_run[wave];
+  }
   constexpr int kT2Rows = tile_rows<Interp>();
   const int y_first = P.y_offset + (ty * kT2Waves + wave) * kT2Rows; // wave-uniform
   // Lanes / rows beyond the image recompute the last valid pixel and never store
@@ -744,7 +811,9 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
           Px<CH> a = px_zero<CH>();
           px_add<CH>(a, sample_direct<Interp, Loop, CH>(P, src, sx, sy)); // :334-336
           const int xo = mx ? P.out_w - 1 - x : x, yo = my ? P.out_h - 1 - yk : yk;
-          if (x < qw && yk < qh) store_px<CH, true>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
+          store_tile_row<CH, true>(P, run_lds, x0 + kT2W <= qw && yk < qh, x < qw && yk < qh, mx ? kT2W - 1 - lane : lane,
+                                   (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)(mx ? P.out_w - x0 - kT2W : x0),
+                                   (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
         }
       }
     }
@@ -786,7 +855,9 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
         Px<CH> a = px_zero<CH>();
         px_add<CH>(a, sample_direct<Interp, Loop, CH>(P, src, sx, sy)); // :334-336
         const int xo = mx ? P.out_w - 1 - x : x, yo = my ? P.out_h - 1 - yk : yk;
-        if (x < qw && yk < qh) store_px<CH, true>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
+        store_tile_row<CH, true>(P, run_lds, x0 + kT2W <= qw && yk < qh, x < qw && yk < qh, mx ? kT2W - 1 - lane : lane,
+                                 (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)(mx ? P.out_w - x0 - kT2W : x0),
+                                 (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
       }
     }
     return;
@@ -813,17 +884,17 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
     }
   }
 
-  if (x < P.out_w) {
 #pragma unroll
-    for (int k = 0; k < kT2Rows; ++k) {
-      const int yk = y_first + k;
-      if (yk < P.y_end) {
-        if (ns == 1)
-          store_px<CH, true>(P, (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x, acc[k]);
-        else
-          store_px<CH>(P, (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x, acc[k]);
-      }
-    }
+  for (int k = 0; k < kT2Rows; ++k) {
+    const int yk = y_first + k;
+    const bool row_inside = yk < P.y_end; // wave-uniform
+    const uint32_t row_first = (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x0;
+    if (ns == 1)
+      store_tile_row<CH, true>(P, run_lds, row_inside && x0 + kT2W <= P.out_w, row_inside && x < P.out_w, lane, row_first,
+                               row_first + (uint32_t)lane, acc[k]);
+    else
+      store_tile_row<CH, false>(P, run_lds, row_inside && x0 + kT2W <= P.out_w, row_inside && x < P.out_w, lane, row_first,
+                                row_first + (uint32_t)lane, acc[k]);
   }
 }
 
@@ -1056,6 +1127,12 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
   const SrcView src = source_view<2, CH>(P);
   const float4 *__restrict__ src4 = reinterpret_cast<const float4 *>(P.src);
   float4 *const win0 = s_win[wave][0];
+  constexpr bool kRunsEverywhere = CH == 5 && OutLens == kEquirect && InMode == kInRect;
+  float *out_lds = nullptr; // RGBAZ: the wavefront's exchange buffer of store_rgbaz_run (three waves per SIMD: the LDS is there)
+  if constexpr (CH == 5) {
+    __shared__ __attribute__((aligned(16))) float s_out[kWinWaves][320];
+    out_lds = s_out[wave];
+  }
   const ColTerms col = column_terms<OutLens>(P, xe, 0);
   ColTerms col_m = col; // the mirrored column
   if constexpr (Quad) col_m = column_terms<OutLens>(P, P.out_w - 1 - xe, 0);
@@ -1431,7 +1508,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
     if (dma_early) issue(g_loop + 1, nxt);
   };
   // The result of pass k of block g: num_samples == 1, (0.0f + s) * normalize (src/reproject.cpp:334-341), store.
-  auto emit = [&](int g, int k, const Rgba &s) {
+  auto emit = [&](int g, int k, const Rgba &s, auto as_runs) {
     Rgba a4 = px_zero<4>();
     px_add<4>(a4, s);
     if constexpr (CH == 5) a4.e = 0.0f + s.e;
@@ -1455,6 +1532,26 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
 #elif defined(LRP_STORE_ROW) // timing experiment (wrong results): the four rows of a pass written as one contiguous 1 KiB run
     store_px<CH, true>(P, ((uint32_t)(yo & ~3) * (uint32_t)P.out_w + (uint32_t)(xo & ~15) * 4u + (uint32_t)((yo & 3) * 16 + (xo & 15))), a);
 #else
+    if constexpr (CH == 5) {
+     if constexpr (decltype(as_runs)::value) {
+      // a pass that lies in the image whole (wave-uniform) leaves as four runs of 16 pixels (store_rgbaz_run).
+      // Used where the stores are what a block costs: corner blocks (four stores and nothing else) in every kernel,
+      // all blocks of a rectilinear view rendered into a panorama (kRunsEverywhere: most of that frame is out of
+      // view or gathers minified taps; 383 -> 334 us).  In the VALU-bound kernels that interpolate from the LDS
+      // window the exchange costs more than the stores gain (measured: 4-7 % slower).
+      const int x_blk = tx * (kBlkW * kWinWaves) + wave * kBlkW;
+      const int y_top = P.y_offset + ty * (quad ? kBlkH : kBlkH * G) + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
+      if (x_blk + kBlkW <= qw && y_top + kPassRows <= qh) {
+        const bool mxo = quad && (gm & 1), myo = quad && (gm >> 1);
+        float c[5];
+        finish_px<5, true>(P, a, c);
+        const uint32_t first = (uint32_t)(myo ? P.out_h - 1 - y_top : y_top) * (uint32_t)P.out_w +
+                               (uint32_t)(mxo ? P.out_w - x_blk - kBlkW : x_blk);
+        store_rgbaz_run<4>(P, out_lds, prow * kBlkW + (mxo ? kBlkW - 1 - pcol : pcol), first, myo ? -P.out_w : P.out_w, c);
+        return;
+      }
+     }
+    }
     store_px<CH, true>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
 #endif
   };
@@ -1495,11 +1592,11 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
       // window is requested in front of the last store, as in the last pass of an ordinary block.
       const Rgba cs = corner_value(cur);
       if (Quad && g + 1 < G) coords(g + 1, nxt);
-      emit(g, 0, cs);
-      emit(g, 1, cs);
-      emit(g, 2, cs);
+      emit(g, 0, cs, std::true_type{});
+      emit(g, 1, cs, std::true_type{});
+      emit(g, 2, cs, std::true_type{});
       if (kWinBuffers == 1 && LRP_ABLATE == 0) next_window();
-      emit(g, 3, cs);
+      emit(g, 3, cs, std::true_type{});
       if (kWinBuffers == 1 && (LRP_ABLATE != 0 || !dma_early) && g + 1 < G) issue(g + 1, nxt);
       cur = nxt;
       continue;
@@ -1617,7 +1714,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
             s = sample_direct<2, Loop, 4, false, 4 * CH>(P, src, psx, psy);
           }
         }
-        emit(g, k, s);
+        emit(g, k, s, std::integral_constant<bool, kRunsEverywhere>{});
       }
     }
     if (kWinBuffers == 1 && (LRP_ABLATE != 0 || !dma_early) && g + 1 < G) issue(g + 1, nxt); // after the last read of the planes
