@@ -125,3 +125,24 @@ def test_mirrored_rays_equidistant_target(lrp, oracle, torch_cuda, out_w, out_h,
                 want = oracle.reproject(lin, src, lout, out_w, out_h, 1, interp, rot, threads=8)
             render_all(lrp, torch_cuda, lin, src, lout, out_w, out_h, interp, rot,
                        f"{in_name}->eqd180 {out_w}x{out_h} C={c} interp={interp} rot={deg}", want, channels=c, families=(2, 0))
+
+
+@pytest.mark.parametrize("span", [None, (-1.25, 1.25, -0.5, 0.5), (-0.5, 0.5, -1.0, 1.0), (-math.pi / 2, math.pi / 2, -math.pi, math.pi),
+                                  (-1.0, 1.0, -2.0, 2.0)])
+def test_alias_pairs_plain_and_mirrored_strips(lrp, oracle, torch_cuda, span):
+    """Rectilinear view into a panorama: the window kernel deals the strip that renders the view and the
+    strip that renders its copy behind the camera to neighbouring workgroups (plain strips: tile (t, r)
+    with (t + tiles_x/2, tiles_y-1-r), walked bottom-up; mirrored strips, which some symmetric
+    panoramas take: columns from both ends inwards, mirror images in reverse).  A permutation of the
+    work only: every channel count, even and odd tile counts, against the oracle."""
+    L = lrp.LensInfo
+    in_w, in_h = 300, 200
+    lin = L.rectilinear(18.0, 36.0, in_w, in_h)
+    for out_w, out_h in ((512, 256), (496, 250), (528, 272), (272, 80)):  # 32 / 31 / 33 / 17 tile columns
+        lout = L.equirectangular() if span is None else L.equirectangular(*span)
+        for c in (4, 5, 3):
+            src = cases.hash_noise(in_h, in_w, c, seed=out_w + c)
+            with np.errstate(all="ignore"):
+                want = oracle.reproject(lin, src, lout, out_w, out_h, 1, 2, None, threads=8)
+            render_all(lrp, torch_cuda, lin, src, lout, out_w, out_h, 2, None, f"rect->eqr{span} {out_w}x{out_h} C={c}", want,
+                       channels=c, families=(2,))
