@@ -260,6 +260,14 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
         out->lens.type == LRP_FISHEYE_EQUIDISTANT)
       P.quad = 2;
     P.win_coef = kernel_choice() == 2;
+    // The view's copy behind the camera sits half a turn away, upside down (lrp_kernel_v2.h "alias pairs"): only when
+    // the panorama spans the full turn and the rotation neither pitches nor rolls.
+    P.alias_pairs = 0;
+    if (out->lens.type == LRP_EQUIRECTANGULAR && in->lens.type == LRP_RECTILINEAR) {
+      const float turn = out->lens.u.equirectangular.longitude_max - out->lens.u.equirectangular.longitude_min;
+      const bool yaw_only = !P.has_rot || (P.rot[1] == 0.0f && P.rot[3] == 0.0f && P.rot[5] == 0.0f && P.rot[7] == 0.0f);
+      P.alias_pairs = std::fabs(turn - 6.2831855f) < 1e-3f && yaw_only;
+    }
     auto launch = [&]() {
       if (window) return lrp::launch_win_bicubic(P, oi, im, stream);
       if (interpolation == LRP_NEAREST) return lrp::launch_tile_nearest(P, oi, im, stream);

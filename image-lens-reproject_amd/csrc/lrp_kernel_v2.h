@@ -61,6 +61,9 @@
 
 namespace lrp {
 
+#ifndef LRP_WIN_ALIAS_PAIRS
+#define LRP_WIN_ALIAS_PAIRS 1 // rectilinear -> panorama: the view and its copy behind the camera rendered side by side
+#endif
 constexpr int kT2W = 64;         // tile width: one output column per lane
 // Output rows per wavefront of the tile kernel, per sampler (measured at the settled
 // clock, 4K frames: bilinear and bicubic hold 4 / 16 taps per pixel in registers and run
@@ -769,6 +772,19 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
 
   int tx, ty;
   if (!xcd_tile(P.tiles_x, P.tiles_y, tx, ty)) return; // whole workgroup
+  // Alias pairs (see the window kernel): a rectilinear view rendered into a panorama appears a second time behind
+  // the camera, from the same source texels; consecutive workgroups of an XCD take the two tiles that read them.
+  if constexpr (LRP_WIN_ALIAS_PAIRS != 0 && OutLens == kEquirect && InMode == kInRect) {
+    if (P.alias_pairs == 0) {
+      // (a partial panorama has no second copy: raster order keeps neighbouring tiles together, 1-3 % faster there)
+    } else if (P.quad == 1) { // quadrant tiles: columns from both ends inwards (tile t shares its texels with tile tiles_x-1-t)
+      tx = (tx & 1) ? P.tiles_x - 1 - (tx >> 1) : (tx >> 1);
+    } else if ((P.tiles_x & 1) == 0) { // tile (t, r) with tile (t + tiles_x/2, tiles_y-1-r)
+      const bool second = (tx & 1) != 0;
+      tx = (tx >> 1) + (second ? P.tiles_x >> 1 : 0);
+      ty = second ? P.tiles_y - 1 - ty : ty;
+    }
+  }
   const int lane = (int)(threadIdx.x & 63u);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int x = tx * kT2W + lane;
@@ -1060,9 +1076,6 @@ template <bool Fat> struct WinBlockT {
 // DMA is therefore the RGBA code; the fourth component carries stale LDS contents through the
 // arithmetic (no traps are enabled) and is never stored.
 template <int OutLens, int InMode, bool Quad, int CH>
-#ifndef LRP_WIN_ALIAS_PAIRS
-#define LRP_WIN_ALIAS_PAIRS 1
-#endif
 #ifndef LRP_WIN_MINWAVES5
 #define LRP_WIN_MINWAVES5 3 // RGBAZ: 168 VGPRs (the 80 registers of a direct-path tap set do not fit 128 without spilling)
 #endif
@@ -1092,7 +1105,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
   constexpr bool kAliasPairs = LRP_WIN_ALIAS_PAIRS != 0 && OutLens == kEquirect && InMode == kInRect && kWinWaves == 1;
   int g_flip = 0;        // mirrored strips: the mirror image rendered by loop iteration g is g ^ g_flip
   bool g_reverse = false; // plain strips: iteration g renders block G-1-g
-  if constexpr (kAliasPairs) {
+  if (kAliasPairs && P.alias_pairs != 0) {
     if constexpr (Quad) {
       g_flip = (tx & 1) ? 3 : 0;
       tx = (tx & 1) ? P.tiles_x - 1 - (tx >> 1) : (tx >> 1);

@@ -71,6 +71,7 @@ struct KParams {
   float in_lon_span, in_lat_span;   // equirectangular source
   int32_t blocks_per_wave;          // window kernel: 16 x 16 blocks per wavefront strip
   int32_t win_coef;                 // window kernel: shared tap-column coefficients allowed (0: raw taps only)
+  int32_t alias_pairs;              // rectilinear view into a full-turn panorama, no pitch / roll: pixel (x + W/2, H-1-y) reads the texels of (x, y) (tile order, lrp_kernel_v2.h)
   // Batched launch (tile / window kernels): frame blockIdx.y reads batch_src[y], writes batch_dst[y]
   int32_t batch_n;
   const float *batch_src[kMaxBatch];
