@@ -125,9 +125,22 @@ int main(int argc, char **argv) {
   HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   const size_t in_elems = (size_t)size * size * channels, out_elems = (size_t)out_size * out_size * channels;
   std::vector<float *> src(distinct), dst(distinct);
+  // KBENCH_ONE_ALLOC=1: all frames are slices of two allocations (an address-translation experiment: one large
+  // allocation can be mapped with larger page fragments than many 256 MiB ones)
+  const bool one_alloc = getenv("KBENCH_ONE_ALLOC") && atoi(getenv("KBENCH_ONE_ALLOC")) != 0;
+  float *src_all = nullptr, *dst_all = nullptr;
+  if (one_alloc) {
+    HIP_OK(hipMalloc(&src_all, in_elems * 4 * (size_t)distinct));
+    HIP_OK(hipMalloc(&dst_all, out_elems * 4 * (size_t)distinct));
+  }
   for (int i = 0; i < distinct; ++i) {
-    HIP_OK(hipMalloc(&src[i], in_elems * 4));
-    HIP_OK(hipMalloc(&dst[i], out_elems * 4));
+    if (one_alloc) {
+      src[i] = src_all + in_elems * (size_t)i;
+      dst[i] = dst_all + out_elems * (size_t)i;
+    } else {
+      HIP_OK(hipMalloc(&src[i], in_elems * 4));
+      HIP_OK(hipMalloc(&dst[i], out_elems * 4));
+    }
     LRP_OKAY(lrp_synth_fill_device(src[i], size, size, channels, 0x5EED0000u + i, channels == 5 ? 4 : -1, 0, stream));
   }
   HIP_OK(hipStreamSynchronize(stream));
@@ -159,8 +172,10 @@ int main(int argc, char **argv) {
     lrp_post pp{2.0f, 4.0f};
     std::vector<lrp_image> ins((size_t)(batch > 0 ? batch : 0), in), outs((size_t)(batch > 0 ? batch : 0), out);
     for (int b = 0; b < batch; ++b) {
-      ins[(size_t)b].data = src[(size_t)b];
-      outs[(size_t)b].data = dst[(size_t)b];
+      // KBENCH_BATCH_DISTINCT=D: the batch cycles over D frame pairs (a footprint experiment; frames rendered more than once)
+      const int cyc = getenv("KBENCH_BATCH_DISTINCT") ? atoi(getenv("KBENCH_BATCH_DISTINCT")) : batch;
+      ins[(size_t)b].data = src[(size_t)(b % (cyc > 0 ? cyc : batch))];
+      outs[(size_t)b].data = dst[(size_t)(b % (cyc > 0 ? cyc : batch))];
     }
     auto launch = [&](int i) {
       if (batch > 0) {
