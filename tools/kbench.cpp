@@ -173,9 +173,14 @@ int main(int argc, char **argv) {
     std::vector<lrp_image> ins((size_t)(batch > 0 ? batch : 0), in), outs((size_t)(batch > 0 ? batch : 0), out);
     for (int b = 0; b < batch; ++b) {
       // KBENCH_BATCH_DISTINCT=D: the batch cycles over D frame pairs (a footprint experiment; frames rendered more than once)
-      const int cyc = getenv("KBENCH_BATCH_DISTINCT") ? atoi(getenv("KBENCH_BATCH_DISTINCT")) : batch;
-      ins[(size_t)b].data = src[(size_t)(b % (cyc > 0 ? cyc : batch))];
-      outs[(size_t)b].data = dst[(size_t)(b % (cyc > 0 ? cyc : batch))];
+      // (KBENCH_BATCH_DISTINCT_SRC / _DST: the same for the sources / the destinations alone)
+      auto cycle = [&](const char *name) {
+        const char *v = getenv(name) ? getenv(name) : getenv("KBENCH_BATCH_DISTINCT");
+        const int c = v ? atoi(v) : batch;
+        return c > 0 ? c : batch;
+      };
+      ins[(size_t)b].data = src[(size_t)(b % cycle("KBENCH_BATCH_DISTINCT_SRC"))];
+      outs[(size_t)b].data = dst[(size_t)(b % cycle("KBENCH_BATCH_DISTINCT_DST"))];
     }
     auto launch = [&](int i) {
       if (batch > 0) {
