@@ -972,6 +972,25 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
   }
   const int xe = x < P.out_w ? x : P.out_w - 1;
   const int ns = P.num_samples;
+  if (ns == 1 && Interp != 2) {
+    // one sample per pixel, any rotation: the rows of this lane with their tap requests ahead of the arithmetic
+    const ColTerms col = column_terms<OutLens>(P, xe, 0);
+    auto coords = [&](int k, float &sx, float &sy) {
+      const int yk = y_first + k;
+      pixel_source<OutLens, InMode>(P, col, yk < P.y_end ? yk : P.y_end - 1, 0, sx, sy); // (row: wave-uniform)
+    };
+    auto finish = [&](int k, const Px<CH> &sample) {
+      const int yk = y_first + k;
+      Px<CH> a = px_zero<CH>();
+      px_add<CH>(a, sample); // :334-336
+      const bool row_inside = yk < P.y_end; // wave-uniform
+      const uint32_t row_first = (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x0;
+      store_tile_row<CH, true>(P, run_lds, row_inside && x0 + kT2W <= P.out_w, row_inside && x < P.out_w, lane, row_first,
+                               row_first + (uint32_t)lane, a);
+    };
+    sample_pixels<Interp, Loop, CH, kT2Rows>(P, src, coords, finish);
+    return;
+  }
 
   Px<CH> acc[kT2Rows];
 #pragma unroll

@@ -67,6 +67,9 @@ static const Workload kWorkloads[] = {
     {"rect_eqrp_nn", "rect", "eqrp", 0, 1, {0, 0, 0}},
     {"rect_eqrp_bl", "rect", "eqrp", 1, 1, {0, 0, 0}},
     {"rect_eqrp_bc", "rect", "eqrp", 2, 1, {0, 0, 0}},
+    // general rotation, nearest / bilinear: the plain (unmirrored) path of the tile kernels
+    {"eqr_rect_nn_rot", "eqr", "rect", 0, 1, {30, -15, 5}},
+    {"eqr_rect_bl_rot", "eqr", "rect", 1, 1, {30, -15, 5}},
 };
 
 static void make_lens(lrp_lens *L, const char *kind, int w, int h) {
