@@ -84,6 +84,9 @@ def test_config1_512_equirect_to_rect_nearest_full_frame(lrp, oracle, torch_cuda
     ("config5 face equirect->rect bicubic pan 90", "eqr_full", "rect", BICUBIC, (90.0, 0.0, 0.0)),
     ("pole face equirect->rect bicubic pitch 90", "eqr_full", "rect", BICUBIC, (0.0, 90.0, 0.0)),
     ("seam equirect->equirect nearest pan 180", "eqr_full", "eqr_full", NEAREST, (180.0, 0.0, 0.0)),
+    ("rect->equirect nearest (alias-paired tiles)", "rect", "eqr_full", NEAREST, None),
+    ("rect->equirect bilinear yaw 40 (alias-paired tiles)", "rect", "eqr_full", BILINEAR, (40.0, 0.0, 0.0)),
+    ("equirect->rect bilinear rotated (plain tile path)", "eqr_full", "rect", BILINEAR, (30.0, -15.0, 5.0)),
 ])
 def test_4k_rgba_rows_against_oracle_and_kernel_families_agree(lrp, oracle, torch_cuda, name, in_kind, out_kind, interp,
                                                                deg):
