@@ -645,6 +645,9 @@ __device__ __forceinline__ Px<CH> sample_direct(const KParams &P, const SrcView 
       const float tx_ = __builtin_truncf(sx), ty_ = __builtin_truncf(sy);
       const float fx = sx - tx_, fy = sy - ty_;
       uint32_t v0 = __umul24((uint32_t)((int)ty_ - 1), row_bytes) + (uint32_t)((int)tx_ - 1) * T;
+#if defined(LRP_ABLATE_L2ROWS) // timing experiment (wrong results): the taps of every pixel come from the first 64 source rows (cache-resident), same access pattern within a row
+      v0 = __umul24((uint32_t)(((int)ty_ - 1) & 63), row_bytes) + (uint32_t)((int)tx_ - 1) * T;
+#endif
 #if defined(LRP_ABLATE_COOP) // timing experiment (wrong results): the tap loads in the access pattern of four lanes per pixel
       {
         // each instruction fetches, for 16 pixels, the 64 contiguous bytes of one tap row (lane = 4 * pixel + tap column)
