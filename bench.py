@@ -55,16 +55,31 @@ WORKLOADS = {
     # north_star's roofline target case.
     "equirect_to_rect_bicubic": dict(in_lens="eqr", out_lens="rect", interp=2, rot=(0.0, 0.0, 0.0), channels=4,
                                      size=4096),
+    # what every real --rotation runs (the CLI always passes a matrix, src/main.cpp:312-325)
+    "equirect_to_rect_bicubic_rot": dict(in_lens="eqr", out_lens="rect", interp=2, rot=(30.0, -15.0, 5.0), channels=4,
+                                         size=4096),
     # BASELINE.json configs[2] shape.
     "equirect_to_fisheye_bilinear": dict(in_lens="eqr", out_lens="eqd", interp=1, rot=(30.0, -15.0, 5.0), channels=4,
                                          size=4096),
+    # SURVEY.md §8d scaling workload: the configs[2] shape with bicubic.
+    "equirect_to_fisheye_bicubic_rot": dict(in_lens="eqr", out_lens="eqd", interp=2, rot=(30.0, -15.0, 5.0), channels=4,
+                                            size=4096),
     # BASELINE.json configs[0] shape at 4K (plumbing case, nearest).
     "equirect_to_rect_nearest": dict(in_lens="eqr", out_lens="rect", interp=0, rot=(0.0, 0.0, 0.0), channels=4,
                                      size=4096),
-    # BASELINE.json configs[3] shape (RGBA variant; the RGBAZ one is timed by tools/kbench).
+    # BASELINE.json configs[3]: RGBAZ, rectilinear -> equirect(full), bicubic, exposure 2^1, Reinhard 4 fused into the store.
+    "rect_to_equirect_bicubic_rgbaz_post": dict(in_lens="rect", out_lens="eqr", interp=2, rot=(0.0, 0.0, 0.0), channels=5,
+                                                depth=4, post=(2.0, 4.0), size=4096),
+    # the same mapping, RGBA, no tonemap
     "rect_to_equirect_bicubic": dict(in_lens="rect", out_lens="eqr", interp=2, rot=(0.0, 0.0, 0.0), channels=4,
                                      size=4096),
+    # BASELINE.json configs[4]: one 8192^2 RGB panorama -> six 2048^2 rectilinear faces, bicubic; a "frame" is a cubemap
+    "cubemap_8k_rgb": dict(in_lens="eqr", out_lens="rect", interp=2, channels=3, size=8192, out_size=2048,
+                           faces=[(0.0, 0.0, 0.0), (90.0, 0.0, 0.0), (180.0, 0.0, 0.0), (270.0, 0.0, 0.0), (0.0, 90.0, 0.0),
+                                  (0.0, -90.0, 0.0)], rot=None),
 }
+DEFAULT_SECONDARY = ("equirect_to_rect_bicubic,equirect_to_rect_bicubic_rot,equirect_to_fisheye_bilinear,"
+                     "equirect_to_fisheye_bicubic_rot,rect_to_equirect_bicubic_rgbaz_post,cubemap_8k_rgb")
 INTERP_NAMES = {0: "nearest", 1: "bilinear", 2: "bicubic"}
 KERNEL_NAMES = {0: "reproject_tile_kernel (nearest)", 1: "reproject_tile_kernel (bilinear)",
                 2: "reproject_bicubic_win_kernel (LDS window)"}
@@ -83,9 +98,9 @@ def kernel_source_sha():
 
 def measured_traffic(workload):
     """HBM bytes per single-frame launch of the dominant kernel from the committed rocprofv3 PMC
-    summary (profiles/traffic_r02.json; tools/collect_traffic.sh on an MI355X).  The file is stamped
+    summary (profiles/traffic_r03.json; tools/collect_traffic.sh on an MI355X).  The file is stamped
     with the hash of the kernel sources it was measured on; a stale file yields None."""
-    path = os.path.join(ROOT, "profiles", "traffic_r02.json")
+    path = os.path.join(ROOT, "profiles", "traffic_r03.json")
     try:
         with open(path) as f:
             d = json.load(f)
@@ -227,7 +242,7 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the frames of a step round-robin over (--per-frame-launches only)")
     ap.add_argument("--workload", default="fisheye_to_rect_bicubic", choices=sorted(WORKLOADS))
-    ap.add_argument("--secondary", default="equirect_to_rect_bicubic",
+    ap.add_argument("--secondary", default=DEFAULT_SECONDARY,
                     help="comma-separated workloads measured (kernel timing only) in the same process; '' = none")
     ap.add_argument("--size", type=int, default=0, help="override the frame size (tests; 0 = the workload's 4096)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -264,23 +279,52 @@ def time_launches(torch, stream, fn, reps):
     return sum(ms) / len(ms), ms[0]
 
 
+def resident_frames(torch, pkg, wl, size, n, dev, first_seed=0x5EED0000):
+    """n distinct synthetic source / destination pairs of one workload, resident in HBM."""
+    c, out_size = wl["channels"], wl.get("out_size") and (wl["out_size"] * size // wl["size"]) or size
+    faces = len(wl.get("faces") or [None])
+    srcs, dsts = [], []
+    for k in range(n):
+        s = torch.empty((size, size, c), dtype=torch.float32, device=dev)
+        pkg.synth_fill(s, size, size, c, first_seed + k, wl.get("depth", -1))
+        srcs.append(s)
+        dsts.append([torch.empty((out_size, out_size, c), dtype=torch.float32, device=dev) for _ in range(faces)])
+    return srcs, dsts
+
+
 def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_ms=None):
     """Roofline figures of one workload's dominant kernel on resident frames: 16-frame launches and
-    single-frame launches, both with HIP events on the launch stream, cycling over the resident frames."""
+    single-frame launches, both with HIP events on the launch stream, cycling over the resident frames.
+    `dsts[k]` is the list of outputs of source k (one; six for the cubemap, where a "frame" is one
+    cubemap = six launches over one resident source and frames_per_launch is 1)."""
     c = wl["channels"]
-    lin, lout = make_lens(pkg, wl["in_lens"], size, size), make_lens(pkg, wl["out_lens"], size, size)
-    rot = make_rot(pkg, wl["rot"])
-    im_in = [pkg.Image(lin, size, size, c, s) for s in srcs]
-    im_out = [pkg.Image(lout, size, size, c, d) for d in dsts]
+    out_size = dsts[0][0].shape[0]
+    lin, lout = make_lens(pkg, wl["in_lens"], size, size), make_lens(pkg, wl["out_lens"], out_size, out_size)
+    post = wl.get("post")
+    faces = wl.get("faces")
     n_res = len(srcs)
-    nb = min(FRAMES_PER_LAUNCH, n_res)
+    im_in = [pkg.Image(lin, size, size, c, s) for s in srcs]
+    im_out = [[pkg.Image(lout, out_size, out_size, c, d) for d in ds] for ds in dsts]
+    if faces:
+        import numpy as np
 
-    def batched(i):
-        ids = [(i * nb + k) % n_res for k in range(nb)]
-        pkg.reproject_batch([im_in[j] for j in ids], [im_out[j] for j in ids], 1, wl["interp"], rot, stream=stream)
+        rots = np.stack([make_rot(pkg, f) for f in faces])
+        nb = 1
 
-    def single(i):
-        pkg.reproject(im_in[i % n_res], im_out[i % n_res], 1, wl["interp"], rot, stream=stream)
+        def batched(i):
+            pkg.reproject_multi(im_in[i % n_res], im_out[i % n_res], 1, wl["interp"], rots, post=post, stream=stream)
+
+        single = batched
+    else:
+        rot = make_rot(pkg, wl["rot"])
+        nb = min(FRAMES_PER_LAUNCH, n_res)
+
+        def batched(i):
+            ids = [(i * nb + k) % n_res for k in range(nb)]
+            pkg.reproject_batch([im_in[j] for j in ids], [im_out[j][0] for j in ids], 1, wl["interp"], rot, post=post, stream=stream)
+
+        def single(i):
+            pkg.reproject(im_in[i % n_res], im_out[i % n_res][0], 1, wl["interp"], rot, post=post, stream=stream)
 
     if timed_region_ms:  # the headline workload: the launches of the timed region itself
         b_avg, b_min = sum(timed_region_ms) / len(timed_region_ms), min(timed_region_ms)
@@ -293,20 +337,27 @@ def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_
         single(i)
     torch.cuda.synchronize()
     s_avg, s_min = time_launches(torch, stream, single, 64)
-    frame_bytes = size * size * c * 4
-    algo = 2 * frame_bytes * nb  # (inW*inH + outW*outH)*C*4 per frame x frames per launch
+    # (inW*inH + outW*outH)*C*4 per launch that reads the source; a cubemap is six such launches
+    launch_bytes = (size * size + out_size * out_size) * c * 4
+    frame_bytes = launch_bytes * (len(faces) if faces else 1)
+    read_bytes = size * size * c * 4 * (len(faces) if faces else 1)
+    algo = frame_bytes * nb
     achieved = algo / (b_avg * 1e-3) / 1e9
     traffic = measured_traffic(name) if size == wl["size"] else None
-    return {
+    hbm_bytes = (traffic or {}).get("hbm_bytes_per_launch")
+    out = {
         "bound": "hbm",
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
-        "frac_read_only": frame_bytes * nb / (b_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "traffic": ((traffic or {}).get("hbm_bytes_per_launch") or 0) * nb or None,
+        "frac_read_only": read_bytes * nb / (b_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        # the bytes the PMC counters saw cross the HBM interface / time / peak: what the memory system actually sustains
+        # (below frac whenever the view does not look at the whole source)
+        "frac_measured_hbm": (hbm_bytes * nb / (b_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if hbm_bytes else None,
+        "traffic": (hbm_bytes or 0) * nb or None,
         "traffic_detail": traffic,
-        "kernel": KERNEL_NAMES[wl["interp"]],
+        "kernel": "six launches of reproject_bicubic_win_kernel (LDS window) over one resident source" if faces else KERNEL_NAMES[wl["interp"]],
         "workload": name,
         "kernel_ms_avg": b_avg,
         "kernel_ms_min": b_min,
@@ -317,10 +368,27 @@ def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_
         "algorithmic_bytes_per_launch": algo,
         "single_launch_us": s_avg * 1e3,
         "single_launch_us_min": s_min * 1e3,
-        "single_launch_frac": 2 * frame_bytes / (s_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "single_launch_frac": frame_bytes / (s_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "traffic_note": "PMC bytes measured per single-frame launch (traffic_detail) x frames_per_launch; null when "
-                        "profiles/traffic_r02.json was measured on other kernel sources",
+                        "profiles/traffic_r03.json was measured on other kernel sources",
     }
+    if faces:
+        out["note"] = ("a frame is one cubemap: six 2048^2 faces from one resident 8192^2 RGB source; algorithmic bytes count the "
+                       "whole source once per face launch as SURVEY 8d prescribes, although a 90-degree face looks at a sixth of it")
+    return out
+
+
+def golden_batch_digest(workload, total_images):
+    """sha256 over the committed per-image checksums (tests/golden/fullframe_golden.json, written by the oracle in
+    the build container) of the first `total_images` images of the batch, or None if there is no fixture."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "fullframe_golden.json")) as f:
+            sums = json.load(f)["bench_batch"][workload]["checksums"]
+    except (OSError, ValueError, KeyError):
+        return None
+    if total_images > len(sums):
+        return None
+    return hashlib.sha256(",".join(sums[:total_images]).encode()).hexdigest()
 
 
 def main():
@@ -376,12 +444,15 @@ def main():
     fit = max(1, int(0.70 * free_b / (2 * frame_bytes)))
     n_res = args.distinct if args.distinct > 0 else min(max(len(shard), 1), fit)
     n_res = max(1, min(n_res, max(len(shard), 1)))
+    if wl.get("faces"):
+        raise SystemExit("bench.py: the cubemap is a secondary workload (six launches per frame), not a batch headline")
     srcs, dsts = [], []
     for k in range(n_res):
         s = torch.empty((size, size, c), dtype=torch.float32, device=dev)
-        pkg.synth_fill(s, size, size, c, 0x5EED0000 + (shard[k] if shard else 0))
+        pkg.synth_fill(s, size, size, c, 0x5EED0000 + (shard[k] if shard else 0), wl.get("depth", -1))
         srcs.append(s)
         dsts.append(torch.empty((size, size, c), dtype=torch.float32, device=dev))
+    post = wl.get("post")
     im_in = [pkg.Image(lin, size, size, c, s) for s in srcs]
     im_out = [pkg.Image(lout, size, size, c, d) for d in dsts]
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
@@ -391,7 +462,7 @@ def main():
     batch_out = [im_out[k % n_res] for k in range(len(shard))]
     launches_per_step = len(shard) if args.per_frame_launches else -(-len(shard) // FRAMES_PER_LAUNCH)
     # the frames of a step share one geometry: one launch per 16 frames, descriptors marshalled once
-    groups = [pkg.PreparedBatch(batch_in[k:k + FRAMES_PER_LAUNCH], batch_out[k:k + FRAMES_PER_LAUNCH], 1, wl["interp"], rot)
+    groups = [pkg.PreparedBatch(batch_in[k:k + FRAMES_PER_LAUNCH], batch_out[k:k + FRAMES_PER_LAUNCH], 1, wl["interp"], rot, post=post)
               for k in range(0, len(shard), FRAMES_PER_LAUNCH)] if not args.per_frame_launches else []
     # HIP events around every launch of the timed region, on the stream it is launched on (roofline.achieved)
     events = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in groups]
@@ -400,7 +471,7 @@ def main():
     def step(timed=None):
         if args.per_frame_launches:
             for k in range(len(shard)):
-                pkg.reproject(batch_in[k], batch_out[k], 1, wl["interp"], rot, stream=streams[k % len(streams)])
+                pkg.reproject(batch_in[k], batch_out[k], 1, wl["interp"], rot, post=post, stream=streams[k % len(streams)])
             return
         for gi, g in enumerate(groups):
             if timed is not None:
@@ -446,17 +517,26 @@ def main():
             with open(args.checksums_file, "w") as f:
                 json.dump({"images": total_images, "n_gpus": world, "checksums": [f"{v:016x}" for v in flat]}, f)
 
+    bad_pixels = False
     if rank == 0:
         res = min(n_res, 64)
-        roof = kernel_figures(torch, pkg, wl, size, srcs[:res], dsts[:res], streams[0], args.workload,
+        roof = kernel_figures(torch, pkg, wl, size, srcs[:res], [[d] for d in dsts[:res]], streams[0], args.workload,
                               timed_region_ms=timed_ms if len(timed_ms) >= 4 else None)
         roof["note"] = ("the un-fused IEEE arithmetic of the reference makes this kernel VALU-bound, not HBM-bound "
                         "(DESIGN.md section 5); frac is algorithmic bytes / kernel time / 8 TB/s as the contract asks")
         secondary = {}
         for name in [n for n in args.secondary.split(",") if n and n != args.workload]:
-            if WORKLOADS[name]["channels"] == c:
-                secondary[name] = kernel_figures(torch, pkg, WORKLOADS[name], size, srcs[:res], dsts[:res], streams[0], name)
+            w2 = WORKLOADS[name]
+            size2 = w2["size"] * size // wl["size"]  # (--size scales every workload alike: tests)
+            if w2["channels"] == c and size2 == size and not w2.get("faces") and w2.get("depth", -1) == wl.get("depth", -1):
+                secondary[name] = kernel_figures(torch, pkg, w2, size, srcs[:res], [[d] for d in dsts[:res]], streams[0], name)
+            else:  # its own resident frames: 32 pairs (4 panoramas + cubemaps for configs[4]), far beyond the Infinity Cache
+                s2, d2 = resident_frames(torch, pkg, w2, size2, 4 if w2.get("faces") else min(32, max(res, 1)), dev, 0x5EED1000)
+                secondary[name] = kernel_figures(torch, pkg, w2, size2, s2, d2, streams[0], name)
+                del s2, d2
+                torch.cuda.empty_cache()
         value = total_images * size * size * args.steps / elapsed / 1e6
+        golden = golden_batch_digest(args.workload, total_images) if size == wl["size"] and args.scaling == "strong" else None
         out = {
             "metric": f"Mpix/s reprojected ({'4K' if size == 4096 else size} {'RGBA' if c == 4 else f'{c}-channel'} float, "
                       f"{INTERP_NAMES[wl['interp']]})",
@@ -485,15 +565,24 @@ def main():
                 "parallelism": f"image-sharded x{world} (static blocks of the sorted list), no collective",
             },
             "outputs_digest": digest,
+            # the same digest from the per-image checksums the ORACLE produced in the build container (committed fixture)
+            "outputs_digest_golden": golden,
+            "outputs_match_golden": (digest == golden) if (digest and golden) else None,
             "roofline": roof,
             "secondary": secondary,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, wl, args.cpu_seconds)
         print(json.dumps(out), flush=True)
+        if digest and golden and digest != golden:
+            print("bench.py: the rendered batch differs from the committed oracle checksums (tests/golden/fullframe_golden.json): "
+                  "the number above was measured on WRONG pixels", file=sys.stderr, flush=True)
+            bad_pixels = True
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if bad_pixels:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -19,16 +19,10 @@ namespace lrp_cli {
 
 namespace {
 
-void *pinned_alloc(size_t n) {
-  void *p = nullptr;
-  return lrp_host_alloc(&p, n) == LRP_OK ? p : nullptr;
-}
-void pinned_free(void *p) { lrp_host_free(p); }
-const lrp_io::Allocator kPinned{pinned_alloc, pinned_free};
-
-struct PinnedBuffer { // a page-locked output buffer, reused by a worker from file to file
+struct PinnedBuffer { // a grow-only page-locked buffer, reused by a worker from file to file
   void *ptr = nullptr;
   size_t cap = 0;
+  bool lent = false;
   ~PinnedBuffer() { lrp_host_free(ptr); }
   void *reserve(size_t n) {
     if (n > cap) {
@@ -41,6 +35,34 @@ struct PinnedBuffer { // a page-locked output buffer, reused by a worker from fi
     return ptr;
   }
 };
+
+// Decoded input files land in the worker's own grow-only page-locked buffer: no hipHostMalloc / hipHostFree per file
+// (page-locking tens of MB costs milliseconds, and a free may wait for the device's streams — i.e. for the other
+// workers' uploads, kernels and downloads on the shared pipeline).  A worker holds one decoded file at a time; should
+// a second allocation arrive while the buffer is lent out it gets page-locked memory of its own.
+thread_local PinnedBuffer t_input;
+void *pinned_alloc(size_t n) {
+  if (!t_input.lent) {
+    try {
+      void *p = t_input.reserve(n);
+      t_input.lent = true;
+      return p;
+    } catch (const std::exception &) {
+      return nullptr;
+    }
+  }
+  void *p = nullptr;
+  return lrp_host_alloc(&p, n) == LRP_OK ? p : nullptr;
+}
+void pinned_free(void *p) {
+  if (p != nullptr && p == t_input.ptr)
+    t_input.lent = false; // stays page-locked for the next file
+  else
+    lrp_host_free(p);
+}
+const lrp_io::Allocator kPinned{pinned_alloc, pinned_free};
+
+struct Aborted {}; // thrown by check_status once the abort message has been printed; nothing else uses this type
 
 struct Shared {
   const RunPlan &plan;
@@ -78,7 +100,7 @@ void check_status(Shared &sh, int st) {
   if (st == LRP_ERR_OUTPUT_LENS || st == LRP_ERR_INPUT_LENS || st == LRP_ERR_INTERPOLATION) {
     std::lock_guard<std::mutex> lock(sh.abort_mutex);
     if (!sh.abort.exchange(true)) std::printf("%s\n", lrp_strerror(st));
-    throw std::logic_error("aborted");
+    throw Aborted{};
   }
   throw std::runtime_error(std::string(lrp_strerror(st)) + ": " + lrp_last_error());
 }
@@ -202,7 +224,7 @@ RunResult run_files(const RunPlan &plan, const std::vector<fs::path> &files) {
         if (i >= dev.end) break;
         try {
           process_file(shared, dev, out_buffer, files[i]);
-        } catch (const std::logic_error &) { // aborted: message already printed
+        } catch (const Aborted &) { // message already printed; every other exception type reaches the handler below
           break;
         } catch (const std::exception &e) { // the reference worker's catch (src/main.cpp:617-619)
           std::printf("Error: %s\n", e.what());

@@ -179,7 +179,9 @@ int resolve_input_lens(const CommandLine &cl, const char *argv0, RunPlan &p) {
   if (cl.has("no-configs")) {
     const std::vector<std::string> wh = split(cl["no-configs"], ',');
     p.in_width = std::atoi(wh[0].c_str());
-    p.in_height = wh.size() > 1 ? std::atoi(cl["no-configs"].substr(wh[0].size() + 1).c_str()) : 0;
+    // without a comma the reference's find() yields -1 and substr(comma + 1) is the whole string again: height = width
+    // (src/main.cpp:389-391)
+    p.in_height = std::atoi(wh.size() > 1 ? cl["no-configs"].substr(wh[0].size() + 1).c_str() : cl["no-configs"].c_str());
     const int found = apply_lens_flags(cl, "i-", (float)p.in_width, (float)p.in_height, p.input_lens);
     if (found < 0) return 1;
     if (found > 1) {

@@ -10,9 +10,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/lrp.h"
@@ -436,15 +440,28 @@ int lrp_reproject_multi_device(const lrp_image *in, lrp_image *outs, int n_out, 
 }
 
 namespace {
-// Per participant of lrp_reproject_multi: a stream and grow-only buffers, kept for the next call.
+// Per participant of lrp_reproject_multi: a stream and grow-only buffers, kept for the next call.  A participant is a
+// (device, occurrence) pair — a device list may name one GPU several times (tests on a one-GPU box do) — and is locked
+// for the duration of a job, so jobs on disjoint device sets run concurrently and jobs that share a GPU queue up on it.
 struct MultiPeer {
   int device = -1;
+  std::mutex busy;
   hipStream_t stream = nullptr;
   hipEvent_t source_ready = nullptr;
   Buffer src, out;
 };
-std::mutex g_multi_mutex; // one multi-GPU job at a time (it uses every GPU it is given)
-std::vector<MultiPeer> g_multi_peers;
+std::mutex g_multi_registry_mutex; // guards the map only, never held while a job runs
+std::map<std::pair<int, int>, std::unique_ptr<MultiPeer>> g_multi_peers;
+
+MultiPeer *multi_peer(int device, int occurrence) {
+  std::lock_guard<std::mutex> lock(g_multi_registry_mutex);
+  std::unique_ptr<MultiPeer> &slot = g_multi_peers[{device, occurrence}];
+  if (!slot) {
+    slot.reset(new MultiPeer);
+    slot->device = device;
+  }
+  return slot.get();
+}
 } // namespace
 
 int lrp_reproject_multi(const lrp_image *in, lrp_image *outs, int n_out, int num_samples, int interpolation,
@@ -460,50 +477,54 @@ int lrp_reproject_multi(const lrp_image *in, lrp_image *outs, int n_out, int num
     if (st != LRP_OK) return st;
   }
   if (n_out == 0 || num_samples <= 0) return LRP_OK;
-  std::lock_guard<std::mutex> lock(g_multi_mutex);
-  if (g_multi_peers.size() < (size_t)n_devices) g_multi_peers.resize((size_t)n_devices);
+  // participants in list order; locked in (device, occurrence) order so that two jobs never wait for each other
+  std::vector<MultiPeer *> peers((size_t)n_devices);
+  for (int d = 0; d < n_devices; ++d) {
+    int occurrence = 0;
+    for (int e = 0; e < d; ++e) occurrence += devices[e] == devices[d];
+    peers[(size_t)d] = multi_peer(devices[d], occurrence);
+  }
+  std::vector<MultiPeer *> order(peers);
+  std::sort(order.begin(), order.end(), std::less<MultiPeer *>()); // stable addresses (map of unique_ptr): any total order will do
+  std::vector<std::unique_lock<std::mutex>> locks;
+  for (MultiPeer *p : order) locks.emplace_back(p->busy);
+
   const size_t in_bytes = image_bytes(*in);
   // every participant renders band d of every output: its output buffer holds its bands back to back
   auto band = [&](const lrp_image &o, int d, int &first, int &count) {
     first = (int)((long long)o.height * d / n_devices);
     count = (int)((long long)o.height * (d + 1) / n_devices) - first;
   };
-  for (int d = 0; d < n_devices; ++d) {
-    MultiPeer &p = g_multi_peers[(size_t)d];
-    LRP_HIP_TRY(hipSetDevice(devices[d]));
-    if (p.device != devices[d]) { // the slot served another GPU before: its buffers live there
-      if (p.device >= 0) {
-        (void)hipSetDevice(p.device);
-        p.src.release();
-        p.out.release();
-        if (p.stream) (void)hipStreamDestroy(p.stream);
-        if (p.source_ready) (void)hipEventDestroy(p.source_ready);
-        p.stream = nullptr;
-        p.source_ready = nullptr;
-        LRP_HIP_TRY(hipSetDevice(devices[d]));
-      }
-      p.device = devices[d];
-    }
-    if (!p.stream) LRP_HIP_TRY(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
-    if (!p.source_ready) LRP_HIP_TRY(hipEventCreateWithFlags(&p.source_ready, hipEventDisableTiming));
+  // Everything that can fail after the first asynchronous copy has been enqueued goes through `result` and falls
+  // through to the synchronisation of every participant's stream below: no copy out of in->data or into outs[i].data
+  // is in flight when this function returns, whatever happened.
+  int result = LRP_OK;
+  auto hip_ok = [&](hipError_t e, const char *what) {
+    if (e != hipSuccess && result == LRP_OK) result = hip_fail(e, what);
+    return e == hipSuccess && result == LRP_OK;
+  };
+  for (int d = 0; d < n_devices && result == LRP_OK; ++d) {
+    MultiPeer &p = *peers[(size_t)d];
+    if (!hip_ok(hipSetDevice(p.device), "hipSetDevice")) break;
+    if (!p.stream && !hip_ok(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking), "hipStreamCreateWithFlags")) break;
+    if (!p.source_ready && !hip_ok(hipEventCreateWithFlags(&p.source_ready, hipEventDisableTiming), "hipEventCreateWithFlags")) break;
     size_t out_bytes = 0;
     for (int i = 0; i < n_out; ++i) {
       int first, count;
       band(outs[i], d, first, count);
       out_bytes += (size_t)count * (size_t)outs[i].width * (size_t)outs[i].channels * 4u;
     }
-    int st = p.src.reserve(in_bytes);
-    if (st == LRP_OK) st = p.out.reserve(out_bytes ? out_bytes : 4);
-    if (st != LRP_OK) return st;
+    result = p.src.reserve(in_bytes);
+    if (result == LRP_OK) result = p.out.reserve(out_bytes ? out_bytes : 4);
   }
   // the source: host -> devices[0] once, then device to device
-  MultiPeer &root = g_multi_peers[0];
-  LRP_HIP_TRY(hipSetDevice(root.device));
-  LRP_HIP_TRY(hipMemcpyAsync(root.src.ptr, in->data, in_bytes, hipMemcpyHostToDevice, root.stream));
-  LRP_HIP_TRY(hipEventRecord(root.source_ready, root.stream));
-  for (int d = 1; d < n_devices; ++d) {
-    MultiPeer &p = g_multi_peers[(size_t)d];
-    LRP_HIP_TRY(hipSetDevice(p.device));
+  MultiPeer &root = *peers[0];
+  if (result == LRP_OK && hip_ok(hipSetDevice(root.device), "hipSetDevice") &&
+      hip_ok(hipMemcpyAsync(root.src.ptr, in->data, in_bytes, hipMemcpyHostToDevice, root.stream), "hipMemcpyAsync (source upload)"))
+    hip_ok(hipEventRecord(root.source_ready, root.stream), "hipEventRecord");
+  for (int d = 1; d < n_devices && result == LRP_OK; ++d) {
+    MultiPeer &p = *peers[(size_t)d];
+    if (!hip_ok(hipSetDevice(p.device), "hipSetDevice")) break;
     int can = p.device == root.device ? 1 : 0;
     if (!can) {
       (void)hipDeviceCanAccessPeer(&can, p.device, root.device);
@@ -514,18 +535,17 @@ int lrp_reproject_multi(const lrp_image *in, lrp_image *outs, int n_out, int num
       }
     }
     if (can) {
-      LRP_HIP_TRY(hipStreamWaitEvent(p.stream, root.source_ready, 0));
-      LRP_HIP_TRY(hipMemcpyPeerAsync(p.src.ptr, p.device, root.src.ptr, root.device, in_bytes, p.stream));
+      if (hip_ok(hipStreamWaitEvent(p.stream, root.source_ready, 0), "hipStreamWaitEvent"))
+        hip_ok(hipMemcpyPeerAsync(p.src.ptr, p.device, root.src.ptr, root.device, in_bytes, p.stream), "hipMemcpyPeerAsync");
     } else {
-      LRP_HIP_TRY(hipMemcpyAsync(p.src.ptr, in->data, in_bytes, hipMemcpyHostToDevice, p.stream));
+      hip_ok(hipMemcpyAsync(p.src.ptr, in->data, in_bytes, hipMemcpyHostToDevice, p.stream), "hipMemcpyAsync (second upload)");
     }
   }
   // bands: render into the participant's buffer at the band's own row offset (the kernels address whole images),
   // download each band to its rows of the host output
-  int result = LRP_OK;
   for (int d = 0; d < n_devices && result == LRP_OK; ++d) {
-    MultiPeer &p = g_multi_peers[(size_t)d];
-    LRP_HIP_TRY(hipSetDevice(p.device));
+    MultiPeer &p = *peers[(size_t)d];
+    if (!hip_ok(hipSetDevice(p.device), "hipSetDevice")) break;
     size_t cursor = 0; // floats into p.out
     for (int i = 0; i < n_out && result == LRP_OK; ++i) {
       int first, count;
@@ -539,15 +559,16 @@ int lrp_reproject_multi(const lrp_image *in, lrp_image *outs, int n_out, int num
       result = enqueue_reproject(&din, &dout, num_samples, interpolation, rotations ? rotations + 9 * i : nullptr, post, p.device,
                                  p.stream, 0, first, count);
       if (result != LRP_OK) break;
-      LRP_HIP_TRY(hipMemcpyAsync(outs[i].data + (size_t)first * row_floats, (float *)p.out.ptr + cursor, (size_t)count * row_floats * 4u,
-                                 hipMemcpyDeviceToHost, p.stream));
+      hip_ok(hipMemcpyAsync(outs[i].data + (size_t)first * row_floats, (float *)p.out.ptr + cursor, (size_t)count * row_floats * 4u,
+                            hipMemcpyDeviceToHost, p.stream), "hipMemcpyAsync (band download)");
       cursor += (size_t)count * row_floats;
     }
   }
-  for (int d = 0; d < n_devices; ++d) {
-    MultiPeer &p = g_multi_peers[(size_t)d];
-    (void)hipSetDevice(p.device);
-    const hipError_t e = hipStreamSynchronize(p.stream);
+  // the one exit: every participant's stream drained, then the first error (if any)
+  for (MultiPeer *p : peers) {
+    if (!p->stream) continue;
+    (void)hipSetDevice(p->device);
+    const hipError_t e = hipStreamSynchronize(p->stream);
     if (e != hipSuccess && result == LRP_OK) result = hip_fail(e, "hipStreamSynchronize");
   }
   return result;

@@ -264,7 +264,12 @@ hipError_t read_flag(const int *d_flag, int *flag, hipStream_t stream) {
 } // namespace
 
 void TableLease::release() {
-  for (int i = 0; i < n; ++i) pins[i]->fetch_sub(1, std::memory_order_release);
+  if (n == 0) return;
+  // Under g_mutex and child first (pins[1], the xsep table built on the output table pins[0]): an eviction pass never
+  // sees a pinned column table whose output table has already been unpinned — it would free the parent and keep an
+  // xsep entry keyed on the dangling pointer, which a later hipMalloc may hand out again for another lens.
+  std::lock_guard<std::mutex> lock(g_mutex);
+  for (int i = n - 1; i >= 0; --i) pins[i]->fetch_sub(1, std::memory_order_release);
   n = 0;
 }
 

@@ -35,8 +35,12 @@ LRP_HD static inline uint32_t lrp_half_to_float_bits(uint16_t h) {
 LRP_HD static inline uint16_t lrp_float_bits_to_half(uint32_t x) {
   const uint32_t sign = (x >> 16) & 0x8000u;
   x &= 0x7fffffffu;
-  if (x >= 0x7f800000u) /* inf / NaN (quiet, payload's top bits kept) */
-    return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? (0x200u | ((x >> 13) & 0x3ffu)) : 0u));
+  if (x >= 0x7f800000u) { /* inf / NaN: the payload's top ten bits kept, bit 0 set if they are all zero — Imath's
+                             software conversion (what the reference's default build, without -mf16c, runs) and numpy's;
+                             the F16C instruction would set the quiet bit of a signalling NaN instead */
+    const uint32_t m = (x >> 13) & 0x3ffu;
+    return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? (m | (m == 0u ? 1u : 0u)) : 0u));
+  }
   if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u); /* rounds to inf (>= 65520) */
   if (x < 0x33000001u) return (uint16_t)sign;              /* <= 2^-25: +-0 */
   if (x < 0x38800000u) {                                   /* subnormal half */

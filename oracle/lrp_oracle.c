@@ -390,3 +390,17 @@ void lrpo_synth_fill(float *data, int width, int height, int channels, uint32_t 
   for (uint32_t p = 0; p < n; ++p)
     for (int c = 0; c < channels; ++c, ++idx) data[idx] = lrpo_synth_value(seed, idx, c == depth_channel);
 }
+
+/* Host twin of lrp_checksum_device (csrc/lrp_aux_kernels.hip; not in the reference): the sum
+ * mod 2^64 over all elements of a 64-bit hash of (bit pattern, index).  Order-independent. */
+uint64_t lrpo_checksum(const float *data, size_t n) {
+  const uint32_t *bits = (const uint32_t *)data;
+  uint64_t acc = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t idx = (uint32_t)i;
+    const uint32_t lo = mix32(bits[i], idx);
+    const uint32_t hi = mix32(bits[i] ^ 0xA5A5A5A5u, idx * 2u + 0x7F4A7C15u);
+    acc += ((uint64_t)hi << 32) | lo;
+  }
+  return acc;
+}

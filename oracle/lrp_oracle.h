@@ -28,6 +28,7 @@
 #ifndef LRP_ORACLE_H
 #define LRP_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -101,6 +102,9 @@ void lrpo_rotation_matrix(float pan, float pitch, float roll, float *out9);
 float lrpo_synth_value(uint32_t seed, uint32_t index, int kind);
 void lrpo_synth_fill(float *data, int width, int height, int channels, uint32_t seed,
                      int depth_channel /* -1 = none */);
+/* Host twin of the product's lrp_checksum_device (include/lrp.h): order-independent 64-bit
+ * checksum of the bit patterns of n floats (fixtures and bench checks; not in the reference). */
+uint64_t lrpo_checksum(const float *data, size_t n);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,8 @@ def lib():
         L.lrpo_synth_fill.restype = None
         L.lrpo_synth_fill.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,
                                       ctypes.c_int]
+        L.lrpo_checksum.restype = ctypes.c_uint64
+        L.lrpo_checksum.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
         _lib = L
     return _lib
 
@@ -149,6 +151,12 @@ def synth_frame(width, height, channels, seed, depth_channel=-1):
     a = np.empty((height, width, channels), dtype=np.float32)
     lib().lrpo_synth_fill(a.ctypes.data, width, height, channels, seed & 0xFFFFFFFF, depth_channel)
     return a
+
+
+def checksum(array):
+    """Host twin of lrp_checksum_device (the product's order-independent 64-bit checksum)."""
+    a = np.ascontiguousarray(array, dtype=np.float32)
+    return int(lib().lrpo_checksum(a.ctypes.data, a.size))
 
 
 def reproject_rows(in_lens, src, out_lens, out_w, out_h, num_samples, interpolation, rotation, rows):

@@ -414,3 +414,22 @@ def test_failed_files_make_the_exit_status_nonzero(cli, torch_cuda, tmp_path):
     r = run(cli, "-i", tmp_path, "-o", tmp_path / "o", "--png", "--no-configs", "8,8", "--i-equirectangular", "full",
             "--rectilinear", "18,36")
     assert r.returncode == 1 and "Error: cannot decode PNG" in r.stdout and (tmp_path / "o" / "a_good.png").exists()
+
+
+@pytest.mark.gpu
+def test_no_configs_without_comma_means_square(cli, torch_cuda, tmp_path):
+    """`--no-configs 48`: the reference's find(",") yields -1 and both substrings are the whole value
+    (src/main.cpp:389-391), so the height equals the width; the run must equal `--no-configs 48,48` byte for byte
+    (the sensor height of --i-rectilinear and the scale-derived output height both come from it)."""
+    from PIL import Image
+
+    rng = np.random.default_rng(77)
+    Image.fromarray(rng.integers(0, 256, size=(48, 48, 3), dtype=np.uint8), "RGB").save(tmp_path / "sq.png")
+    outs = []
+    for k, size in enumerate(("48", "48,48")):
+        out = tmp_path / f"out{k}"
+        r = run(cli, "--single", tmp_path / "sq.png", "-o", out, "--png", "--no-configs", size, "--i-rectilinear", "18,36",
+                "--equirectangular", "full", "--bl")
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(np.array(Image.open(out / "sq.png")))
+    assert outs[0].shape == (48, 48, 4) and (outs[0] == outs[1]).all()
