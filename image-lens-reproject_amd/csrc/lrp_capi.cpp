@@ -189,6 +189,14 @@ bool quad_enabled() {
   }();
   return on;
 }
+// LRP_MIRROR_MODES=0 keeps pan / pitch rotations on the plain blocks of the window kernel (A/B checks).
+bool mirror_modes_enabled() {
+  static const bool on = [] {
+    const char *v = std::getenv("LRP_MIRROR_MODES");
+    return !(v && std::strcmp(v, "0") == 0);
+  }();
+  return on;
+}
 // LRP_XSEP=0 in the environment switches the column-separable source x tables off (A/B checks).
 bool xsep_enabled() {
   static const bool on = [] {
@@ -219,7 +227,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
   hipError_t e;
   lrp::TableLease lease; // pins the cached tables until every launch of this call is enqueued (scope end)
   const bool tile_channels = out->channels >= 3 && out->channels <= 5;
-  bool mirror = false; // the output-lens tables are symmetric about the image centre
+  int symmetry = 0; // bit 0 / 1: the column / row terms of the output-lens tables are mirror images about the image centre
   bool tile = kernel_choice() != 0 && tile_channels && in->width <= 65535 && in->height <= 32767 &&
               (long long)out->width * num_samples < (1ll << 30) && (long long)out->height * num_samples < (1ll << 30);
   if (tile && out->lens.type != LRP_FISHEYE_EQUIDISTANT) {
@@ -227,7 +235,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     const int out_kind = out->lens.type == LRP_RECTILINEAR ? lrp::kRect : lrp::kEquirect;
     bool plain = false;
     e = lrp::get_output_tables(device, out_kind, P.out_lens, out->width, out->height, num_samples, stream, lease,
-                               &P.col_tab, &P.row_tab, &plain, &mirror);
+                               &P.col_tab, &P.row_tab, &plain, &symmetry);
     if (e == hipErrorOutOfMemory) {
       (void)hipGetLastError();
       tile = false; // no memory for the tables: per-pixel kernel
@@ -253,7 +261,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     // takes part through the column-separable x table only (its longitude is not odd in x).
     // Family 3 keeps every sharing path of the tile / window kernels off (cross-checks).
     const bool in_eqr = im == lrp::kInEquirect || im == lrp::kInEquirectLoop;
-    const bool sym_out = out->lens.type == LRP_FISHEYE_EQUIDISTANT ? true : mirror;
+    const bool sym_out = out->lens.type == LRP_FISHEYE_EQUIDISTANT ? true : symmetry == 3;
     P.quad = !band && quad_enabled() && kernel_choice() != 3 && num_samples == 1 && !P.has_rot && sym_out &&
              (!in_eqr || P.xsep_tab != nullptr);
     const bool window = interpolation == LRP_BICUBIC && kernel_choice() >= 2 && num_samples == 1 &&
@@ -264,6 +272,19 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
         out->lens.type == LRP_FISHEYE_EQUIDISTANT)
       P.quad = 2;
     P.win_coef = kernel_choice() == 2;
+    // Mirror mode of the window kernel (lrp_kernel_v2.h QMode): both axes without a rotation; rows only for a pan,
+    // columns only for a pitch into a rectilinear target.  Signed zeros count as zeros in the matrix tests.
+    P.win_mode = P.quad == 1 ? 1 : 0;
+    if (window && P.win_mode == 0 && !band && quad_enabled() && mirror_modes_enabled() && kernel_choice() != 3 && P.has_rot) {
+      const float *R = P.rot;
+      auto tiny = [](float v) { return !(std::fabs(v) >= 0x1p-20f); }; // (also true for a NaN)
+      if (P.xsep_tab != nullptr && (symmetry & 2) && R[3] == 0.0f && R[5] == 0.0f && !tiny(R[4]))
+        P.win_mode = 2; // ny = R4 vy exactly: odd in vy; nx, nz come from the column table
+      else if (out->lens.type == LRP_RECTILINEAR && (symmetry & 1) && R[1] == 0.0f && R[2] == 0.0f && R[3] == 0.0f && R[6] == 0.0f &&
+               !tiny(R[0]) && R[5] != 0.0f && R[8] != 0.0f && std::isfinite(R[4]) && std::isfinite(R[5]) && std::isfinite(R[7]) &&
+               std::isfinite(R[8]))
+        P.win_mode = 3; // nx = R0 vx exactly: odd in vx; ny, nz end in the non-zero terms R5 vz, R8 vz (vz = -1: no underflow)
+    }
     // The view's copy behind the camera sits half a turn away, upside down (lrp_kernel_v2.h "alias pairs"): only when
     // the panorama spans the full turn and the rotation neither pitches nor rolls.
     P.alias_pairs = 0;

@@ -201,7 +201,38 @@ __device__ __forceinline__ void bicubic_indices(float sx, float sy, int w, int h
 // plus a single (c2 for RGB, c4 for RGBAZ); every interpolation step is one packed
 // instruction per pair (v_pk_mul_f32 / v_pk_add_f32 round each half exactly like
 // the scalar instruction) plus a scalar one for the odd channel, weights broadcast.
+#ifndef LRP_NO_PACKED
+#define LRP_NO_PACKED 0
+#endif
+#if LRP_NO_PACKED
+// Channel pairs as two independent floats: every operation is a plain VOP2 / VOP3 instruction (build with
+// -fno-slp-vectorize so that the compiler does not fuse them back into v_pk_*_f32).  On gfx950 a wavefront
+// whose VALU stream contains packed-f32 instructions issues ALL its VALU instructions at ~4 cycles; a stream
+// without them issues plain, SGPR-operand, convert and compare instructions at ~2.2 (tools/microbench/valu_runs.hip).
+struct f2 {
+  float x, y;
+};
+__device__ __forceinline__ f2 operator+(const f2 a, const f2 b) { return f2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ f2 operator-(const f2 a, const f2 b) { return f2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ f2 operator*(const f2 a, const f2 b) { return f2{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ f2 operator+(const f2 a, const float b) { return f2{a.x + b, a.y + b}; }
+__device__ __forceinline__ f2 operator-(const f2 a, const float b) { return f2{a.x - b, a.y - b}; }
+__device__ __forceinline__ f2 operator*(const f2 a, const float b) { return f2{a.x * b, a.y * b}; }
+__device__ __forceinline__ f2 operator+(const float a, const f2 b) { return f2{a + b.x, a + b.y}; }
+__device__ __forceinline__ f2 operator*(const float a, const f2 b) { return f2{a * b.x, a * b.y}; }
+__device__ __forceinline__ f2 &operator+=(f2 &a, const f2 b) {
+  a.x += b.x;
+  a.y += b.y;
+  return a;
+}
+__device__ __forceinline__ f2 &operator+=(f2 &a, const float b) {
+  a.x += b;
+  a.y += b;
+  return a;
+}
+#else
 typedef float f2 __attribute__((ext_vector_type(2)));
+#endif
 template <int CH> struct Px {
   f2 lo; // channels 0, 1
   f2 hi; // channels 2, 3 (CH >= 4)
@@ -1189,13 +1220,35 @@ template <bool Fat> struct WinBlockT {
 // untouched), i.e. the hardware expands RGB texels into RGBA-sized slots.  Everything after the
 // DMA is therefore the RGBA code; the fourth component carries stale LDS contents through the
 // arithmetic (no traps are enabled) and is never stored.
-template <int OutLens, int InMode, bool Quad, int CH>
+//
+// QMode — which mirror images of a block one wavefront renders with a single evaluation of stage 1 of the
+// coordinate math (everything between the output pixel and the last quantity that only changes sign under the mirror):
+//   0  plain blocks: none (any rotation)
+//   1  both axes (no rotation): the block and its three mirror images, g = 0..3, bit 0 mirrors x, bit 1 mirrors y
+//   2  rows only: a rotation about the vertical axis (pan) leaves the mapping symmetric top / bottom — the rotated ray of
+//      pixel (x, H-1-y) is the ray of (x, y) with its y negated, exactly (rows 0 and 2 of the matrix do not see vy: that
+//      is the column-separable case, which the host requires; row 1 is (+-0, c, +-0)).  Images g = 0, 2.  The four
+//      side faces of a cubemap, any --rotation pan,0,0.
+//   3  columns only: a rotation about the horizontal axis (pitch) with a rectilinear target (vz = -1 exactly) leaves it
+//      symmetric left / right: rows 1 and 2 of the matrix are (+-0, c, -s) / (+-0, s, c), so ny, nz do not see vx (the
+//      zero products vanish in sums that end in the non-zero R5 vz, R8 vz) and nx = vx.  Images g = 0, 1.  The top and
+//      bottom faces of a cubemap, any --rotation 0,pitch,0.
+// The host (lrp_capi.cpp win_mirror_mode) checks the matrix entries and the symmetry flags of the output-lens tables.
+template <int OutLens, int InMode, int QMode, int CH>
 #ifndef LRP_WIN_MINWAVES5
 #define LRP_WIN_MINWAVES5 3 // RGBAZ: 168 VGPRs (the 80 registers of a direct-path tap set do not fit 128 without spilling)
 #endif
-__global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_MINWAVES) void reproject_bicubic_win_kernel(const KParams Pk) {
+#ifndef LRP_WIN_MINWAVES_AXIS
+#define LRP_WIN_MINWAVES_AXIS 4 // one-axis mirror modes (QMode 2, 3)
+#endif
+__global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode >= 2 ? LRP_WIN_MINWAVES_AXIS : LRP_WIN_MINWAVES)) void reproject_bicubic_win_kernel(const KParams Pk) {
+  constexpr bool Quad = QMode != 0;
+  constexpr bool MirX = QMode == 1 || QMode == 3, MirY = QMode == 1 || QMode == 2;
+  constexpr int kAllMirrors = (MirX ? 1 : 0) | (MirY ? 2 : 0); // the image mirrored in every mirrored axis
   using WinBlock = WinBlockT<Quad>;
   static_assert(CH == 3 || CH == 4 || CH == 5, "window kernel: RGB, RGBA or RGBAZ");
+  static_assert(QMode != 2 || (OutLens != kEquidistant && InMode != kInEquidistant), "rows-only mirroring goes through the column-separable source x");
+  static_assert(QMode != 3 || OutLens == kRect, "columns-only mirroring needs vz == -1");
   static_assert(CH != 5 || LRP_WIN_SIGNED_PITCH == 0, "the RGBAZ depth plane assumes top-down window rows");
   const KParams P = batch_frame(Pk);
   constexpr bool Loop = (InMode == kInEquirectLoop);
@@ -1220,9 +1273,16 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
   int g_flip = 0;        // mirrored strips: the mirror image rendered by loop iteration g is g ^ g_flip
   bool g_reverse = false; // plain strips: iteration g renders block G-1-g
   if (kAliasPairs && P.alias_pairs != 0) {
-    if constexpr (Quad) {
+    if constexpr (QMode == 1) {
       g_flip = (tx & 1) ? 3 : 0;
       tx = (tx & 1) ? P.tiles_x - 1 - (tx >> 1) : (tx >> 1);
+    } else if constexpr (QMode == 2) {
+      // rows-only strips span all columns: the partner of strip t is strip t + tiles_x/2, whose image 2 (bottom) reads what
+      // image 0 (top) of this one reads
+      if ((P.tiles_x & 1) == 0) {
+        g_flip = (tx & 1) ? 2 : 0;
+        tx = (tx >> 1) + ((tx & 1) ? P.tiles_x >> 1 : 0);
+      }
     } else if ((P.tiles_x & 1) == 0) {
       g_reverse = (tx & 1) != 0;
       tx = (tx >> 1) + (g_reverse ? P.tiles_x >> 1 : 0);
@@ -1242,8 +1302,11 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
   // its three mirror images (g = 0..3: bit 0 mirrors x, bit 1 mirrors y), and stage 1 of
   // the coordinate math (pixel_plane) runs once for the four of them.
   constexpr bool quad = Quad;
-  const int qw = quad ? (P.out_w + 1) >> 1 : P.out_w; // columns / rows enumerated by the launch
-  const int qh = quad ? (P.out_h + 1) >> 1 : P.y_end; // (a row band: rows beyond it re-render its last row)
+  const int qw = MirX ? (P.out_w + 1) >> 1 : P.out_w; // columns / rows enumerated by the launch
+  const int qh = MirY ? (P.out_h + 1) >> 1 : P.y_end; // (a row band: rows beyond it re-render its last row)
+  // mirror image rendered by loop iteration g of a mirrored strip (bit 0: mirrored in x, bit 1: in y)
+  // (masked: the compiler then knows that an axis which is not mirrored never selects the mirrored column / sign)
+  auto image_of = [&](int g) { return ((QMode == 2 ? 2 * g : g) ^ g_flip) & (QMode == 2 ? kAllMirrors : -1); };
   // workgroup tile = 16 kWinWaves x 16G (x 16 of the quadrant when mirrored): one strip per wavefront
   int prow, pcol; // this lane's pixel of a pass
   win_lane_pixel(lane, prow, pcol);
@@ -1262,16 +1325,24 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
   }
   const ColTerms col = column_terms<OutLens>(P, xe, 0);
   ColTerms col_m = col; // the mirrored column
-  if constexpr (Quad) col_m = column_terms<OutLens>(P, P.out_w - 1 - xe, 0);
+  if constexpr (MirX) col_m = column_terms<OutLens>(P, P.out_w - 1 - xe, 0);
   // Stage-1 results of the four quadrant pixels of this lane, kept for the whole strip:
   //   rectilinear / equidistant source: (qa, qb) = plane coordinates (u, v); a mirror image negates them;
   //   equirectangular source (through the xsep table): qa, qb = source texel y for +phi and for -phi
   //   (the division of :269 once per sign, not once per mirror image); x comes from the column tables.
+  //   columns-only mirroring of an equirectangular source (no column table: the rotation pitches): the longitude
+  //   theta = -atan2f(-nx, -nz) is odd in nx (lrp_math.h atan2f_: the sign of y only selects +-z, tests/test_math_vs_libm.py),
+  //   the latitude does not see its sign: qa, qc = source texel x for +theta and for -theta, qb = source texel y.
   float qa[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   constexpr bool kInEqr = InMode == kInEquirect || InMode == kInEquirectLoop;
+  constexpr bool kEqrByTheta = QMode == 3 && kInEqr;
+  float qc[kEqrByTheta ? 4 : 1] = {};
   auto quad_xy = [&](int g, int k, float &sx, float &sy) { // source texel coordinates of pixel k of mirror image g
     const bool mx = (g & 1) != 0, my = (g >> 1) != 0;
-    if constexpr (kInEqr) {
+    if constexpr (kEqrByTheta) {
+      sx = mx ? qc[k] : qa[k];
+      sy = qb[k];
+    } else if constexpr (kInEqr) {
       sx = mx ? col_m.sx : col.sx;
       sy = my ? qb[k] : qa[k];
     } else {
@@ -1419,13 +1490,13 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
   uint32_t plan_exact = 0;
   constexpr bool kStripPlan = Quad && LRP_WIN_STRIP_PLAN != 0 && LRP_WIN_SIGNED_PITCH == 0 && LRP_ABLATE == 0;
   auto plan_strip = [&]() {
-    Extremes e0, e1; // unmirrored (g = 0) and mirrored in both axes (g = 3)
+    Extremes e0, e1; // unmirrored (image 0) and mirrored in every mirrored axis (an axis that is not mirrored has one range: e1's equals e0's)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float sx, sy;
       quad_xy(0, k, sx, sy);
       note_pixel(e0, k, sx, sy);
-      quad_xy(3, k, sx, sy);
+      quad_xy(kAllMirrors, k, sx, sy);
       note_pixel(e1, k, sx, sy);
     }
     plan_exact = (wave_all(e0.exact_x != 0) ? 1u : 0u) | (wave_all(e1.exact_x != 0) ? 2u : 0u) |
@@ -1443,7 +1514,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
   auto coords = [&](int g, WinBlock &b) {
     // the four row terms first, all loads in flight together (one exposed latency per
     // block instead of one in front of every pixel's coordinate chain)
-    const int gm = g ^ g_flip; // (plain blocks: g_flip == 0)
+    const int gm = image_of(g); // (plain blocks: g)
     const int mx = quad ? (gm & 1) : 0, my = quad ? (gm >> 1) : 0;
     (void)mx;
     (void)my;
@@ -1461,14 +1532,41 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
         const int yk = y_lane + kPassRows * k;
         const int ye = yk < qh ? yk : qh - 1;
         float u, v;
-        pixel_plane<OutLens, InMode>(P, col, row_v[k], ye, 0, u, v);
-        if constexpr (kInEqr) { // host guarantees the xsep table: v = phi
-          float unused;
-          plane_to_texel<OutLens, InMode>(P, col, u, v, unused, qa[k]);
-          plane_to_texel<OutLens, InMode>(P, col, u, -v, unused, qb[k]);
+        if constexpr (kEqrByTheta) {
+          // vec_to_equirectangular (src/reproject.cpp:259-271) split at the longitude: everything up to theta once, the
+          // rest of :268 once per sign of theta; the latitude half is the same for both mirror images
+          float vx, vy, vz;
+          pixel_ray<OutLens>(P, col, row_v[k], ye, 0, vx, vy, vz);
+          if (P.has_rot) { // :303-311
+            const float nx = P.rot[0] * vx + P.rot[1] * vy + P.rot[2] * vz;
+            const float ny = P.rot[3] * vx + P.rot[4] * vy + P.rot[5] * vz;
+            const float nz = P.rot[6] * vx + P.rot[7] * vy + P.rot[8] * vz;
+            vx = nx;
+            vy = ny;
+            vz = nz;
+          }
+          const float lon_min = P.in_lens.p[2], img_w = (float)P.in_w;
+          const float theta = -atan2f_(-vx, -vz); // :262
+          qa[k] = texel_coord(((theta - lon_min) / P.in_lon_span - 0.5f) * img_w, img_w);  // :268, :323
+          qc[k] = texel_coord(((-theta - lon_min) / P.in_lon_span - 0.5f) * img_w, img_w); // the mirrored pixel's
+          // the centre column of an odd-sized image is its own mirror image: nx is a zero, theta is 0 or +-pi, and -pi is
+          // not the same longitude bit for bit — the pixel is rendered twice, both times with its own theta
+          if (2 * xe == P.out_w - 1) qc[k] = qa[k];
+          qb[k] = texel_coord(equirect_cy(vx, vy, vz, P.in_lens.p[0], P.in_lat_span, (float)P.in_h), (float)P.in_h); // :263, :269, :324
+          (void)u;
+          (void)v;
+          // one pixel after the other: interleaved, the four atan2f / asinf evaluations need more registers than there are
+          __builtin_amdgcn_sched_barrier(0);
         } else {
-          qa[k] = u;
-          qb[k] = v;
+          pixel_plane<OutLens, InMode>(P, col, row_v[k], ye, 0, u, v);
+          if constexpr (kInEqr) { // host guarantees the xsep table: v = phi
+            float unused;
+            plane_to_texel<OutLens, InMode>(P, col, u, v, unused, qa[k]);
+            plane_to_texel<OutLens, InMode>(P, col, u, -v, unused, qb[k]);
+          } else {
+            qa[k] = u;
+            qb[k] = v;
+          }
         }
       }
       if constexpr (kStripPlan) plan_strip();
@@ -1649,7 +1747,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
     if constexpr (Quad && kInEqr) asm volatile("" : "+v"(y_base));
     const int yk = y_base + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
     const int yc = yk < qh ? yk : qh - 1;
-    const int gm = g ^ g_flip;
+    const int gm = image_of(g);
     const int xo = (quad && (gm & 1)) ? P.out_w - 1 - xe : xe; // mirrored blocks write the mirrored pixel
     const int yo = (quad && (gm >> 1)) ? P.out_h - 1 - yc : yc;
 #if defined(LRP_NO_STORE) // timing experiment: almost no output traffic
@@ -1742,7 +1840,11 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : LRP_WIN_
         const bool last_pass = kWinBuffers == 1 && LRP_ABLATE == 0 && k == 3;
         if (Quad && k == 3 && g + 1 < G) coords(g + 1, nxt); // only its box is kept
         float psx = cur.sx[k], psy = cur.sy[k];
-        if constexpr (Quad) quad_xy(g ^ g_flip, k, psx, psy); // re-derived (2-4 instructions) instead of held in registers
+        if constexpr (Quad) quad_xy(image_of(g), k, psx, psy); // re-derived (2-4 instructions) instead of held in registers
+        // (where the coordinates of a mirror image are a plain selection of stored values the compiler would otherwise
+        // hoist everything derived from them — truncations, weights, window addresses of all four passes and both
+        // images — out of the block loop and spill it: the selected values are opaque here)
+        if constexpr (QMode >= 2) asm volatile("" : "+v"(psx), "+v"(psy));
         Rgba s;
         if (kWinCoef && cur.coef()) {
           const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
@@ -1887,31 +1989,42 @@ template <int Interp> hipError_t launch_tile_interp(KParams P, int out_idx, int 
   return hipGetLastError();
 }
 
-template <bool Quad, int CH> struct WinKernelTable {
+// The window kernel of one (output lens, source mode) cell for a mirror mode, or null where the mode does not exist
+// (rows-only needs the column-separable source x: no equidistant lens on either side; columns-only a rectilinear target).
+template <int OutLens, int InMode, int QMode, int CH> constexpr TileKernelFn win_kernel_fn() {
+  if constexpr (QMode == 2 && (OutLens == kEquidistant || InMode == kInEquidistant))
+    return nullptr;
+  else if constexpr (QMode == 3 && OutLens != kRect)
+    return nullptr;
+  else
+    return reproject_bicubic_win_kernel<OutLens, InMode, QMode, CH>;
+}
+template <int QMode, int CH> struct WinKernelTable {
   static TileKernelFn get(int out_idx, int in_mode) {
     static const TileKernelFn table[3][4] = {
-        {reproject_bicubic_win_kernel<kRect, kInRect, Quad, CH>, reproject_bicubic_win_kernel<kRect, kInEquidistant, Quad, CH>,
-         reproject_bicubic_win_kernel<kRect, kInEquirect, Quad, CH>, reproject_bicubic_win_kernel<kRect, kInEquirectLoop, Quad, CH>},
-        {reproject_bicubic_win_kernel<kEquidistant, kInRect, Quad, CH>,
-         reproject_bicubic_win_kernel<kEquidistant, kInEquidistant, Quad, CH>,
-         reproject_bicubic_win_kernel<kEquidistant, kInEquirect, Quad, CH>,
-         reproject_bicubic_win_kernel<kEquidistant, kInEquirectLoop, Quad, CH>},
-        {reproject_bicubic_win_kernel<kEquirect, kInRect, Quad, CH>, reproject_bicubic_win_kernel<kEquirect, kInEquidistant, Quad, CH>,
-         reproject_bicubic_win_kernel<kEquirect, kInEquirect, Quad, CH>,
-         reproject_bicubic_win_kernel<kEquirect, kInEquirectLoop, Quad, CH>}};
+        {win_kernel_fn<kRect, kInRect, QMode, CH>(), win_kernel_fn<kRect, kInEquidistant, QMode, CH>(),
+         win_kernel_fn<kRect, kInEquirect, QMode, CH>(), win_kernel_fn<kRect, kInEquirectLoop, QMode, CH>()},
+        {win_kernel_fn<kEquidistant, kInRect, QMode, CH>(), win_kernel_fn<kEquidistant, kInEquidistant, QMode, CH>(),
+         win_kernel_fn<kEquidistant, kInEquirect, QMode, CH>(), win_kernel_fn<kEquidistant, kInEquirectLoop, QMode, CH>()},
+        {win_kernel_fn<kEquirect, kInRect, QMode, CH>(), win_kernel_fn<kEquirect, kInEquidistant, QMode, CH>(),
+         win_kernel_fn<kEquirect, kInEquirect, QMode, CH>(), win_kernel_fn<kEquirect, kInEquirectLoop, QMode, CH>()}};
     return table[out_idx][in_mode];
   }
 };
 
-// num_samples must be 1 (the pipeline keeps no accumulator across sub-samples).
-template <bool Quad, int CH>
+// num_samples must be 1 (the pipeline keeps no accumulator across sub-samples).  QMode != 0: P.win_mode == QMode,
+// set by the host only for cells where the mode exists.
+template <int QMode, int CH>
 inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, hipStream_t stream) {
   const int rows = P.y_end - P.y_offset;
-  if (Quad) {
-    // the launch enumerates the top-left quadrant; a wavefront renders a block and its three mirror images
-    P.tiles_x = ((P.out_w + 1) / 2 + kBlkW * kWinWaves - 1) / (kBlkW * kWinWaves);
-    P.tiles_y = ((P.out_h + 1) / 2 + kBlkH - 1) / kBlkH;
-    P.blocks_per_wave = 4;
+  if (QMode != 0) {
+    // the launch enumerates the top-left quadrant (the top / the left half when one axis is mirrored); a wavefront
+    // renders a block and its mirror images
+    const int qw = (QMode == 1 || QMode == 3) ? (P.out_w + 1) / 2 : P.out_w;
+    const int qh = (QMode == 1 || QMode == 2) ? (P.out_h + 1) / 2 : P.out_h;
+    P.tiles_x = (qw + kBlkW * kWinWaves - 1) / (kBlkW * kWinWaves);
+    P.tiles_y = (qh + kBlkH - 1) / kBlkH;
+    P.blocks_per_wave = QMode == 1 ? 4 : 2;
   } else {
     P.tiles_x = (P.out_w + kBlkW * kWinWaves - 1) / (kBlkW * kWinWaves);
     // strips of LRP_WIN_STRIP blocks when that still leaves >= 8 workgroups per CU, else shorter
@@ -1923,7 +2036,8 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
   }
   const int n_tiles = P.tiles_x * P.tiles_y;
   if (n_tiles <= 0) return hipSuccess;
-  const TileKernelFn fn = WinKernelTable<Quad, CH>::get(out_idx, in_mode);
+  const TileKernelFn fn = WinKernelTable<QMode, CH>::get(out_idx, in_mode);
+  if (!fn) return hipErrorInvalidValue; // (the host never asks for a mode outside its cells)
   hipLaunchKernelGGL(fn, dim3((unsigned)(kXcds * xcd_rows(P.tiles_y) * P.tiles_x), (unsigned)(P.batch_n > 0 ? P.batch_n : 1)), dim3(kWinThreads), 0, stream, P);
   return hipGetLastError();
 }

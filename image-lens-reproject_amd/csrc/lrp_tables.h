@@ -24,12 +24,12 @@ struct TableLease {
 // (rectilinear uses the first half only) and *row_tab has out_h * ns floats, both
 // complete (the build is synchronous) and valid while `lease` pins them.
 // *plain: no table value is -0.0f, an infinity or a NaN (then an identity rotation
-// matrix changes no bit of any ray and may be dropped).  *mirror: ns == 1 and the tables are
-// symmetric about the image centre bit for bit: vx(W-1-x) == -vx(x), vz(W-1-x) == vz(x),
-// vy(H-1-y) == -vy(y).
+// matrix changes no bit of any ray and may be dropped).  *symmetry (ns == 1 only, else 0): bit 0 = the columns
+// are mirror images bit for bit, vx(W-1-x) == -vx(x), vz(W-1-x) == vz(x); bit 1 = the rows are,
+// vy(H-1-y) == -vy(y); and no |vx| / |vy| other than a centre zero is below 2^-60.
 // A miss builds the tables on `stream` and waits for it.
 hipError_t get_output_tables(int device, int out_lens, const LensP &lens, int out_w, int out_h, int ns, hipStream_t stream,
-                             TableLease &lease, const float **col_tab, const float **row_tab, bool *plain, bool *mirror);
+                             TableLease &lease, const float **col_tab, const float **row_tab, bool *plain, int *symmetry);
 // Column-separable source x for a rectilinear / equirectangular source (in_mode kInRect,
 // kInEquirect or kInEquirectLoop) behind the output tables `col_tab`: [3][out_w * ns] floats
 // (rotated ray x, rotated ray z, source texel x), or null when it does not apply (the sign

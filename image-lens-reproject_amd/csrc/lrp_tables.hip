@@ -78,7 +78,9 @@ __device__ __forceinline__ void table_value(const TableArgs &A, bool is_col, int
 
 // flags[0]: bit 0 = some table value is -0.0f, an infinity or a NaN; bit 1 = the columns are
 // not mirror images of each other (vx(W-1-j) == -vx(j), vz(W-1-j) == vz(j), bit for bit);
-// bit 2 = the rows are not (vy(H-1-j) == -vy(j)).  Mirror bits are only meaningful for ns == 1.
+// bit 2 = the rows are not (vy(H-1-j) == -vy(j)).  Mirror bits are only meaningful for ns == 1.  A vx / vy of a
+// magnitude below 2^-60 (other than the exact zero of a centre column / row) also clears the axis' symmetry: the
+// kernels that share work between mirror images multiply these by matrix entries and must not meet an underflow.
 __global__ __launch_bounds__(256) void build_tables_kernel(const TableArgs A) {
   const int n_col = A.out_w * A.ns, n_row = A.out_h * A.ns;
   const int i = (int)(blockIdx.x * 256 + threadIdx.x);
@@ -97,6 +99,10 @@ __global__ __launch_bounds__(256) void build_tables_kernel(const TableArgs A) {
   // the centre column / row of an odd-sized image is its own mirror image (its +0 has no -0 partner)
   const bool self = 2 * j == (is_col ? n_col : n_row) - 1;
   if (!self && __float_as_uint(m0) != (__float_as_uint(v0) ^ 0x80000000u)) flags |= is_col ? 2 : 4;
+  if (!self && __builtin_fabsf(v0) < 0x1p-60f) flags |= is_col ? 2 : 4;
+  // ... and the centre column / row, its own mirror image, must be the zero it is for a symmetric lens (a one-pixel
+  // wide or high target of an asymmetric partial panorama has nothing but a centre)
+  if (self && v0 != 0.0f) flags |= is_col ? 2 : 4;
   if (is_col) {
     A.tab[j] = v0;
     if (A.out_lens != kRect) {
@@ -274,9 +280,10 @@ void TableLease::release() {
 }
 
 hipError_t get_output_tables(int device, int out_lens, const LensP &lens, int out_w, int out_h, int ns, hipStream_t stream,
-                             TableLease &lease, const float **col_tab, const float **row_tab, bool *plain, bool *mirror) {
+                             TableLease &lease, const float **col_tab, const float **row_tab, bool *plain, int *symmetry) {
   *col_tab = *row_tab = nullptr;
-  *plain = *mirror = false;
+  *plain = false;
+  *symmetry = 0;
   TableArgs want;
   std::memset(&want, 0, sizeof(want));
   want.lens = lens;
@@ -292,7 +299,7 @@ hipError_t get_output_tables(int device, int out_lens, const LensP &lens, int ou
     *col_tab = e.key.tab;
     *row_tab = e.key.tab + 2 * n_col;
     *plain = !(e.flags & 1);
-    *mirror = ns == 1 && !(e.flags & 6);
+    *symmetry = ns == 1 ? ((e.flags & 2) ? 0 : 1) | ((e.flags & 4) ? 0 : 2) : 0;
   };
   for (const auto &e : g_entries)
     if (e->device == device && same_key(e->key, want)) {

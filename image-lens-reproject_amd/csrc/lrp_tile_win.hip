@@ -1,19 +1,27 @@
-// lrp_tile_win.hip — bicubic window-kernel instantiations (lrp_kernel_v2.h): RGBA, plain blocks.
+// lrp_tile_win.hip — bicubic window-kernel instantiations (lrp_kernel_v2.h): RGBA, plain blocks; the dispatcher.
 #include "lrp_kernel_v2.h"
 
 namespace lrp {
-hipError_t launch_win_bicubic_quad(const KParams &P, int out_idx, int in_mode, hipStream_t stream);     // lrp_tile_winq.hip
-hipError_t launch_win_bicubic_rgb(const KParams &P, int out_idx, int in_mode, hipStream_t stream);      // lrp_tile_win3.hip
-hipError_t launch_win_bicubic_rgb_quad(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winq3.hip
-hipError_t launch_win_bicubic_rgbaz(const KParams &P, int out_idx, int in_mode, hipStream_t stream);      // lrp_tile_win5.hip
-hipError_t launch_win_bicubic_rgbaz_quad(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winq5.hip
-// P.channels must be 3, 4 or 5, P.num_samples 1.
+// one translation unit per (channel count, mirror mode): they compile in parallel
+hipError_t launch_win_bicubic_c4_m1(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winq.hip
+hipError_t launch_win_bicubic_c4_m2(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winy.hip
+hipError_t launch_win_bicubic_c4_m3(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winx.hip
+hipError_t launch_win_bicubic_c3_m0(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_win3.hip
+hipError_t launch_win_bicubic_c3_m1(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winq3.hip
+hipError_t launch_win_bicubic_c3_m2(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winy3.hip
+hipError_t launch_win_bicubic_c3_m3(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winx3.hip
+hipError_t launch_win_bicubic_c5_m0(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_win5.hip
+hipError_t launch_win_bicubic_c5_m1(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winq5.hip
+hipError_t launch_win_bicubic_c5_m2(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winy5.hip
+hipError_t launch_win_bicubic_c5_m3(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winx5.hip
+// P.channels must be 3, 4 or 5, P.num_samples 1; P.win_mode = the mirror mode (lrp_kernel_v2.h QMode).
 hipError_t launch_win_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream) {
-  if (P.channels == 5)
-    return P.quad == 1 ? launch_win_bicubic_rgbaz_quad(P, out_idx, in_mode, stream) : launch_win_bicubic_rgbaz(P, out_idx, in_mode, stream);
-  if (P.channels == 3)
-    return P.quad == 1 ? launch_win_bicubic_rgb_quad(P, out_idx, in_mode, stream) : launch_win_bicubic_rgb(P, out_idx, in_mode, stream);
-  if (P.quad == 1) return launch_win_bicubic_quad(P, out_idx, in_mode, stream);
-  return launch_win_bicubic_impl<false, 4>(P, out_idx, in_mode, stream);
+  using Fn = hipError_t (*)(const KParams &, int, int, hipStream_t);
+  static const Fn table[3][4] = {
+      {launch_win_bicubic_c3_m0, launch_win_bicubic_c3_m1, launch_win_bicubic_c3_m2, launch_win_bicubic_c3_m3},
+      {[](const KParams &Q, int o, int i, hipStream_t s) { return launch_win_bicubic_impl<0, 4>(Q, o, i, s); }, launch_win_bicubic_c4_m1,
+       launch_win_bicubic_c4_m2, launch_win_bicubic_c4_m3},
+      {launch_win_bicubic_c5_m0, launch_win_bicubic_c5_m1, launch_win_bicubic_c5_m2, launch_win_bicubic_c5_m3}};
+  return table[P.channels - 3][P.win_mode & 3](P, out_idx, in_mode, stream);
 }
 } // namespace lrp

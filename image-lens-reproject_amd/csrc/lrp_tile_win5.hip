@@ -2,7 +2,7 @@
 #include "lrp_kernel_v2.h"
 
 namespace lrp {
-hipError_t launch_win_bicubic_rgbaz(const KParams &P, int out_idx, int in_mode, hipStream_t stream) {
-  return launch_win_bicubic_impl<false, 5>(P, out_idx, in_mode, stream);
+hipError_t launch_win_bicubic_c5_m0(const KParams &P, int out_idx, int in_mode, hipStream_t stream) {
+  return launch_win_bicubic_impl<0, 5>(P, out_idx, in_mode, stream);
 }
 } // namespace lrp

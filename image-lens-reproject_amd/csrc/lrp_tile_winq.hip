@@ -1,9 +1,9 @@
-// lrp_tile_winq.hip — bicubic window-kernel instantiations (lrp_kernel_v2.h): RGBA, mirrored blocks.
+// lrp_tile_winq.hip — bicubic window-kernel instantiations (lrp_kernel_v2.h): RGBA, mirrored in both axes.
 #include "lrp_kernel_v2.h"
 
 namespace lrp {
-hipError_t launch_win_bicubic_quad(const KParams &P, int out_idx, int in_mode, hipStream_t stream) {
-  return launch_win_bicubic_impl<true, 4>(P, out_idx, in_mode, stream);
+hipError_t launch_win_bicubic_c4_m1(const KParams &P, int out_idx, int in_mode, hipStream_t stream) {
+  return launch_win_bicubic_impl<1, 4>(P, out_idx, in_mode, stream);
 }
 } // namespace lrp
 

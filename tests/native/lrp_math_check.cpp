@@ -178,7 +178,10 @@ uint64_t lrp_check_atan2(uint64_t seed, uint64_t count, int mode, int threads, u
         float y, x;
         memcpy(&y, &uy, 4);
         memcpy(&x, &ux, 4);
-        if (!same(lrp::atan2f_(y, x), atan2f(y, x))) {
+        // ... and odd in y, bit for bit, in both implementations: the columns-only mirror mode of the window kernel
+        // evaluates the longitude -atan2f(-x, -z) once for a pixel and its left / right mirror image (lrp_kernel_v2.h)
+        const float own_yx = lrp::atan2f_(y, x), ref_yx = atan2f(y, x);
+        if (!same(own_yx, ref_yx) || !same(lrp::atan2f_(-y, x), -own_yx) || !same(atan2f(-y, x), -ref_yx)) {
           ++local;
           if (have.exchange(1) == 0) {
             if (bad_y) *bad_y = uy;

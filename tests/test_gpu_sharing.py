@@ -146,3 +146,94 @@ def test_alias_pairs_plain_and_mirrored_strips(lrp, oracle, torch_cuda, span):
                 want = oracle.reproject(lin, src, lout, out_w, out_h, 1, 2, None, threads=8)
             render_all(lrp, torch_cuda, lin, src, lout, out_w, out_h, 2, None, f"rect->eqr{span} {out_w}x{out_h} C={c}", want,
                        channels=c, families=(2,))
+
+
+# ---- one-axis mirror modes of the window kernel (lrp_kernel_v2.h QMode 2 / 3) -----------------------------------------
+PAN_DEG = [(90.0, 0.0, 0.0), (180.0, 0.0, 0.0), (270.0, 0.0, 0.0), (37.5, 0.0, 0.0), (-120.0, 0.0, 0.0), (1e-4, 0.0, 0.0)]
+PITCH_DEG = [(0.0, 90.0, 0.0), (0.0, -90.0, 0.0), (0.0, 33.0, 0.0), (0.0, -71.5, 0.0), (0.0, 180.0, 0.0), (0.0, 1e-4, 0.0)]
+
+
+@pytest.mark.parametrize("out_w,out_h", [(256, 192), (255, 193), (64, 48), (33, 17), (16, 16), (5, 3), (130, 1), (1, 77)])
+@pytest.mark.parametrize("deg", PAN_DEG + PITCH_DEG)
+def test_one_axis_mirror_modes_all_cells_and_sizes(lrp, oracle, torch_cuda, out_w, out_h, deg):
+    """Pan-only rotations render a block and its top / bottom mirror image from one evaluation of stage 1
+    (rectilinear / equirectangular lenses on both sides), pitch-only rotations a block and its left / right mirror
+    image (rectilinear target, every source).  Odd sizes: the centre row / column is its own mirror image.  Each case
+    against the oracle with the mode on (family 2), with every sharing path off (3) and per pixel (0)."""
+    in_w, in_h = 150, 110
+    rot = cases.rotation(lrp, deg)
+    pan = deg[1] == 0.0
+    cells = ([("eqr_full", "rect"), ("eqr_part", "rect"), ("rect_tele", "rect"), ("rect", "eqr_full"), ("eqr_full", "eqr_part")] if pan
+             else [("eqr_full", "rect"), ("eqr_part", "rect"), ("rect_tele", "rect"), ("eqd180", "rect")])
+    for in_name, out_name in cells:
+        src = cases.hash_noise(in_h, in_w, 4, seed=out_w * 7 + out_h)
+        lin, lout = cases.lenses(lrp, in_w, in_h)[in_name], cases.lenses(lrp, out_w, out_h)[out_name]
+        with np.errstate(all="ignore"):
+            want = oracle.reproject(lin, src, lout, out_w, out_h, 1, 2, rot, threads=8)
+        render_all(lrp, torch_cuda, lin, src, lout, out_w, out_h, 2, rot, f"{in_name}->{out_name} {out_w}x{out_h} rot={deg}", want)
+
+
+@pytest.mark.parametrize("channels", [3, 5])
+@pytest.mark.parametrize("deg", [(90.0, 0.0, 0.0), (-37.5, 0.0, 0.0), (0.0, 90.0, 0.0), (0.0, -40.0, 0.0)])
+def test_one_axis_mirror_modes_rgb_and_rgbaz(lrp, oracle, torch_cuda, channels, deg):
+    in_w, in_h, out_w, out_h = 384, 192, 201, 137
+    rot = cases.rotation(lrp, deg)
+    pan = deg[1] == 0.0
+    for in_name, out_name in ([("eqr_full", "rect"), ("rect", "eqr_full"), ("rect_tele", "rect")] if pan
+                              else [("eqr_full", "rect"), ("eqd180", "rect"), ("rect_tele", "rect")]):
+        src = cases.hash_noise(in_h, in_w, channels, seed=channels)
+        lin, lout = cases.lenses(lrp, in_w, in_h)[in_name], cases.lenses(lrp, out_w, out_h)[out_name]
+        want = oracle.reproject(lin, src, lout, out_w, out_h, 1, 2, rot, threads=8)
+        render_all(lrp, torch_cuda, lin, src, lout, out_w, out_h, 2, rot, f"{in_name}->{out_name} C={channels} rot={deg}", want,
+                   channels=channels, families=(2, 0))
+
+
+@pytest.mark.parametrize("deg", [(20.0, 1e-3, 0.0), (20.0, 0.0, 1e-3), (1e-3, 40.0, 0.0), (0.0, 40.0, 1e-3), (0.0, 0.0, 45.0)])
+def test_one_axis_mirror_modes_are_not_used_beyond_their_rotations(lrp, oracle, torch_cuda, deg):
+    """A trace of pitch or roll next to a pan (or of pan / roll next to a pitch) breaks the symmetry: plain blocks."""
+    in_w, in_h, out_w, out_h = 300, 160, 201, 137
+    rot = cases.rotation(lrp, deg)
+    for in_name, out_name in (("eqr_full", "rect"), ("rect_tele", "rect"), ("eqd180", "rect"), ("rect", "eqr_full")):
+        src = cases.hash_noise(in_h, in_w, 4, seed=3)
+        lin, lout = cases.lenses(lrp, in_w, in_h)[in_name], cases.lenses(lrp, out_w, out_h)[out_name]
+        want = oracle.reproject(lin, src, lout, out_w, out_h, 1, 2, rot, threads=8)
+        render_all(lrp, torch_cuda, lin, src, lout, out_w, out_h, 2, rot, f"{in_name}->{out_name} rot={deg}", want, families=(2, 0))
+
+
+def test_one_axis_mirror_modes_negative_zero_in_the_tables(lrp, oracle, torch_cuda):
+    """A negative focal length puts -0.0f into the centre column / row of an odd-sized target: the tables are then not
+    'plain', no column table is built and the rows-only mode must not be chosen; the columns-only mode sees a centre
+    column that is its own mirror image."""
+    in_w, in_h, out_w, out_h = 96, 64, 63, 41
+    L = lrp.LensInfo
+    lout = L.rectilinear(-18.0, 36.0, out_w, out_h)
+    src = cases.hash_noise(in_h, in_w, 4, seed=5)
+    for lin in (L.equirectangular(), L.equidistant(math.pi), L.rectilinear(24.0, 36.0, in_w, in_h)):
+        for deg in ((90.0, 0.0, 0.0), (0.0, 90.0, 0.0), (0.0, -30.0, 0.0)):
+            rot = cases.rotation(lrp, deg)
+            with np.errstate(all="ignore"):
+                want = oracle.reproject(lin, src, lout, out_w, out_h, 1, 2, rot)
+            render_all(lrp, torch_cuda, lin, src, lout, out_w, out_h, 2, rot, f"negative focal, lens {lin.type}, rot={deg}", want)
+
+
+def test_hand_made_pan_and_pitch_matrices(lrp, oracle, torch_cuda):
+    """Matrices a caller may hand over directly (signed zeros, a pan by exactly 90 degrees with an exact 0 / 1 pattern,
+    mirror-like matrices with a negative diagonal entry) — whatever mode the host picks, the bits are the oracle's."""
+    in_w, in_h, out_w, out_h = 300, 160, 137, 95
+    mats = [
+        [0.0, 0.0, 1.0, 0.0, 1.0, 0.0, -1.0, 0.0, 0.0],        # exact quarter turn about y
+        [0.0, -0.0, 1.0, -0.0, 1.0, 0.0, -1.0, 0.0, -0.0],     # the same with signed zeros
+        [0.6, 0.0, 0.8, 0.0, -1.0, 0.0, -0.8, 0.0, 0.6],       # pan with a flipped vertical axis
+        [1.0, 0.0, 0.0, 0.0, 0.6, -0.8, 0.0, 0.8, 0.6],        # pitch
+        [-1.0, -0.0, 0.0, 0.0, 0.6, -0.8, -0.0, 0.8, 0.6],     # pitch with a flipped horizontal axis
+        [1.0, 0.0, 0.0, 0.0, 0.0, -1.0, 0.0, 1.0, 0.0],        # exact quarter turn about x (R4 == R8 == 0)
+        [1.0, 0.0, 0.0, 0.0, 1e-30, 0.0, 0.0, 0.0, 1.0],       # degenerate: tiny R4
+    ]
+    for m in mats:
+        rot = np.array(m, dtype=np.float32)
+        for in_name, out_name in (("eqr_full", "rect"), ("rect_tele", "rect"), ("eqd180", "rect"), ("rect", "eqr_part")):
+            src = cases.hash_noise(in_h, in_w, 4, seed=9)
+            lin, lout = cases.lenses(lrp, in_w, in_h)[in_name], cases.lenses(lrp, out_w, out_h)[out_name]
+            with np.errstate(all="ignore"):
+                want = oracle.reproject(lin, src, lout, out_w, out_h, 1, 2, rot, threads=8)
+            render_all(lrp, torch_cuda, lin, src, lout, out_w, out_h, 2, rot, f"{in_name}->{out_name} matrix {m}", want, families=(2, 0))

@@ -50,6 +50,7 @@ def test_odd_functions_are_odd_bit_for_bit(chk, func, name):
 
 @pytest.mark.parametrize("mode,count", [(0, 1 << 27), (1, 1 << 28), (2, 1 << 26)])
 def test_atan2_random_pairs(chk, mode, count):
+    """atan2f_ == libm's atan2f, and both odd in their first argument (atan2f(-y, x) == -atan2f(y, x) bit for bit)."""
     by, bx = ctypes.c_uint32(0), ctypes.c_uint32(0)
     bad = chk.lrp_check_atan2(0xC0FFEE + mode, count, mode, THREADS, ctypes.byref(by), ctypes.byref(bx))
     assert bad == 0, f"atan2f mode {mode}: {bad} mismatches, first y=0x{by.value:08x} x=0x{bx.value:08x}"
@@ -65,6 +66,13 @@ def test_atan2_special_grid(chk):
     chk.lrp_eval_atan2(y.ctypes.data, x.ctypes.data, own.ctypes.data, ref.ctypes.data, y.size)
     same = (own.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(own) & np.isnan(ref))
     assert same.all(), f"atan2f special grid: y={y[~same][:4]} x={x[~same][:4]}"
+    # odd in y, signed zeros and infinities included (the columns-only mirror mode relies on it)
+    own_n, ref_n = np.empty_like(y), np.empty_like(y)
+    ny = (-y).copy()
+    chk.lrp_eval_atan2(ny.ctypes.data, x.ctypes.data, own_n.ctypes.data, ref_n.ctypes.data, y.size)
+    for a, b, what in ((own_n, -own, "atan2f_"), (ref_n, -ref, "libm atan2f")):
+        odd = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+        assert odd.all(), f"{what} is not odd in y at y={y[~odd][:4]} x={x[~odd][:4]}"
 
 
 def test_u8_quantiser_equals_its_threshold_table(chk, lrp):
