@@ -61,6 +61,12 @@
 
 namespace lrp {
 
+#ifndef LRP_OPT_POST
+#define LRP_OPT_POST 1
+#endif
+#ifndef LRP_OPT_TIER
+#define LRP_OPT_TIER 1
+#endif
 #ifndef LRP_WIN_ALIAS_PAIRS
 #define LRP_WIN_ALIAS_PAIRS 1 // rectilinear -> panorama: the view and its copy behind the camera rendered side by side
 #endif
@@ -798,20 +804,22 @@ __device__ __forceinline__ void finish_px(const KParams &P, const Px<CH> &a, flo
 #pragma unroll
     for (int i = 0; i < 5; ++i) c[i] *= n;
   }
-  if (P.has_post) {
+  // (the flag is made opaque where it is tested: hoisted out of the pass loops as a lane mask, its negation for the
+  // branch comes back as a v_cndmask + v_cmp pair in front of every store; as a scalar integer it is an s_cmp)
+  int has_post = P.has_post;
+#if LRP_OPT_POST
+  asm volatile("" : "+s"(has_post));
+#endif
+  if (has_post != 0) {
     c[0] = tonemap(c[0], P.exposure, P.reinhard);
     c[1] = tonemap(c[1], P.exposure, P.reinhard);
     c[2] = tonemap(c[2], P.exposure, P.reinhard);
   }
 }
-template <int CH, bool UnitNorm = false>
-__device__ __forceinline__ void store_px(const KParams &P, uint32_t pixel_index, Px<CH> a) {
-  float c[5];
-  finish_px<CH, UnitNorm>(P, a, c);
-  // Non-temporal stores: the output is written once and never read by this kernel;
-  // keeping it out of the L2 leaves the cache to the source texels (measured on a 4K
-  // frame: nearest 88 -> 63 us, bilinear 117 -> 95 us, bicubic 223 -> 214 us).
-  float *d = P.dst + (size_t)pixel_index * CH;
+// One finished pixel to `d`.  Non-temporal stores: the output is written once and never read by this kernel;
+// keeping it out of the L2 leaves the cache to the source texels (measured on a 4K
+// frame: nearest 88 -> 63 us, bilinear 117 -> 95 us, bicubic 223 -> 214 us).
+template <int CH> __device__ __forceinline__ void store_texel_nt(float *d, const float c[5]) {
   typedef float v4f __attribute__((ext_vector_type(4)));
   typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
   typedef float v3f_a4 __attribute__((ext_vector_type(3), aligned(4)));
@@ -828,7 +836,12 @@ __device__ __forceinline__ void store_px(const KParams &P, uint32_t pixel_index,
     __builtin_nontemporal_store(c[4], d + 4);
   }
 }
-
+template <int CH, bool UnitNorm = false>
+__device__ __forceinline__ void store_px(const KParams &P, uint32_t pixel_index, Px<CH> a) {
+  float c[5];
+  finish_px<CH, UnitNorm>(P, a, c);
+  store_texel_nt<CH>(P.dst + (size_t)pixel_index * CH, c);
+}
 // RGBAZ output, a whole run of pixels per wavefront.  Stored per lane, a 20-byte pixel is a dwordx4 and a dword
 // at a 20-byte lane stride: two instructions that each touch every 64-byte segment of the run and fill it only
 // partly — measured at half the rate of whole segments (tools/microbench/store_stride.hip: 114 us against 62 us
@@ -1812,7 +1825,16 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode >
 #endif
     if (kWinBuffers == 2 && g + 1 < G) issue(g + 1, nxt);
     const float4 *const win = win0 + (g & (kWinBuffers - 1)) * kWinCap;
-    if (cur.corner() != 0) {
+    // The tier of this block in a scalar register for the branches below: carried through the block loop inside `cur` it
+    // ends up in a VGPR (the kernel is at the SGPR limit), and every test of it then costs a v_and + v_cmp and the
+    // branch condition is re-materialised through v_cndmask / v_cmp at each use — seven VALU instructions per pass.
+#if LRP_OPT_TIER
+    const int tier = __builtin_amdgcn_readfirstlane(cur.tier);
+#else
+    const int tier = cur.tier;
+#endif
+    const bool t_coef = kWinCoef && (tier & 2) != 0, t_staged = (tier & 1) != 0, t_whole = (tier & 4) != 0;
+    if ((tier >> 3) != 0) {
       // every pixel of this block is one value: no taps, no per-pixel arithmetic — four stores.  The next block's
       // window is requested in front of the last store, as in the last pass of an ordinary block.
       const Rgba cs = corner_value(cur);
@@ -1832,7 +1854,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode >
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #if !defined(LRP_SKIP_PLANES) // timing experiment (wrong results): the coefficient phase removed
-      if (kWinCoef && cur.coef() && (h == 0 || !cur.whole())) precompute(cur, h);
+      if (t_coef && (h == 0 || !t_whole)) precompute(cur, h);
 #endif
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -1846,7 +1868,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode >
         // images — out of the block loop and spill it: the selected values are opaque here)
         if constexpr (QMode >= 2) asm volatile("" : "+v"(psx), "+v"(psy));
         Rgba s;
-        if (kWinCoef && cur.coef()) {
+        if (t_coef) {
           const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
           const float fx = psx - tx_, fy = psy - ty_;
           const float hfx = 0.5f * fx, hfy = 0.5f * fy;
@@ -1875,7 +1897,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode >
           const Rgba k0 = vert(0, b0), k1 = vert(1, b1), k2 = vert(2, b2), k3 = vert(3, b3);
           s = cubic4(k0, k1, k2, k3, fx, hfx);
           if constexpr (CH == 5) s.e = depth_from_window(win, tap - cur.spitch(), fx, fy, hfx, hfy, last_pass);
-        } else if (cur.staged()) {
+        } else if (t_staged) {
           const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
           const float fx = psx - tx_, fy = psy - ty_;
           const int slot0 = cur.org() + __mul24((int)ty_ - 1 - cur.y_lo, cur.spitch()) + ((int)tx_ - 1 - cur.x_lo);
