@@ -94,3 +94,64 @@ def test_checksum_host_matches_its_definition(lrp):
     for i, b in enumerate(int(v) for v in bits):
         want += (mix32(b ^ 0xA5A5A5A5, (2 * i + 0x7F4A7C15) & 0xFFFFFFFF) << 32) | mix32(b, i)
     assert lrp.checksum_host(a) == want & 0xFFFFFFFFFFFFFFFF
+
+
+@pytest.mark.gpu
+def test_two_ranks_over_rccl_on_two_gpus(torch_cuda, tmp_path):
+    """The launch the driver uses for N > 1 — `--dist-backend nccl` (RCCL), one rank per GPU — on the first two GPUs of
+    the box.  Needs two GPUs (a one-GPU box cannot host two RCCL ranks): skipped there, the gloo tests above cover the
+    sharding and the reporting, and RCCL only carries the barrier and the one-float MAX of the elapsed time."""
+    if torch_cuda.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: two RCCL ranks need two")
+    one, sums1 = run_bench(1, tmp_path)
+    out = tmp_path / "sums_nccl.json"
+    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", str(BATCH), "--size", str(SIZE), "--no-cpu-baseline",
+            "--secondary", "", "--settle-seconds", "0", "--dist-backend", "nccl", "--checksums-file", str(out)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, BENCH, *args], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    two = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and json.load(open(out))["checksums"] == sums1["checksums"]
+
+
+@pytest.mark.gpu
+def test_device_visibility_is_honoured(torch_cuda, tmp_path):
+    """HIP_VISIBLE_DEVICES subsets: the library sees exactly the listed GPUs — the last one alone renders the
+    same image as device 0 of the full list, and with none visible every compute entry point fails loudly
+    (LRP_ERR_NO_DEVICE): there is no CPU fallback to fall into."""
+    code = r'''
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+lrp = importlib.import_module("image-lens-reproject_amd")
+n = lrp.device_count()
+print("count", n)
+src = (np.arange(64 * 32 * 4, dtype=np.float32).reshape(32, 64, 4) %% 17) / 16
+out = np.full((24, 40, 4), -1.0, dtype=np.float32)
+try:
+    lrp.reproject(lrp.Image(lrp.LensInfo.equirectangular(), 64, 32, 4, src), lrp.Image(lrp.LensInfo.rectilinear(18.0, 36.0, 40, 24), 40, 24, 4, out), 1, 2, None)
+    print("sum", float(out.sum()))
+except lrp.LrpError as e:
+    print("error", int(e.status))
+''' % ROOT
+    def run(visible):
+        env = dict(os.environ)
+        if visible is None:
+            env.pop("HIP_VISIBLE_DEVICES", None)
+        else:
+            env["HIP_VISIBLE_DEVICES"] = visible
+        env.pop("ROCR_VISIBLE_DEVICES", None)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return dict(ln.split(" ", 1) for ln in r.stdout.splitlines() if " " in ln)
+
+    full = run(None)
+    n = int(full["count"])
+    assert n >= 1 and "sum" in full
+    last = run(str(n - 1))
+    assert int(last["count"]) == 1 and last["sum"] == full["sum"]
+    none = run("")
+    if int(none["count"]) == 0:  # (an empty list hides every GPU on this runtime; if it does not, there is nothing to check)
+        lrp = __import__("importlib").import_module("image-lens-reproject_amd")
+        assert int(none["error"]) == int(lrp.Status.NO_DEVICE)

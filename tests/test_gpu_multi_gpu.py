@@ -61,3 +61,39 @@ def test_cubemap_job_over_a_device_list(lrp, oracle, torch_cuda, devices):
                             devices=devices)
     for d, o, r in zip(degs, outs, rots):
         cases.assert_same_bits(o, oracle.reproject(lin, src, lout, face, face, 1, 2, r), f"face {d} on devices {devices}")
+
+
+def test_multi_gpu_jobs_on_disjoint_and_shared_device_lists_run_concurrently(lrp, oracle, torch_cuda):
+    """lrp_reproject_multi locks its participants ((device, occurrence) pairs, taken in one global order), not the
+    library: four host threads run cubemap jobs at once — on a one-GPU box they all name GPU 0 (they queue up on its
+    participants and on the second occurrence), on a larger box the lists differ — and every job gets the oracle's bytes."""
+    import threading
+
+    n_dev = torch_cuda.cuda.device_count()
+    in_w, in_h, face = 512, 256, 96
+    lin = lrp.LensInfo.equirectangular()
+    lout = lrp.LensInfo.rectilinear(18.0, 36.0, face, face)
+    degs = [(0, 0, 0), (90, 0, 0), (0, 90, 0)]
+    rots = np.stack([cases.rotation(lrp, d) for d in degs])
+    lists = [(0,), (n_dev - 1, 0), (0, 0), tuple(range(n_dev))]
+    srcs = [cases.hash_noise(in_h, in_w, 4, seed=100 + t) for t in range(len(lists))]
+    wants = [[oracle.reproject(lin, s, lout, face, face, 1, 2, r) for r in rots] for s in srcs]
+    errors = []
+
+    def job(t):
+        try:
+            for _ in range(3):
+                outs = [np.full((face, face, 4), -1.0, dtype=np.float32) for _ in degs]
+                lrp.reproject_multi_gpu(lrp.Image(lin, in_w, in_h, 4, srcs[t]), [lrp.Image(lout, face, face, 4, o) for o in outs], 1, 2, rots,
+                                        devices=lists[t])
+                for o, w in zip(outs, wants[t]):
+                    cases.assert_same_bits(o, w, f"job {t} on devices {lists[t]}")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=job, args=(t,)) for t in range(len(lists))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
