@@ -275,6 +275,11 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     // Mirror mode of the window kernel (lrp_kernel_v2.h QMode): both axes without a rotation; rows only for a pan,
     // columns only for a pitch into a rectilinear target.  Signed zeros count as zeros in the matrix tests.
     P.win_mode = P.quad == 1 ? 1 : 0;
+    // equidistant target that is not fully mirrored (a rotation, or an equirectangular source): the four mirror pixels
+    // still share the ray through the output lens
+    if (window && P.win_mode == 0 && !band && quad_enabled() && mirror_modes_enabled() && kernel_choice() != 3 &&
+        out->lens.type == LRP_FISHEYE_EQUIDISTANT)
+      P.win_mode = 4;
     if (window && P.win_mode == 0 && !band && quad_enabled() && mirror_modes_enabled() && kernel_choice() != 3 && P.has_rot) {
       const float *R = P.rot;
       auto tiny = [](float v) { return !(std::fabs(v) >= 0x1p-20f); }; // (also true for a NaN)

@@ -1246,6 +1246,11 @@ template <bool Fat> struct WinBlockT {
 //      symmetric left / right: rows 1 and 2 of the matrix are (+-0, c, -s) / (+-0, s, c), so ny, nz do not see vx (the
 //      zero products vanish in sums that end in the non-zero R5 vz, R8 vz) and nx = vx.  Images g = 0, 1.  The top and
 //      bottom faces of a cubemap, any --rotation 0,pitch,0.
+//   4  shared rays: an equidistant TARGET under any rotation.  Its ray costs a square root, a double-precision sincosf
+//      and three divides per pixel, no table can hold it (the lens is not separable), and it is odd in cx and in cy by
+//      construction (src/reproject.cpp:171-186: r_px is even, vx = s cx, vy = s cy, vz = cos theta) — so the ray is
+//      evaluated once per quadrant pixel and its sign-flipped copies go through the rotation and the source lens per
+//      mirror image, like the pixels of plain blocks.  Images g = 0..3.
 // The host (lrp_capi.cpp win_mirror_mode) checks the matrix entries and the symmetry flags of the output-lens tables.
 template <int OutLens, int InMode, int QMode, int CH>
 #ifndef LRP_WIN_MINWAVES5
@@ -1254,9 +1259,14 @@ template <int OutLens, int InMode, int QMode, int CH>
 #ifndef LRP_WIN_MINWAVES_AXIS
 #define LRP_WIN_MINWAVES_AXIS 4 // one-axis mirror modes (QMode 2, 3)
 #endif
-__global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode >= 2 ? LRP_WIN_MINWAVES_AXIS : LRP_WIN_MINWAVES)) void reproject_bicubic_win_kernel(const KParams Pk) {
+#ifndef LRP_WIN_MINWAVES_RAYS
+#define LRP_WIN_MINWAVES_RAYS 3 // shared-ray mode (QMode 4): the rays of four pixels (12 VGPRs) next to the coordinates of two blocks do not fit 128; measured 251 us at four waves per SIMD (66 spilled registers), 227 at three, 236 plain
+#endif
+__global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode == 4 ? LRP_WIN_MINWAVES_RAYS : (QMode >= 2 ? LRP_WIN_MINWAVES_AXIS : LRP_WIN_MINWAVES))) void reproject_bicubic_win_kernel(const KParams Pk) {
   constexpr bool Quad = QMode != 0;
-  constexpr bool MirX = QMode == 1 || QMode == 3, MirY = QMode == 1 || QMode == 2;
+  constexpr bool MirX = QMode == 1 || QMode == 3 || QMode == 4, MirY = QMode == 1 || QMode == 2 || QMode == 4;
+  constexpr bool kSharedRays = QMode == 4; // only the ray through the output lens is shared: per-image coordinates are stored like a plain block's
+  static_assert(QMode != 4 || OutLens == kEquidistant, "shared rays: the equidistant target");
   constexpr int kAllMirrors = (MirX ? 1 : 0) | (MirY ? 2 : 0); // the image mirrored in every mirrored axis
   using WinBlock = WinBlockT<Quad>;
   static_assert(CH == 3 || CH == 4 || CH == 5, "window kernel: RGB, RGBA or RGBAZ");
@@ -1338,7 +1348,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode >
   }
   const ColTerms col = column_terms<OutLens>(P, xe, 0);
   ColTerms col_m = col; // the mirrored column
-  if constexpr (MirX) col_m = column_terms<OutLens>(P, P.out_w - 1 - xe, 0);
+  if constexpr (MirX && !kSharedRays) col_m = column_terms<OutLens>(P, P.out_w - 1 - xe, 0);
   // Stage-1 results of the four quadrant pixels of this lane, kept for the whole strip:
   //   rectilinear / equidistant source: (qa, qb) = plane coordinates (u, v); a mirror image negates them;
   //   equirectangular source (through the xsep table): qa, qb = source texel y for +phi and for -phi
@@ -1349,10 +1359,20 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode >
   float qa[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   constexpr bool kInEqr = InMode == kInEquirect || InMode == kInEquirectLoop;
   constexpr bool kEqrByTheta = QMode == 3 && kInEqr;
-  float qc[kEqrByTheta ? 4 : 1] = {};
+  //   shared rays: (qa, qb, qc) = the ray (vx, vy, vz) of the quadrant pixel.
+  float qc[(kEqrByTheta || kSharedRays) ? 4 : 1] = {};
   auto quad_xy = [&](int g, int k, float &sx, float &sy) { // source texel coordinates of pixel k of mirror image g
     const bool mx = (g & 1) != 0, my = (g >> 1) != 0;
-    if constexpr (kEqrByTheta) {
+    if constexpr (kSharedRays) {
+      // the mirrored pixel's ray: vx / vy negated — except in the centre column / row of an odd-sized image, which is
+      // its own mirror image: its component is the +0 of s * 0 and stays +0 (a -0 is another input to atan2f)
+      const int yk = y_lane + kPassRows * k;
+      const uint32_t sgn_x = (mx && 2 * xe != P.out_w - 1) ? 0x80000000u : 0u;
+      const uint32_t sgn_y = (my && 2 * yk != P.out_h - 1) ? 0x80000000u : 0u;
+      float u, v;
+      ray_to_plane<InMode>(P, u2f(f2u(qa[k]) ^ sgn_x), u2f(f2u(qb[k]) ^ sgn_y), qc[k], u, v);
+      plane_to_texel<OutLens, InMode>(P, col, u, v, sx, sy);
+    } else if constexpr (kEqrByTheta) {
       sx = mx ? qc[k] : qa[k];
       sy = qb[k];
     } else if constexpr (kInEqr) {
@@ -1501,7 +1521,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode >
   // long way, precise test included.
   int plan = 0;
   uint32_t plan_exact = 0;
-  constexpr bool kStripPlan = Quad && LRP_WIN_STRIP_PLAN != 0 && LRP_WIN_SIGNED_PITCH == 0 && LRP_ABLATE == 0;
+  constexpr bool kStripPlan = Quad && !kSharedRays && LRP_WIN_STRIP_PLAN != 0 && LRP_WIN_SIGNED_PITCH == 0 && LRP_ABLATE == 0;
   auto plan_strip = [&]() {
     Extremes e0, e1; // unmirrored (image 0) and mirrored in every mirrored axis (an axis that is not mirrored has one range: e1's equals e0's)
 #pragma unroll
@@ -1545,7 +1565,11 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode >
         const int yk = y_lane + kPassRows * k;
         const int ye = yk < qh ? yk : qh - 1;
         float u, v;
-        if constexpr (kEqrByTheta) {
+        if constexpr (kSharedRays) {
+          pixel_ray<OutLens>(P, col, row_v[k], ye, 0, qa[k], qb[k], qc[k]);
+          (void)u;
+          (void)v;
+        } else if constexpr (kEqrByTheta) {
           // vec_to_equirectangular (src/reproject.cpp:259-271) split at the longitude: everything up to theta once, the
           // rest of :268 once per sign of theta; the latitude half is the same for both mirror images
           float vx, vy, vz;
@@ -1603,6 +1627,8 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode >
       else
         quad_xy(gm, k, b.sx[k], b.sy[k]);
       note_pixel(e, k, b.sx[k], b.sy[k]);
+      // (shared rays: one pixel's rotation + source lens after the other — interleaved they do not fit the registers)
+      if constexpr (kSharedRays) __builtin_amdgcn_sched_barrier(0);
     }
     bool all_exact = wave_all((e.exact_x & e.exact_y) != 0);
     if (!all_exact) { // the precise test, for the stripe of blocks next to a power-of-two coordinate
@@ -1816,7 +1842,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode >
     g_loop = g;
     // plain blocks: the next block's coordinates here, long before its window is requested in the
     // last pass; mirrored blocks derive theirs in a few instructions right there (fewer live registers)
-    if (!Quad && g + 1 < G) coords(g + 1, nxt);
+    if ((!Quad || kSharedRays) && g + 1 < G) coords(g + 1, nxt); // (shared rays: the rotation and the source lens run per image, as for a plain block)
 #if !defined(LRP_NO_DMA_WAIT) // timing experiment (wrong results): how much of the frame is exposed DMA / store latency
     if (g == 0 || !dma_early || kWinBuffers != 1 || LRP_ABLATE != 0)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the window was the last thing requested
@@ -1838,7 +1864,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode >
       // every pixel of this block is one value: no taps, no per-pixel arithmetic — four stores.  The next block's
       // window is requested in front of the last store, as in the last pass of an ordinary block.
       const Rgba cs = corner_value(cur);
-      if (Quad && g + 1 < G) coords(g + 1, nxt);
+      if (Quad && !kSharedRays && g + 1 < G) coords(g + 1, nxt);
       emit(g, 0, cs, std::true_type{});
       emit(g, 1, cs, std::true_type{});
       emit(g, 2, cs, std::true_type{});
@@ -1860,9 +1886,9 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode >
       for (int kk = 0; kk < 2; ++kk) {
         const int k = 2 * h + kk;
         const bool last_pass = kWinBuffers == 1 && LRP_ABLATE == 0 && k == 3;
-        if (Quad && k == 3 && g + 1 < G) coords(g + 1, nxt); // only its box is kept
+        if (Quad && !kSharedRays && k == 3 && g + 1 < G) coords(g + 1, nxt); // only its box is kept
         float psx = cur.sx[k], psy = cur.sy[k];
-        if constexpr (Quad) quad_xy(image_of(g), k, psx, psy); // re-derived (2-4 instructions) instead of held in registers
+        if constexpr (Quad && !kSharedRays) quad_xy(image_of(g), k, psx, psy); // re-derived (2-4 instructions) instead of held in registers
         // (where the coordinates of a mirror image are a plain selection of stored values the compiler would otherwise
         // hoist everything derived from them — truncations, weights, window addresses of all four passes and both
         // images — out of the block loop and spill it: the selected values are opaque here)
@@ -2018,6 +2044,8 @@ template <int OutLens, int InMode, int QMode, int CH> constexpr TileKernelFn win
     return nullptr;
   else if constexpr (QMode == 3 && OutLens != kRect)
     return nullptr;
+  else if constexpr (QMode == 4 && OutLens != kEquidistant)
+    return nullptr;
   else
     return reproject_bicubic_win_kernel<OutLens, InMode, QMode, CH>;
 }
@@ -2042,11 +2070,11 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
   if (QMode != 0) {
     // the launch enumerates the top-left quadrant (the top / the left half when one axis is mirrored); a wavefront
     // renders a block and its mirror images
-    const int qw = (QMode == 1 || QMode == 3) ? (P.out_w + 1) / 2 : P.out_w;
-    const int qh = (QMode == 1 || QMode == 2) ? (P.out_h + 1) / 2 : P.out_h;
+    const int qw = (QMode == 1 || QMode == 3 || QMode == 4) ? (P.out_w + 1) / 2 : P.out_w;
+    const int qh = (QMode == 1 || QMode == 2 || QMode == 4) ? (P.out_h + 1) / 2 : P.out_h;
     P.tiles_x = (qw + kBlkW * kWinWaves - 1) / (kBlkW * kWinWaves);
     P.tiles_y = (qh + kBlkH - 1) / kBlkH;
-    P.blocks_per_wave = QMode == 1 ? 4 : 2;
+    P.blocks_per_wave = (QMode == 1 || QMode == 4) ? 4 : 2;
   } else {
     P.tiles_x = (P.out_w + kBlkW * kWinWaves - 1) / (kBlkW * kWinWaves);
     // strips of LRP_WIN_STRIP blocks when that still leaves >= 8 workgroups per CU, else shorter

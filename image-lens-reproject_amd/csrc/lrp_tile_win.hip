@@ -6,6 +6,9 @@ namespace lrp {
 hipError_t launch_win_bicubic_c4_m1(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winq.hip
 hipError_t launch_win_bicubic_c4_m2(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winy.hip
 hipError_t launch_win_bicubic_c4_m3(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winx.hip
+hipError_t launch_win_bicubic_c4_m4(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winr.hip
+hipError_t launch_win_bicubic_c3_m4(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winr3.hip
+hipError_t launch_win_bicubic_c5_m4(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winr5.hip
 hipError_t launch_win_bicubic_c3_m0(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_win3.hip
 hipError_t launch_win_bicubic_c3_m1(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winq3.hip
 hipError_t launch_win_bicubic_c3_m2(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winy3.hip
@@ -17,11 +20,12 @@ hipError_t launch_win_bicubic_c5_m3(const KParams &P, int out_idx, int in_mode, 
 // P.channels must be 3, 4 or 5, P.num_samples 1; P.win_mode = the mirror mode (lrp_kernel_v2.h QMode).
 hipError_t launch_win_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream) {
   using Fn = hipError_t (*)(const KParams &, int, int, hipStream_t);
-  static const Fn table[3][4] = {
-      {launch_win_bicubic_c3_m0, launch_win_bicubic_c3_m1, launch_win_bicubic_c3_m2, launch_win_bicubic_c3_m3},
+  static const Fn table[3][5] = {
+      {launch_win_bicubic_c3_m0, launch_win_bicubic_c3_m1, launch_win_bicubic_c3_m2, launch_win_bicubic_c3_m3, launch_win_bicubic_c3_m4},
       {[](const KParams &Q, int o, int i, hipStream_t s) { return launch_win_bicubic_impl<0, 4>(Q, o, i, s); }, launch_win_bicubic_c4_m1,
-       launch_win_bicubic_c4_m2, launch_win_bicubic_c4_m3},
-      {launch_win_bicubic_c5_m0, launch_win_bicubic_c5_m1, launch_win_bicubic_c5_m2, launch_win_bicubic_c5_m3}};
-  return table[P.channels - 3][P.win_mode & 3](P, out_idx, in_mode, stream);
+       launch_win_bicubic_c4_m2, launch_win_bicubic_c4_m3, launch_win_bicubic_c4_m4},
+      {launch_win_bicubic_c5_m0, launch_win_bicubic_c5_m1, launch_win_bicubic_c5_m2, launch_win_bicubic_c5_m3, launch_win_bicubic_c5_m4}};
+  if (P.win_mode < 0 || P.win_mode > 4) return hipErrorInvalidValue;
+  return table[P.channels - 3][P.win_mode](P, out_idx, in_mode, stream);
 }
 } // namespace lrp

@@ -237,3 +237,21 @@ def test_hand_made_pan_and_pitch_matrices(lrp, oracle, torch_cuda):
             with np.errstate(all="ignore"):
                 want = oracle.reproject(lin, src, lout, out_w, out_h, 1, 2, rot, threads=8)
             render_all(lrp, torch_cuda, lin, src, lout, out_w, out_h, 2, rot, f"{in_name}->{out_name} matrix {m}", want, families=(2, 0))
+
+
+@pytest.mark.parametrize("out_w,out_h", [(200, 136), (201, 137), (65, 33), (16, 16), (7, 5), (130, 1), (1, 77)])
+@pytest.mark.parametrize("deg", [None, (0.0, 0.0, 0.0), (30.0, -15.0, 5.0), (0.0, 90.0, 0.0), (180.0, 0.0, 0.0)])
+def test_shared_rays_equidistant_target_bicubic(lrp, oracle, torch_cuda, out_w, out_h, deg):
+    """Equidistant target, bicubic (window kernel, QMode 4): the four mirror pixels share the ray through the output lens
+    under any rotation, each image runs its own rotation and source lens; the centre column / row of an odd-sized image
+    is its own mirror image.  Every source lens, RGBA / RGB / RGBAZ."""
+    in_w, in_h = 300, 160
+    rot = cases.rotation(lrp, deg)
+    lout = cases.lenses(lrp, out_w, out_h)["eqd180"]
+    for in_name, c in (("eqr_full", 4), ("eqr_part", 3), ("rect", 4), ("eqd120", 5), ("eqd180", 4)):
+        src = cases.hash_noise(in_h, in_w, c, seed=out_w + 3 * c)
+        lin = cases.lenses(lrp, in_w, in_h)[in_name]
+        with np.errstate(all="ignore"):
+            want = oracle.reproject(lin, src, lout, out_w, out_h, 1, 2, rot, threads=8)
+        render_all(lrp, torch_cuda, lin, src, lout, out_w, out_h, 2, rot, f"{in_name}->eqd180 C={c} {out_w}x{out_h} rot={deg}", want,
+                   channels=c, families=(2, 3, 0) if c == 4 else (2, 0))

@@ -13,7 +13,7 @@ for spec in "$@"; do
   FLAGS=(--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
          -fno-fast-math -fno-gpu-flush-denormals-to-zero -Wno-unused-function -I"$src" -I"$root/include" "${extra[@]}")
   pids=()
-  for s in lrp_kernels_nn.hip lrp_kernels_bl.hip lrp_kernels_bc.hip lrp_tile_nn.hip lrp_tile_bl.hip lrp_tile_bc.hip lrp_tile_win.hip lrp_tile_winq.hip lrp_tile_win3.hip lrp_tile_winq3.hip lrp_tile_win5.hip lrp_tile_winq5.hip lrp_tile_winy.hip lrp_tile_winx.hip lrp_tile_winy3.hip lrp_tile_winx3.hip lrp_tile_winy5.hip lrp_tile_winx5.hip lrp_tables.hip lrp_aux_kernels.hip lrp_pixel_kernels.hip lrp_capi.cpp lrp_host_util.cpp; do
+  for s in lrp_kernels_nn.hip lrp_kernels_bl.hip lrp_kernels_bc.hip lrp_tile_nn.hip lrp_tile_bl.hip lrp_tile_bc.hip lrp_tile_win.hip lrp_tile_winq.hip lrp_tile_win3.hip lrp_tile_winq3.hip lrp_tile_win5.hip lrp_tile_winq5.hip lrp_tile_winy.hip lrp_tile_winx.hip lrp_tile_winy3.hip lrp_tile_winx3.hip lrp_tile_winy5.hip lrp_tile_winx5.hip lrp_tile_winr.hip lrp_tile_winr3.hip lrp_tile_winr5.hip lrp_tables.hip lrp_aux_kernels.hip lrp_pixel_kernels.hip lrp_capi.cpp lrp_host_util.cpp; do
     ( /opt/rocm/bin/hipcc "${FLAGS[@]}" -x hip -c "$src/$s" -o "$out/${s%.*}.o" ) & pids+=($!)
   done
   for p in "${pids[@]}"; do wait "$p"; done

@@ -59,6 +59,9 @@ static const Workload kWorkloads[] = {
     {"rect_rect_bc", "rect", "rect", 2, 1, {10, 5, 0}},
     {"eqd_eqd_bc", "eqd", "eqd", 2, 1, {10, 5, 0}},
     {"eqr_eqr_bc_rot", "eqr", "eqr", 2, 1, {30, -15, 5}},
+    {"eqr_eqd_bc_rot", "eqr", "eqd", 2, 1, {30, -15, 5}},  // SURVEY 8d scaling shape: configs[2] with bicubic
+    {"eqr_rect_bc_gen", "eqr", "rect", 2, 1, {30, -15, 5}}, // general rotation (plain blocks)
+    {"rect_eqd_bc", "rect", "eqd", 2, 0, {0, 0, 0}},
     {"eqd_rect_bl", "eqd", "rect", 1, 0, {0, 0, 0}},
     {"eqd_rect_nn", "eqd", "rect", 0, 0, {0, 0, 0}},
     {"rect_eqr_nn", "rect", "eqr", 0, 1, {0, 0, 0}},
