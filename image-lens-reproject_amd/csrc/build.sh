@@ -11,12 +11,22 @@ FLAGS=(--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off
        -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -fno-gpu-flush-denormals-to-zero
        -Wall -Wno-unused-function -I"$here" -I"$here/../../include")
 srcs=(lrp_kernels_nn.hip lrp_kernels_bl.hip lrp_kernels_bc.hip lrp_tile_nn.hip lrp_tile_bl.hip lrp_tile_bc.hip lrp_tile_win.hip lrp_tile_winq.hip lrp_tile_win3.hip lrp_tile_winq3.hip lrp_tile_win5.hip lrp_tile_winq5.hip lrp_tile_winy.hip lrp_tile_winx.hip lrp_tile_winy3.hip lrp_tile_winx3.hip lrp_tile_winy5.hip lrp_tile_winx5.hip lrp_tile_winr.hip lrp_tile_winr3.hip lrp_tile_winr5.hip lrp_tables.hip lrp_aux_kernels.hip lrp_pixel_kernels.hip lrp_capi.cpp lrp_host_util.cpp)
+# Per-unit code generation options (measured on MI355X, tools/ablate.sh variants; bits are unaffected):
+#   the plain-block window kernels schedule for instruction-level parallelism: rectilinear -> equirectangular bicubic
+#   (BASELINE configs[3]) 229 -> 217 us, the other plain-block mappings within +-1 %; the mirrored units gain nothing.
+unit_flags() {
+  case "$1" in
+    lrp_tile_win.hip|lrp_tile_win3.hip|lrp_tile_win5.hip) echo "-mllvm -amdgpu-sched-strategy=max-ilp" ;;
+    *) echo "" ;;
+  esac
+}
 pids=()
 for s in "${srcs[@]}"; do
   o="$obj/${s%.*}.o"
   if [[ ! -f "$o" || "$here/$s" -nt "$o" || -n "$(find "$here" -maxdepth 1 -name '*.h' -newer "$o" -print -quit)" \
-        || "$here/../../include/lrp.h" -nt "$o" ]]; then
-    ( "$HIPCC" "${FLAGS[@]}" -x hip -c "$here/$s" -o "$o" ) &
+        || "$here/../../include/lrp.h" -nt "$o" || "${BASH_SOURCE[0]}" -nt "$o" ]]; then
+    # shellcheck disable=SC2046
+    ( "$HIPCC" "${FLAGS[@]}" $(unit_flags "$s") -x hip -c "$here/$s" -o "$o" ) &
     pids+=($!)
   fi
 done

@@ -29,11 +29,15 @@ def random_lens(lrp, rng, w, h):
 
 
 def random_rotation(lrp, rng):
-    r = rng.integers(0, 4)
+    r = rng.integers(0, 6)
     if r == 0:
         return None
     if r == 1:
         return cases.rotation(lrp, (0.0, 0.0, 0.0))
+    if r == 2:
+        return cases.rotation(lrp, (float(rng.uniform(-180.0, 180.0)), 0.0, 0.0))
+    if r == 3:
+        return cases.rotation(lrp, (0.0, float(rng.uniform(-180.0, 180.0)), 0.0))
     return cases.rotation(lrp, tuple(float(v) for v in rng.uniform(-180.0, 180.0, size=3)))
 
 
@@ -126,7 +130,7 @@ def test_magnified_bicubic_shared_tap_coefficients(lrp, oracle, torch_cuda, pair
 @pytest.mark.parametrize("chunk", range(int(__import__("os").environ.get("LRP_STRESS_CHUNKS", "8"))))
 def test_kernel_families_agree_on_many_random_configurations(lrp, torch_cuda, chunk):
     """40 random configurations per chunk (sizes up to 1500, all lens pairs, unrotated / identity /
-    pan-only / general rotations, 3-5 channels, 1-3 sub-samples), every sampler: the default
+    pan-only / pitch-only / general rotations, 3-5 channels, 1-3 sub-samples), every sampler: the default
     family (all work sharing on) must produce the bytes of the one-pixel-per-lane kernel, which
     shares nothing.  No oracle involved, so the configurations can be large and many."""
     torch = torch_cuda
@@ -137,13 +141,15 @@ def test_kernel_families_agree_on_many_random_configurations(lrp, torch_cuda, ch
         c = int(rng.choice([3, 4, 4, 5]))
         ns = int(rng.choice([1, 1, 1, 1, 2, 3]))
         lin, lout = random_lens(lrp, rng, in_w, in_h), random_lens(lrp, rng, out_w, out_h)
-        kind = int(rng.integers(0, 5))
+        kind = int(rng.integers(0, 6))
         if kind == 0:
             rot = None
         elif kind == 1:
             rot = cases.rotation(lrp, (0.0, 0.0, 0.0))
-        elif kind == 2:
+        elif kind == 2:  # pan only: top / bottom mirror blocks
             rot = cases.rotation(lrp, (float(rng.choice([90.0, 180.0, 270.0, 33.0, -71.5])), 0.0, 0.0))
+        elif kind == 3:  # pitch only: left / right mirror blocks (rectilinear targets)
+            rot = cases.rotation(lrp, (0.0, float(rng.choice([90.0, -90.0, 180.0, 33.0, -71.5])), 0.0))
         else:
             rot = cases.rotation(lrp, tuple(float(v) for v in rng.uniform(-180.0, 180.0, size=3)))
         d_in = torch.empty((in_h, in_w, c), dtype=torch.float32, device="cuda")

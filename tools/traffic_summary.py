@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""Summarise the FETCH_SIZE / WRITE_SIZE passes of tools/collect_traffic.sh.
+"""Summarise the FETCH_SIZE / WRITE_SIZE passes of tools/collect_traffic.sh into profiles/traffic_rNN.json.
 
 rocprofv3 reports both counters in KiB.  MI355X_MICROARCH.md (section HBM): on gfx950
 FETCH_SIZE reads exactly half the bytes of a wide coalesced streaming read and other
 access patterns are uncalibrated, WRITE_SIZE reads 16-byte streaming stores exactly.
-The probe therefore runs a calibration kernel with known traffic (stand-alone
-post_process on a 4096^2 RGBA frame: 268435456 B read, 268435456 B written) and the
-read-side factor measured on it is applied to the reprojection kernels."""
+The probe therefore launches a calibration kernel with known traffic in front of every workload
+(stand-alone post_process on a 4096^2 RGBA frame: 268435456 B read, 268435456 B written) and the
+read-side factor measured on it is applied to the reprojection kernels.  The dispatches are
+attributed to workloads by their ORDER (tools/traffic_probe.py writes it): the calibration
+launches separate them; the first frame of each workload is dropped."""
 import collections
 import csv
 import glob
@@ -19,45 +21,58 @@ import bench  # noqa: E402  (kernel_source_sha: the stamp bench.py checks before
 
 src_dir, out_path = sys.argv[1], sys.argv[2]
 KNOWN = 4096 * 4096 * 4 * 4
+order = json.load(open(os.path.join(src_dir, "order.json")))
+SKIP = ("build_tables_kernel", "build_xsep_kernel", "synth_fill_kernel", "checksum_kernel", "__amd_rocclr")
 
 
-def per_kernel(counter):
-    vals = collections.defaultdict(list)
+def dispatches(counter):
+    """[(dispatch id, kernel name, bytes)] in dispatch order."""
+    rows = {}
     for f in glob.glob(os.path.join(src_dir, counter, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
-                vals[r["Kernel_Name"]].append(float(r["Counter_Value"]) * 1024.0)
-    return {k: sum(v) / len(v) for k, v in vals.items()}, {k: len(v) for k, v in vals.items()}
+                rows[int(r["Dispatch_Id"])] = (r["Kernel_Name"], float(r["Counter_Value"]) * 1024.0)
+    return [(i, k, v) for i, (k, v) in sorted(rows.items()) if not any(s in k for s in SKIP)]
 
 
-fetch, nf = per_kernel("FETCH_SIZE")
-write, nw = per_kernel("WRITE_SIZE")
-cal = [k for k in fetch if "post_process_kernel" in k]
-read_factor, write_factor = 2.0, 1.0
-calibration = None
-if cal:
-    k = cal[0]
-    read_factor = KNOWN / fetch[k]
-    write_factor = KNOWN / write[k] if k in write and write[k] else 1.0
-    calibration = {"kernel": k, "known_bytes_each_way": KNOWN, "FETCH_SIZE_bytes_raw": fetch[k],
-                   "WRITE_SIZE_bytes_raw": write.get(k), "read_factor": read_factor, "write_factor": write_factor}
-names = {"reproject_bicubic_win_kernel<0, 1,": "fisheye_to_rect_bicubic",
-         "reproject_bicubic_win_kernel<0, 3,": "equirect_to_rect_bicubic",
-         "reproject_tile_kernel<1, 3, 1, 4>": "equirect_to_fisheye_bilinear",
-         "reproject_tile_kernel<0, 3, 0, 4>": "equirect_to_rect_nearest",
-         "reproject_bicubic_win_kernel<4, 0,": "rect_to_equirect_bicubic"}
+def per_workload(counter):
+    """calibration average, {workload: (bytes per frame, kernel names, frames averaged)}"""
+    groups, cal, cur = [], [], None
+    for _i, k, v in dispatches(counter):
+        if "post_process_kernel" in k:
+            cal.append(v)
+            cur = []
+            groups.append(cur)
+        elif cur is not None:
+            cur.append((k, v))
+    out = {}
+    for o, g in zip(order, groups):
+        lpf, frames = o["launches_per_frame"], o["frames"]
+        if len(g) != lpf * frames:
+            out[o["workload"]] = None  # the launch sequence is not what the probe says: do not guess
+            continue
+        kept = g[lpf:]  # drop the first frame
+        out[o["workload"]] = (sum(v for _k, v in kept) / (frames - 1), sorted({k for k, _v in kept}), frames - 1)
+    return (sum(cal) / len(cal) if cal else None), out
+
+
+cal_f, fetch = per_workload("FETCH_SIZE")
+cal_w, write = per_workload("WRITE_SIZE")
+read_factor = KNOWN / cal_f if cal_f else 2.0
+write_factor = KNOWN / cal_w if cal_w else 1.0
 result = {"_kernel_source_sha": bench.kernel_source_sha(),
-          "_calibration": calibration,
+          "_calibration": {"kernel": "post_process_kernel on a 4096^2 RGBA frame", "known_bytes_each_way": KNOWN, "FETCH_SIZE_bytes_raw": cal_f,
+                           "WRITE_SIZE_bytes_raw": cal_w, "read_factor": read_factor, "write_factor": write_factor},
           "_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/traffic_probe.py; KiB -> "
                      "bytes; reads scaled by the factor measured on the calibration kernel (guide: 2.0 for 16 B/lane "
-                     "streams on gfx950), writes taken as reported"}
-for k in fetch:
-    for pat, wl in names.items():
-        if pat in k:
-            rd = fetch[k] * read_factor
-            wr = write.get(k, float("nan"))
-            result[wl] = {"kernel": k, "launches_averaged": nf[k], "FETCH_SIZE_bytes_raw": fetch[k],
-                          "WRITE_SIZE_bytes_raw": write.get(k), "hbm_read_bytes": rd, "hbm_write_bytes": wr,
-                          "hbm_bytes_per_launch": rd + wr}
+                     "streams on gfx950), writes taken as reported; per FRAME of the workload (one launch; six for the cubemap)"}
+for o in order:
+    wl = o["workload"]
+    f, w = fetch.get(wl), write.get(wl)
+    if not f or not w:
+        continue
+    rd, wr = f[0] * read_factor, w[0]
+    result[wl] = {"kernels": f[1], "frames_averaged": f[2], "launches_per_frame": o["launches_per_frame"], "FETCH_SIZE_bytes_raw": f[0],
+                  "WRITE_SIZE_bytes_raw": w[0], "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
 json.dump(result, open(out_path, "w"), indent=1)
 print(json.dumps(result, indent=1))
