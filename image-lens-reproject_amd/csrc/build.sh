@@ -6,6 +6,7 @@ out="$here/../lib"
 obj="$here/../lib/obj"
 mkdir -p "$out" "$obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+jobs="${1:-$(( $(nproc) + 4 ))}"
 # Parity flags: no FMA contraction, IEEE divide/sqrt, denormals kept, no fast-math.
 FLAGS=(--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off
        -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -fno-gpu-flush-denormals-to-zero
@@ -25,6 +26,8 @@ for s in "${srcs[@]}"; do
   o="$obj/${s%.*}.o"
   if [[ ! -f "$o" || "$here/$s" -nt "$o" || -n "$(find "$here" -maxdepth 1 -name '*.h' -newer "$o" -print -quit)" \
         || "$here/../../include/lrp.h" -nt "$o" || "${BASH_SOURCE[0]}" -nt "$o" ]]; then
+    # at most $jobs compilers at once (a window-kernel unit takes 1-2 GiB)
+    while (( $(jobs -rp | wc -l) >= jobs )); do wait -n || true; done
     # shellcheck disable=SC2046
     ( "$HIPCC" "${FLAGS[@]}" $(unit_flags "$s") -x hip -c "$here/$s" -o "$o" ) &
     pids+=($!)

@@ -61,6 +61,9 @@
 
 namespace lrp {
 
+#ifndef LRP_VERT_STEPS
+#define LRP_VERT_STEPS 1 // coefficient tier: the vertical evaluations interleaved step by step (0: chain by chain, the compiler's order)
+#endif
 #ifndef LRP_OPT_POST
 #define LRP_OPT_POST 1
 #endif
@@ -1920,7 +1923,59 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
             r.hi = bj.hi + hfy * (cma.hi + fy * (m0.hi + fy * inner.hi));
             return r;
           };
+#if LRP_VERT_STEPS
+          // The four vertical evaluations step by step across the eight channel-pair chains instead of chain by chain:
+          // a step's eight instructions are independent and the next step's operands are eight instructions old, so a
+          // wavefront never waits on its own previous instruction (chain by chain, the compiler's order, every other
+          // instruction depends on its predecessor and is preceded by an s_nop).  The plane reads are issued in the
+          // order the steps consume them.  Same operations on the same operands.
+          (void)vert;
+          Rgba ci_[4], cm_[4], cc_[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ci_[j] = as_rgba(ci[j]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) cm_[j] = as_rgba(cm[j]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) cc_[j] = as_rgba(cc[j]);
+          __builtin_amdgcn_sched_barrier(0);
+          const Rgba bb[4] = {b0, b1, b2, b3};
+          f2 t[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            t[2 * j] = fy * ci_[j].lo;
+            t[2 * j + 1] = fy * ci_[j].hi;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            t[2 * j] = cm_[j].lo + t[2 * j];
+            t[2 * j + 1] = cm_[j].hi + t[2 * j + 1];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) t[i] = fy * t[i];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            t[2 * j] = cc_[j].lo + t[2 * j];
+            t[2 * j + 1] = cc_[j].hi + t[2 * j + 1];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) t[i] = hfy * t[i];
+          __builtin_amdgcn_sched_barrier(0);
+          Rgba kk[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            kk[j] = px_zero<4>();
+            kk[j].lo = bb[j].lo + t[2 * j];
+            kk[j].hi = bb[j].hi + t[2 * j + 1];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const Rgba k0 = kk[0], k1 = kk[1], k2 = kk[2], k3 = kk[3];
+#else
           const Rgba k0 = vert(0, b0), k1 = vert(1, b1), k2 = vert(2, b2), k3 = vert(3, b3);
+#endif
           s = cubic4(k0, k1, k2, k3, fx, hfx);
           if constexpr (CH == 5) s.e = depth_from_window(win, tap - cur.spitch(), fx, fy, hfx, hfy, last_pass);
         } else if (t_staged) {
