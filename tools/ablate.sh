@@ -1,14 +1,16 @@
 #!/usr/bin/env bash
-# Builds timing-experiment variants of liblrp_hip.so into tools/_ablate/<n>/ (LRP_ABLATE=n
-# switches parts of the bicubic window kernel off; outputs are WRONG by design).
-# Run a variant with:  LD_LIBRARY_PATH=tools/_ablate/<n> tools/kbench eqd_rect_bc
+# Builds variants of liblrp_hip.so into tools/_ablate/<name>/ for same-box A/B timing: tuning knobs (-DLRP_WIN_STRIP=4,
+# -DLRP_VERT_STEPS=0, -DLRP_NO_PACKED=1 ...), compiler options (-mllvm ...), and the timing-only experiments whose
+# outputs are WRONG by design (-DLRP_ABLATE_ONETAP, -DLRP_ABLATE_L2ROWS, -DLRP_NO_STORE, -DLRP_SKIP_PLANES,
+# -DLRP_SKIP_TAP_READS, -DLRP_NO_DMA_WAIT).  Note: the per-unit options of csrc/build.sh are not applied here.
+# Run a variant with:  LD_LIBRARY_PATH=tools/_ablate/<name> tools/kbench eqd_rect_bc
 set -euo pipefail
 root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 src="$root/image-lens-reproject_amd/csrc"
-# usage: ablate.sh <name>[:-Dflag[,-Dflag...]] ...   (a bare number n means -DLRP_ABLATE=n)
+# usage: ablate.sh <name>:<flag>[,<flag>...] ...
 for spec in "$@"; do
   n="${spec%%:*}"; extra=()
-  if [[ "$spec" == *:* ]]; then IFS=, read -ra extra <<< "${spec#*:}"; else extra=(-DLRP_ABLATE=$n); fi
+  if [[ "$spec" == *:* ]]; then IFS=, read -ra extra <<< "${spec#*:}"; fi
   out="$root/tools/_ablate/$n"; mkdir -p "$out"
   FLAGS=(--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
          -fno-fast-math -fno-gpu-flush-denormals-to-zero -Wno-unused-function -I"$src" -I"$root/include" "${extra[@]}")
