@@ -37,6 +37,9 @@
 //   taps fall back, per wavefront, to explicit per-tap addressing.
 #pragma once
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "lrp_device.h"
 #include "lrp_source_axes.h"
 
@@ -1179,7 +1182,9 @@ template <bool Fat> struct WinBlockT {
 //      evaluated once per quadrant pixel and its sign-flipped copies go through the rotation and the source lens per
 //      mirror image, like the pixels of plain blocks.  Images g = 0..3.
 // The host (lrp_capi.cpp win_mirror_mode) checks the matrix entries and the symmetry flags of the output-lens tables.
-template <int OutLens, int InMode, int QMode, int CH>
+// Frames: the instantiation for batched launches whose wavefronts walk several frames (the frame loop costs the
+// one-frame case registers, so single launches keep an instantiation without it).
+template <int OutLens, int InMode, int QMode, int CH, bool Frames = false>
 #ifndef LRP_WIN_MINWAVES5
 #define LRP_WIN_MINWAVES5 3 // RGBAZ: 168 VGPRs (the 80 registers of a direct-path tap set do not fit 128 without spilling)
 #endif
@@ -1189,7 +1194,10 @@ template <int OutLens, int InMode, int QMode, int CH>
 #ifndef LRP_WIN_MINWAVES_RAYS
 #define LRP_WIN_MINWAVES_RAYS 3 // shared-ray mode (QMode 4): the rays of four pixels (12 VGPRs) next to the coordinates of two blocks do not fit 128; measured 251 us at four waves per SIMD (66 spilled registers), 227 at three, 236 plain
 #endif
-__global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode == 4 ? LRP_WIN_MINWAVES_RAYS : (QMode >= 2 ? LRP_WIN_MINWAVES_AXIS : LRP_WIN_MINWAVES))) void reproject_bicubic_win_kernel(const KParams Pk) {
+#ifndef LRP_WIN_MINWAVES_FRAMES
+#define LRP_WIN_MINWAVES_FRAMES 4 // the instantiations with the frame loop
+#endif
+__global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode == 4 ? LRP_WIN_MINWAVES_RAYS : (Frames ? LRP_WIN_MINWAVES_FRAMES : (QMode >= 2 ? LRP_WIN_MINWAVES_AXIS : LRP_WIN_MINWAVES)))) void reproject_bicubic_win_kernel(const KParams Pk) {
   constexpr bool Quad = QMode != 0;
   constexpr bool MirX = QMode == 1 || QMode == 3 || QMode == 4, MirY = QMode == 1 || QMode == 2 || QMode == 4;
   constexpr bool kSharedRays = QMode == 4; // only the ray through the output lens is shared: per-image coordinates are stored like a plain block's
@@ -1199,7 +1207,18 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   static_assert(CH == 3 || CH == 4 || CH == 5, "window kernel: RGB, RGBA or RGBAZ");
   static_assert(QMode != 2 || (OutLens != kEquidistant && InMode != kInEquidistant), "rows-only mirroring goes through the column-separable source x");
   static_assert(QMode != 3 || OutLens == kRect, "columns-only mirroring needs vz == -1");
-  const KParams P = batch_frame(Pk);
+  // Frames of a batched launch share one geometry: the source coordinates of a pixel, the window of a block and its tier
+  // are the same in every frame.  A wavefront therefore renders its strip for `frames_per_wave` consecutive frames
+  // (blockIdx.y = group of frames) and runs everything that does not depend on the pixel DATA — stage 1 of the coordinate
+  // math, the wave-wide box reductions, the window plan — once per block instead of once per block and frame.
+  const int frames_per_wave = Frames ? (Pk.frames_per_wave > 0 ? Pk.frames_per_wave : 1) : 1;
+  const int frame0 = Pk.batch_n > 0 ? (int)blockIdx.y * frames_per_wave : 0;
+  const int n_frames = (Frames && Pk.batch_n > 0) ? min(frames_per_wave, Pk.batch_n - frame0) : 1;
+  auto frame_src = [&](int f) { return Pk.batch_n > 0 ? Pk.batch_src[frame0 + f] : Pk.src; };
+  auto frame_dst = [&](int f) { return Pk.batch_n > 0 ? Pk.batch_dst[frame0 + f] : Pk.dst; };
+  KParams P = Pk; // src / dst: the frame being rendered (set_frame below)
+  P.src = frame_src(0);
+  P.dst = frame_dst(0);
   constexpr bool Loop = (InMode == kInEquirectLoop);
   constexpr int kPlanes = 3;
   __shared__ float4 s_win[kWinWaves][kWinCap];
@@ -1263,8 +1282,12 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   const int y_lane = P.y_offset + ty * (quad ? kBlkH : kBlkH * G) + prow; // + kBlkH * g + kPassRows * pass
   const int xe = x < qw ? x : qw - 1;
   const int in_w = P.in_w;
-  const SrcView src = source_view<2, CH>(P);
-  const float4 *__restrict__ src4 = reinterpret_cast<const float4 *>(P.src);
+  SrcView src = source_view<2, CH>(P);
+  auto set_frame = [&](int f) {
+    P.src = frame_src(f);
+    P.dst = frame_dst(f);
+    src = source_view<2, CH>(P);
+  };
   float4 *const win0 = s_win[wave];
   constexpr bool kRunsEverywhere = CH == 5 && OutLens == kEquirect && InMode == kInRect;
   float *out_lds = nullptr; // RGBAZ: the wavefront's exchange buffer of store_rgbaz_run (three waves per SIMD: the LDS is there)
@@ -1560,13 +1583,13 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       return cubic_px<4>(k, k, k, k, fx, hfx);
     }
   };
-  auto issue = [&](int g, const WinBlock &b) {
+  auto issue = [&](const float *frame, const WinBlock &b) { // the window `b` of the source frame `frame`
     if (b.staged()) {
       // LDS-DMA, one window row per instruction, lanes beyond the width masked off
       float4 *const win = win0;
-      const float4 *gp = src4 + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane));
-      const float *gp3 = P.src + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane)) * 3u;
-      const float *gp5 = P.src + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane)) * 5u;
+      const float4 *gp = reinterpret_cast<const float4 *>(frame) + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane));
+      const float *gp3 = frame + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane)) * 3u;
+      const float *gp5 = frame + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane)) * 5u;
       // Issued as inline assembly: the compiler's wait-count insertion then does not know
       // that LDS is being written and puts no vmcnt(0) in front of later LDS reads (of the
       // coefficient planes, which the DMA does not touch); the one wait that IS needed sits
@@ -1663,13 +1686,22 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   // see below, so that store is always issued.)
   WinBlock cur, nxt;
   coords(0, cur);
-  issue(0, cur);
-  int g_loop = 0;
+  issue(P.src, cur);
+  int g_loop = 0, f_loop = 0;
   bool dma_early = false; // the pending window was requested before its block's last store
+  // The step after (block g_loop, frame f_loop): the same block in the next frame, or the next block in the first frame.
+  auto issue_next = [&]() {
+    if (f_loop + 1 < n_frames)
+      issue(frame_src(f_loop + 1), cur);
+    else
+      issue(frame_src(0), nxt);
+  };
+  auto has_next = [&]() { return f_loop + 1 < n_frames || g_loop + 1 < G; };
   auto next_window = [&]() {
     // while this block's coefficient planes are still being read the next raw window must stay in front of them
-    dma_early = g_loop + 1 < G && (!(kWinCoef && cur.coef()) || raw_slots(nxt) <= cur.c_base);
-    if (dma_early) issue(g_loop + 1, nxt);
+    // (the same block's window in the next frame always does: planes sit behind the raw window)
+    dma_early = has_next() && (!(kWinCoef && cur.coef()) || f_loop + 1 < n_frames || raw_slots(nxt) <= cur.c_base);
+    if (dma_early) issue_next();
   };
   // The result of pass k of block g: num_samples == 1, (0.0f + s) * normalize (src/reproject.cpp:334-341), store.
   auto emit = [&](int g, int k, const Rgba &s, auto as_runs) {
@@ -1683,7 +1715,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
     // (the four clamped rows of a mirrored strip are loop-invariant; hoisted they occupy four VGPRs for the whole
     // strip — which spilled — so the row is re-derived from an opaque copy here: an add and a min per pass)
     int y_base = y_lane;
-    if constexpr (Quad && kInEqr) asm volatile("" : "+v"(y_base));
+    asm volatile("" : "+v"(y_base)); // (likewise not hoisted out of the frame loop)
     const int yk = y_base + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
     const int yc = yk < qh ? yk : qh - 1;
     const int gm = image_of(g);
@@ -1735,12 +1767,17 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   };
 #pragma unroll 1
   for (int g = 0; g < G; ++g) {
-    g_loop = g;
-    // plain blocks: the next block's coordinates here, long before its window is requested in the
-    // last pass; mirrored blocks derive theirs in a few instructions right there (fewer live registers)
-    if ((!Quad || kSharedRays) && g + 1 < G) coords(g + 1, nxt); // (shared rays: the rotation and the source lens run per image, as for a plain block)
+   g_loop = g;
+   // plain blocks: the next block's coordinates here, long before its window is requested in the
+   // last pass; mirrored blocks derive theirs in a few instructions right there (fewer live registers)
+   if ((!Quad || kSharedRays) && g + 1 < G) coords(g + 1, nxt); // (shared rays: the rotation and the source lens run per image, as for a plain block)
+#pragma unroll 1
+   for (int f = 0; f < n_frames; ++f) {
+    f_loop = f;
+    if (n_frames > 1 || g == 0) set_frame(f);
+    const bool last_frame = f + 1 == n_frames; // the next step is the next block
 #if !defined(LRP_NO_DMA_WAIT) // timing experiment (wrong results): how much of the frame is exposed DMA / store latency
-    if (g == 0 || !dma_early)
+    if ((g == 0 && f == 0) || !dma_early)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the window was the last thing requested
     else
       asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); // window g has landed; block g-1's last store may be in flight
@@ -1759,14 +1796,14 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       // every pixel of this block is one value: no taps, no per-pixel arithmetic — four stores.  The next block's
       // window is requested in front of the last store, as in the last pass of an ordinary block.
       const Rgba cs = corner_value(cur);
-      if (Quad && !kSharedRays && g + 1 < G) coords(g + 1, nxt);
+      if (Quad && !kSharedRays && last_frame && g + 1 < G) coords(g + 1, nxt);
       emit(g, 0, cs, std::true_type{});
       emit(g, 1, cs, std::true_type{});
       emit(g, 2, cs, std::true_type{});
       next_window();
       emit(g, 3, cs, std::true_type{});
-      if (!dma_early && g + 1 < G) issue(g + 1, nxt);
-      cur = nxt;
+      if (!dma_early && has_next()) issue_next();
+      if (last_frame) cur = nxt;
       continue;
     }
 #if defined(LRP_TIER_STATS)
@@ -1781,13 +1818,16 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       for (int kk = 0; kk < 2; ++kk) {
         const int k = 2 * h + kk;
         const bool last_pass = k == 3;
-        if (Quad && !kSharedRays && k == 3 && g + 1 < G) coords(g + 1, nxt); // only its box is kept
+        if (Quad && !kSharedRays && k == 3 && last_frame && g + 1 < G) coords(g + 1, nxt); // only its box is kept
         float psx = cur.sx[k], psy = cur.sy[k];
         if constexpr (Quad && !kSharedRays) quad_xy(image_of(g), k, psx, psy); // re-derived (2-4 instructions) instead of held in registers
         // (where the coordinates of a mirror image are a plain selection of stored values the compiler would otherwise
         // hoist everything derived from them — truncations, weights, window addresses of all four passes and both
         // images — out of the block loop and spill it: the selected values are opaque here)
-        if constexpr (QMode >= 2) asm volatile("" : "+v"(psx), "+v"(psy));
+        // (the same goes for the frame loop: everything derived from the coordinates of a pass is the same in every frame,
+        // and kept for all four passes it does not fit the registers — what IS shared between frames is stage 1 and the
+        // window plan, by construction)
+        asm volatile("" : "+v"(psx), "+v"(psy));
         Rgba s;
         if (t_coef) {
           const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
@@ -1906,8 +1946,9 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
         emit(g, k, s, std::integral_constant<bool, kRunsEverywhere>{});
       }
     }
-    if (!dma_early && g + 1 < G) issue(g + 1, nxt); // after the last read of the planes
-    cur = nxt;
+    if (!dma_early && has_next()) issue_next(); // after the last read of the planes
+    if (last_frame) cur = nxt;
+   }
   }
 }
 
@@ -1951,7 +1992,7 @@ template <int Interp> hipError_t launch_tile_interp(KParams P, int out_idx, int 
 
 // The window kernel of one (output lens, source mode) cell for a mirror mode, or null where the mode does not exist
 // (rows-only needs the column-separable source x: no equidistant lens on either side; columns-only a rectilinear target).
-template <int OutLens, int InMode, int QMode, int CH> constexpr TileKernelFn win_kernel_fn() {
+template <int OutLens, int InMode, int QMode, int CH, bool Frames> constexpr TileKernelFn win_kernel_fn() {
   if constexpr (QMode == 2 && (OutLens == kEquidistant || InMode == kInEquidistant))
     return nullptr;
   else if constexpr (QMode == 3 && OutLens != kRect)
@@ -1959,17 +2000,17 @@ template <int OutLens, int InMode, int QMode, int CH> constexpr TileKernelFn win
   else if constexpr (QMode == 4 && OutLens != kEquidistant)
     return nullptr;
   else
-    return reproject_bicubic_win_kernel<OutLens, InMode, QMode, CH>;
+    return reproject_bicubic_win_kernel<OutLens, InMode, QMode, CH, Frames>;
 }
-template <int QMode, int CH> struct WinKernelTable {
+template <int QMode, int CH, bool Frames> struct WinKernelTable {
   static TileKernelFn get(int out_idx, int in_mode) {
     static const TileKernelFn table[3][4] = {
-        {win_kernel_fn<kRect, kInRect, QMode, CH>(), win_kernel_fn<kRect, kInEquidistant, QMode, CH>(),
-         win_kernel_fn<kRect, kInEquirect, QMode, CH>(), win_kernel_fn<kRect, kInEquirectLoop, QMode, CH>()},
-        {win_kernel_fn<kEquidistant, kInRect, QMode, CH>(), win_kernel_fn<kEquidistant, kInEquidistant, QMode, CH>(),
-         win_kernel_fn<kEquidistant, kInEquirect, QMode, CH>(), win_kernel_fn<kEquidistant, kInEquirectLoop, QMode, CH>()},
-        {win_kernel_fn<kEquirect, kInRect, QMode, CH>(), win_kernel_fn<kEquirect, kInEquidistant, QMode, CH>(),
-         win_kernel_fn<kEquirect, kInEquirect, QMode, CH>(), win_kernel_fn<kEquirect, kInEquirectLoop, QMode, CH>()}};
+        {win_kernel_fn<kRect, kInRect, QMode, CH, Frames>(), win_kernel_fn<kRect, kInEquidistant, QMode, CH, Frames>(),
+         win_kernel_fn<kRect, kInEquirect, QMode, CH, Frames>(), win_kernel_fn<kRect, kInEquirectLoop, QMode, CH, Frames>()},
+        {win_kernel_fn<kEquidistant, kInRect, QMode, CH, Frames>(), win_kernel_fn<kEquidistant, kInEquidistant, QMode, CH, Frames>(),
+         win_kernel_fn<kEquidistant, kInEquirect, QMode, CH, Frames>(), win_kernel_fn<kEquidistant, kInEquirectLoop, QMode, CH, Frames>()},
+        {win_kernel_fn<kEquirect, kInRect, QMode, CH, Frames>(), win_kernel_fn<kEquirect, kInEquidistant, QMode, CH, Frames>(),
+         win_kernel_fn<kEquirect, kInEquirect, QMode, CH, Frames>(), win_kernel_fn<kEquirect, kInEquirectLoop, QMode, CH, Frames>()}};
     return table[out_idx][in_mode];
   }
 };
@@ -1998,9 +2039,23 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
   }
   const int n_tiles = P.tiles_x * P.tiles_y;
   if (n_tiles <= 0) return hipSuccess;
-  const TileKernelFn fn = WinKernelTable<QMode, CH>::get(out_idx, in_mode);
+  // Frames per wavefront of a batched launch: as many as leave at least two rounds of wavefronts on the chip
+  // (4096 wave slots), so that a 4K batch of 16 runs every strip through all 16 frames and small images keep the chip full.
+  int groups = P.batch_n > 0 ? P.batch_n : 1;
+  P.frames_per_wave = 1;
+  if (P.batch_n > 1) {
+    const long long units = (long long)n_tiles * kWinWaves * P.batch_n;
+    int F = (int)std::min<long long>(P.batch_n, std::max<long long>(1, units / 8192));
+    // a rectilinear view inside a panorama: a quarter of the strips (the ones in view) carry most of the frame's time and
+    // gain nothing from shared coordinates (they wait for gathers) — 16 frames long they unbalance the launch (223 -> 256 us)
+    if (out_idx == 2 && in_mode == kInRect) F = 1;
+    if (const char *e = std::getenv("LRP_BATCH_FRAMES")) F = std::max(1, std::min(P.batch_n, std::atoi(e))); // A/B runs
+    P.frames_per_wave = F;
+    groups = (P.batch_n + F - 1) / F;
+  }
+  const TileKernelFn fn = P.frames_per_wave > 1 ? WinKernelTable<QMode, CH, true>::get(out_idx, in_mode) : WinKernelTable<QMode, CH, false>::get(out_idx, in_mode);
   if (!fn) return hipErrorInvalidValue; // (the host never asks for a mode outside its cells)
-  hipLaunchKernelGGL(fn, dim3((unsigned)(kXcds * xcd_rows(P.tiles_y) * P.tiles_x), (unsigned)(P.batch_n > 0 ? P.batch_n : 1)), dim3(kWinThreads), 0, stream, P);
+  hipLaunchKernelGGL(fn, dim3((unsigned)(kXcds * xcd_rows(P.tiles_y) * P.tiles_x), (unsigned)groups), dim3(kWinThreads), 0, stream, P);
   return hipGetLastError();
 }
 

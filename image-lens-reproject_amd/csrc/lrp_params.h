@@ -77,6 +77,7 @@ struct KParams {
   const float *batch_src[kMaxBatch];
   float *batch_dst[kMaxBatch];
   int32_t quad;                     // 1: mirrored pixels / blocks (mapping symmetric about both image axes); 2: mirrored rays (tile kernels, equidistant target)
+  int32_t frames_per_wave;          // window kernel, batched launch: consecutive frames one wavefront renders its strip for (blockIdx.y = group of frames)
   int32_t win_mode;                 // window kernel: 0 plain blocks, 1 blocks mirrored in both axes (== quad 1), 2 rows only (pan), 3 columns only (pitch), 4 shared rays (equidistant target, any rotation)
 };
 

@@ -133,6 +133,49 @@ def test_batched_launch_equals_single_calls(lrp, torch_cuda, channels, interp, d
         assert bool(torch.equal(single[i].view(torch.int32), batched[i].view(torch.int32))), f"frame {i} differs"
 
 
+@pytest.mark.parametrize("frames", ["2", "3", "16"])
+@pytest.mark.parametrize("channels,in_name,out_name,deg", [
+    (4, "eqd180", "rect", None),                  # mirrored in both axes
+    (4, "eqr_full", "rect", (90.0, 0.0, 0.0)),    # rows only
+    (3, "eqr_full", "rect", (0.0, -90.0, 0.0)),   # columns only
+    (4, "eqr_full", "eqd180", (30.0, -15.0, 5.0)),  # shared rays
+    (4, "rect_tele", "rect", (30.0, -15.0, 5.0)),   # plain blocks, raw taps
+    (5, "eqr_part", "rect", (12.0, 7.0, 0.0)),      # RGBAZ, plain blocks
+    (4, "rect", "eqr_full", None),                  # corner blocks, direct taps, alias pairs
+])
+def test_batched_launch_with_several_frames_per_wavefront(lrp, torch_cuda, frames, channels, in_name, out_name, deg):
+    """Bicubic batches: a wavefront of the window kernel renders its strip for several consecutive frames and shares the
+    coordinate math and the window plan between them (LRP_BATCH_FRAMES forces the count; by default small images keep
+    one frame per wavefront).  21 frames (so that the last group is short: 21 = 16 + 5 launches, groups of 2 / 3 / 16)
+    against 21 single calls, bit for bit, in every mirror mode."""
+    import os
+
+    torch = torch_cuda
+    in_w, in_h, out_w, out_h, n = 300, 180, 201, 137, 21
+    lin, lout = cases.lenses(lrp, in_w, in_h)[in_name], cases.lenses(lrp, out_w, out_h)[out_name]
+    rot = cases.rotation(lrp, deg)
+    srcs = [torch.empty((in_h, in_w, channels), dtype=torch.float32, device="cuda") for _ in range(n)]
+    for i, s in enumerate(srcs):
+        lrp.synth_fill(s, in_w, in_h, channels, 0xF4A30000 + i, 4 if channels == 5 else -1)
+    single = [torch.full((out_h, out_w, channels), -1.0, dtype=torch.float32, device="cuda") for _ in range(n)]
+    batched = [torch.full((out_h, out_w, channels), -2.0, dtype=torch.float32, device="cuda") for _ in range(n)]
+    for s, d in zip(srcs, single):
+        lrp.reproject(lrp.Image(lin, in_w, in_h, channels, s), lrp.Image(lout, out_w, out_h, channels, d), 1, 2, rot, post=(2.0, 4.0))
+    prev = os.environ.get("LRP_BATCH_FRAMES")
+    os.environ["LRP_BATCH_FRAMES"] = frames
+    try:
+        lrp.reproject_batch([lrp.Image(lin, in_w, in_h, channels, s) for s in srcs],
+                            [lrp.Image(lout, out_w, out_h, channels, d) for d in batched], 1, 2, rot, post=(2.0, 4.0))
+        torch.cuda.synchronize()
+    finally:
+        if prev is None:
+            del os.environ["LRP_BATCH_FRAMES"]
+        else:
+            os.environ["LRP_BATCH_FRAMES"] = prev
+    for i in range(n):
+        assert bool(torch.equal(single[i].view(torch.int32), batched[i].view(torch.int32))), f"frame {i} differs"
+
+
 def test_batched_launch_rejects_mixed_geometries(lrp, torch_cuda):
     torch = torch_cuda
     a = torch.zeros((64, 64, 4), dtype=torch.float32, device="cuda")
