@@ -264,6 +264,9 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     const bool sym_out = out->lens.type == LRP_FISHEYE_EQUIDISTANT ? true : symmetry == 3;
     P.quad = !band && quad_enabled() && kernel_choice() != 3 && num_samples == 1 && !P.has_rot && sym_out &&
              (!in_eqr || P.xsep_tab != nullptr);
+    // A batch of nearest-neighbour frames shares its coordinates between up to 16 frames (the plain path of the tile
+    // kernel keeps them in registers), which beats sharing them between four mirror pixels: 71 -> 66 us per 4K frame.
+    if (P.quad && n_batch >= 4 && interpolation == LRP_NEAREST) P.quad = 0;
     const bool window = interpolation == LRP_BICUBIC && kernel_choice() >= 2 && num_samples == 1 &&
                         (out->channels == 4 || out->channels == 3 || out->channels == 5);
     // Equidistant target, rotated (or an equirectangular source): the four mirror pixels still

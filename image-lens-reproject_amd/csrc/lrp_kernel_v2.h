@@ -867,10 +867,23 @@ __device__ __forceinline__ void store_tile_row(const KParams &P, float *run_lds,
 }
 
 // ---- the tile kernel (RGB / RGBA / RGBAZ float) ----------------------------------
-template <int OutLens, int InMode, int Interp, int CH>
-__global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_kernel(const KParams Pk) {
+// Frames: the instantiation for batched launches whose wavefronts render their pixels for several consecutive frames of
+// the batch (all frames share one geometry): the source coordinates of a wavefront's pixels are evaluated once, kept in
+// registers, and every frame only requests its taps, interpolates and stores.
+#ifndef LRP_TILE_MINWAVES_FRAMES
+#define LRP_TILE_MINWAVES_FRAMES 4 // the frame-loop instantiations keep <= 128 VGPRs: they are bound by memory and need the wavefronts
+#endif
+template <int OutLens, int InMode, int Interp, int CH, bool Frames = false>
+__global__ __launch_bounds__(kT2Threads, Frames ? LRP_TILE_MINWAVES_FRAMES : LRP_TILE_MINWAVES) void reproject_tile_kernel(const KParams Pk) {
   constexpr bool Loop = (InMode == kInEquirectLoop);
-  const KParams P = batch_frame(Pk);
+  const int frames_per_wave = Frames ? (Pk.frames_per_wave > 0 ? Pk.frames_per_wave : 1) : 1;
+  const int frame0 = Pk.batch_n > 0 ? (int)blockIdx.y * frames_per_wave : 0;
+  const int n_frames = (Frames && Pk.batch_n > 0) ? min(frames_per_wave, Pk.batch_n - frame0) : 1;
+  KParams P = Pk; // src / dst: the frame being rendered
+  if (Pk.batch_n > 0) {
+    P.src = Pk.batch_src[frame0];
+    P.dst = Pk.batch_dst[frame0];
+  }
 
   int tx, ty;
   if (!xcd_tile(P.tiles_x, P.tiles_y, tx, ty)) return; // whole workgroup
@@ -900,7 +913,35 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
   const int y_first = P.y_offset + (ty * kT2Waves + wave) * kT2Rows; // wave-uniform
   // Lanes / rows beyond the image recompute the last valid pixel and never store
   // (all 64 lanes stay active for the wave-wide votes).
-  const SrcView src = source_view<Interp, CH>(P);
+  SrcView src = source_view<Interp, CH>(P);
+  // N pixels per lane: coordinates from coords(p, sx, sy), results to finish(p, sample) — for one frame straight through
+  // sample_pixels, for several frames with the coordinates held in registers between the frames.
+  auto render = [&](auto n_tag, auto coords, auto finish) {
+    constexpr int N = decltype(n_tag)::value;
+    if constexpr (!Frames) {
+      sample_pixels<Interp, Loop, CH, N>(P, src, coords, finish);
+    } else {
+      float sxs[N], sys[N];
+#pragma unroll
+      for (int p = 0; p < N; ++p) {
+        coords(p, sxs[p], sys[p]);
+        __builtin_amdgcn_sched_barrier(0); // one pixel's coordinate math after the other (interleaved they need 200 registers)
+      }
+#pragma unroll 1
+      for (int f = 0; f < n_frames; ++f) {
+        P.src = Pk.batch_src[frame0 + f];
+        P.dst = Pk.batch_dst[frame0 + f];
+        src = source_view<Interp, CH>(P);
+        sample_pixels<Interp, Loop, CH, N>(
+            P, src,
+            [&](int p, float &sx, float &sy) {
+              sx = sxs[p];
+              sy = sys[p];
+            },
+            finish);
+      }
+    }
+  };
   if (P.quad == 2) {
     // Mirrored rays (equidistant target, num_samples == 1, any rotation): the ray through the
     // OUTPUT lens — a square root, sincosf and three divides per pixel that no table can hold,
@@ -937,6 +978,8 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
                                  (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)(mx ? P.out_w - x0 - kT2W : x0),
                                  (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
       };
+      // (one frame per wavefront: this path is bound by memory, and 8-16 pixels' coordinates in registers cost it occupancy:
+      // equirect -> fisheye bilinear 124 -> 125-160 us with the frame loop)
       sample_pixels<Interp, Loop, CH, 4 * kT2Rows>(P, src, coords, finish);
     }
     return;
@@ -986,7 +1029,7 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
                                (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)(mx ? P.out_w - x0 - kT2W : x0),
                                (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
     };
-    sample_pixels<Interp, Loop, CH, 4 * kT2Rows>(P, src, coords, finish);
+    sample_pixels<Interp, Loop, CH, 4 * kT2Rows>(P, src, coords, finish); // (likewise one frame per wavefront)
     return;
   }
   const int xe = x < P.out_w ? x : P.out_w - 1;
@@ -1007,9 +1050,10 @@ __global__ __launch_bounds__(kT2Threads, LRP_TILE_MINWAVES) void reproject_tile_
       store_tile_row<CH, true>(P, run_lds, row_inside && x0 + kT2W <= P.out_w, row_inside && x < P.out_w, lane, row_first,
                                row_first + (uint32_t)lane, a);
     };
-    sample_pixels<Interp, Loop, CH, kT2Rows>(P, src, coords, finish);
+    render(std::integral_constant<int, kT2Rows>{}, coords, finish);
     return;
   }
+  // (super-sampled pixels and the tile kernel's bicubic: one frame per wavefront; the host launches them that way)
 
   Px<CH> acc[kT2Rows];
 #pragma unroll
@@ -1954,18 +1998,18 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
 
 using TileKernelFn = void (*)(const KParams);
 
-template <int Interp, int CH> struct TileKernelTable {
+template <int Interp, int CH, bool Frames> struct TileKernelTable {
   static TileKernelFn get(int out_idx, int in_mode) {
     static const TileKernelFn table[3][4] = {
-        {reproject_tile_kernel<kRect, kInRect, Interp, CH>, reproject_tile_kernel<kRect, kInEquidistant, Interp, CH>,
-         reproject_tile_kernel<kRect, kInEquirect, Interp, CH>, reproject_tile_kernel<kRect, kInEquirectLoop, Interp, CH>},
-        {reproject_tile_kernel<kEquidistant, kInRect, Interp, CH>,
-         reproject_tile_kernel<kEquidistant, kInEquidistant, Interp, CH>,
-         reproject_tile_kernel<kEquidistant, kInEquirect, Interp, CH>,
-         reproject_tile_kernel<kEquidistant, kInEquirectLoop, Interp, CH>},
-        {reproject_tile_kernel<kEquirect, kInRect, Interp, CH>, reproject_tile_kernel<kEquirect, kInEquidistant, Interp, CH>,
-         reproject_tile_kernel<kEquirect, kInEquirect, Interp, CH>,
-         reproject_tile_kernel<kEquirect, kInEquirectLoop, Interp, CH>}};
+        {reproject_tile_kernel<kRect, kInRect, Interp, CH, Frames>, reproject_tile_kernel<kRect, kInEquidistant, Interp, CH, Frames>,
+         reproject_tile_kernel<kRect, kInEquirect, Interp, CH, Frames>, reproject_tile_kernel<kRect, kInEquirectLoop, Interp, CH, Frames>},
+        {reproject_tile_kernel<kEquidistant, kInRect, Interp, CH, Frames>,
+         reproject_tile_kernel<kEquidistant, kInEquidistant, Interp, CH, Frames>,
+         reproject_tile_kernel<kEquidistant, kInEquirect, Interp, CH, Frames>,
+         reproject_tile_kernel<kEquidistant, kInEquirectLoop, Interp, CH, Frames>},
+        {reproject_tile_kernel<kEquirect, kInRect, Interp, CH, Frames>, reproject_tile_kernel<kEquirect, kInEquidistant, Interp, CH, Frames>,
+         reproject_tile_kernel<kEquirect, kInEquirect, Interp, CH, Frames>,
+         reproject_tile_kernel<kEquirect, kInEquirectLoop, Interp, CH, Frames>}};
     return table[out_idx][in_mode];
   }
 };
@@ -1983,10 +2027,32 @@ template <int Interp> hipError_t launch_tile_interp(KParams P, int out_idx, int 
   }
   const int n_tiles = P.tiles_x * P.tiles_y;
   if (n_tiles <= 0) return hipSuccess;
-  const TileKernelFn fn = P.channels == 4   ? TileKernelTable<Interp, 4>::get(out_idx, in_mode)
-                          : P.channels == 3 ? TileKernelTable<Interp, 3>::get(out_idx, in_mode)
-                                            : TileKernelTable<Interp, 5>::get(out_idx, in_mode);
-  hipLaunchKernelGGL(fn, dim3((unsigned)(kXcds * xcd_rows(P.tiles_y) * P.tiles_x), (unsigned)(P.batch_n > 0 ? P.batch_n : 1)), dim3(kT2Threads), 0, stream, P);
+  // Frames per wavefront of a batched launch (nearest / bilinear, one sample per pixel): as many as leave at least two
+  // rounds of workgroups on the chip.
+  int groups = P.batch_n > 0 ? P.batch_n : 1;
+  P.frames_per_wave = 1;
+  if (Interp != 2 && P.num_samples == 1 && P.batch_n > 1 && P.quad == 0) { // (the plain path: any rotation; the mirrored paths are bound by memory)
+    const long long units = (long long)n_tiles * P.batch_n;
+    int F = (int)std::min<long long>(P.batch_n, std::max<long long>(1, units / 4096));
+    if (out_idx == 2 && in_mode == kInRect) F = 1; // (see the window kernel: uneven tiles)
+    if (const char *e = std::getenv("LRP_BATCH_FRAMES")) F = std::max(1, std::min(P.batch_n, std::atoi(e))); // A/B runs
+    P.frames_per_wave = F;
+    groups = (P.batch_n + F - 1) / F;
+  }
+  TileKernelFn fn;
+  if (P.frames_per_wave > 1) {
+    if constexpr (Interp != 2)
+      fn = P.channels == 4   ? TileKernelTable<Interp, 4, true>::get(out_idx, in_mode)
+           : P.channels == 3 ? TileKernelTable<Interp, 3, true>::get(out_idx, in_mode)
+                             : TileKernelTable<Interp, 5, true>::get(out_idx, in_mode);
+    else
+      return hipErrorInvalidValue;
+  } else {
+    fn = P.channels == 4   ? TileKernelTable<Interp, 4, false>::get(out_idx, in_mode)
+         : P.channels == 3 ? TileKernelTable<Interp, 3, false>::get(out_idx, in_mode)
+                           : TileKernelTable<Interp, 5, false>::get(out_idx, in_mode);
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)(kXcds * xcd_rows(P.tiles_y) * P.tiles_x), (unsigned)groups), dim3(kT2Threads), 0, stream, P);
   return hipGetLastError();
 }
 

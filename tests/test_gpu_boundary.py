@@ -176,6 +176,41 @@ def test_batched_launch_with_several_frames_per_wavefront(lrp, torch_cuda, frame
         assert bool(torch.equal(single[i].view(torch.int32), batched[i].view(torch.int32))), f"frame {i} differs"
 
 
+@pytest.mark.parametrize("frames", ["2", "5", "16"])
+@pytest.mark.parametrize("interp", [0, 1])
+@pytest.mark.parametrize("channels,in_name,out_name,deg", [(4, "eqr_full", "rect", (30.0, -15.0, 5.0)), (3, "eqd180", "rect", (0.0, 40.0, 0.0)),
+                                                          (5, "eqr_part", "eqr_full", (10.0, 5.0, 20.0)), (4, "rect", "eqd120", (30.0, -15.0, 5.0))])
+def test_batched_nearest_and_bilinear_with_several_frames_per_wavefront(lrp, torch_cuda, frames, interp, channels, in_name, out_name, deg):
+    """Tile kernels, rotated mappings: the source coordinates of a wavefront's pixels stay in registers while it walks
+    the frames of its group.  21 frames against 21 single calls."""
+    import os
+
+    torch = torch_cuda
+    in_w, in_h, out_w, out_h, n = 300, 180, 201, 137, 21
+    lin, lout = cases.lenses(lrp, in_w, in_h)[in_name], cases.lenses(lrp, out_w, out_h)[out_name]
+    rot = cases.rotation(lrp, deg)
+    srcs = [torch.empty((in_h, in_w, channels), dtype=torch.float32, device="cuda") for _ in range(n)]
+    for i, s in enumerate(srcs):
+        lrp.synth_fill(s, in_w, in_h, channels, 0xF4A40000 + i, 4 if channels == 5 else -1)
+    single = [torch.full((out_h, out_w, channels), -1.0, dtype=torch.float32, device="cuda") for _ in range(n)]
+    batched = [torch.full((out_h, out_w, channels), -2.0, dtype=torch.float32, device="cuda") for _ in range(n)]
+    for s, d in zip(srcs, single):
+        lrp.reproject(lrp.Image(lin, in_w, in_h, channels, s), lrp.Image(lout, out_w, out_h, channels, d), 1, interp, rot)
+    prev = os.environ.get("LRP_BATCH_FRAMES")
+    os.environ["LRP_BATCH_FRAMES"] = frames
+    try:
+        lrp.reproject_batch([lrp.Image(lin, in_w, in_h, channels, s) for s in srcs],
+                            [lrp.Image(lout, out_w, out_h, channels, d) for d in batched], 1, interp, rot)
+        torch.cuda.synchronize()
+    finally:
+        if prev is None:
+            del os.environ["LRP_BATCH_FRAMES"]
+        else:
+            os.environ["LRP_BATCH_FRAMES"] = prev
+    for i in range(n):
+        assert bool(torch.equal(single[i].view(torch.int32), batched[i].view(torch.int32))), f"frame {i} differs"
+
+
 def test_batched_launch_rejects_mixed_geometries(lrp, torch_cuda):
     torch = torch_cuda
     a = torch.zeros((64, 64, 4), dtype=torch.float32, device="cuda")
