@@ -1629,11 +1629,10 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   };
   auto issue = [&](const float *frame, const WinBlock &b) { // the window `b` of the source frame `frame`
     if (b.staged()) {
-      // LDS-DMA, one window row per instruction, lanes beyond the width masked off
+      // LDS-DMA, one window row per instruction, lanes beyond the width masked off.  The address is a wave-uniform row
+      // base in an SGPR pair (advanced by scalar adds) plus one per-lane byte offset that is the same for every row and
+      // every frame: no vector arithmetic per row.
       float4 *const win = win0;
-      const float4 *gp = reinterpret_cast<const float4 *>(frame) + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane));
-      const float *gp3 = frame + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane)) * 3u;
-      const float *gp5 = frame + ((uint32_t)b.y_lo * (uint32_t)in_w + (uint32_t)(b.x_lo + lane)) * 5u;
       // Issued as inline assembly: the compiler's wait-count insertion then does not know
       // that LDS is being written and puts no vmcnt(0) in front of later LDS reads (of the
       // coefficient planes, which the DMA does not touch); the one wait that IS needed sits
@@ -1643,31 +1642,35 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       if (lane < b.bw) {
         uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win + (uint32_t)b.org() * 16u;
         const uint32_t lds_step = (uint32_t)(b.spitch() * 16); // dwordx3 too writes one 16-byte slot per lane
+        const uint32_t lane_bytes = (uint32_t)(b.x_lo + lane) * (4u * CH);
+        const char *row = reinterpret_cast<const char *>(frame) + (size_t)((uint32_t)b.y_lo * src.row_bytes); // wave-uniform
         for (int r = 0; r < b.bh; ++r) {
           if constexpr (CH == 4)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                          :
-                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(gp + (size_t)r * in_w)
+                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(row)
                          : "memory", "m0");
           else if constexpr (CH == 5) {
             // colour into the 16-byte slots of the row, depth into the row of the float plane behind the colour plane
+            // (an instruction offset would move the LDS address as well as the global one: the fifth float's 16 bytes
+            // go into the scalar base)
             const uint32_t lds_d = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win +
                                    (uint32_t)(b.pitch * b.bh) * 16u + (uint32_t)(r * b.pitch) * 4u;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                          :
-                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(gp5 + (size_t)r * in_w * 5)
+                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(row)
                          : "memory", "m0");
-            // (an instruction offset would move the LDS address as well as the global one: the fifth float is addressed in the VGPR)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
                          :
-                         : "s"(__builtin_amdgcn_readfirstlane(lds_d)), "v"(gp5 + (size_t)r * in_w * 5 + 4)
+                         : "s"(__builtin_amdgcn_readfirstlane(lds_d)), "v"(lane_bytes), "s"(row + 16)
                          : "memory", "m0");
           } else
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, off"
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %2"
                          :
-                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(gp3 + (size_t)r * in_w * 3)
+                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(row)
                          : "memory", "m0");
           lds += lds_step;
+          row += src.row_bytes;
         }
       }
     }
