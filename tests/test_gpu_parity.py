@@ -204,6 +204,50 @@ def test_multi_output_cubemap_faces(lrp, oracle, torch_cuda):
         cases.assert_same_bits(t.cpu().numpy(), want, f"face {d}")
 
 
+def test_multi_output_stays_ordered_on_the_callers_stream(lrp, oracle, torch_cuda):
+    """lrp_reproject_multi_device deals its launches over an internal side stream (fork / join by events): work queued on
+    the caller's stream before the call (the copy that fills the source) must be seen by every face, work queued after it
+    (the copy that takes the faces away, the next source) must see every face; repeated so that a missing edge shows.
+    Captured into a hipGraph the call keeps to the one stream and replays to the same bits."""
+    torch = torch_cuda
+    in_w, in_h, face = 512, 256, 160
+    lin = cases.lenses(lrp, in_w, in_h)["eqr_full"]
+    lout = lrp.LensInfo.rectilinear(18.0, 36.0, face, face)
+    degs = [(0, 0, 0), (90, 0, 0), (180, 0, 0), (270, 0, 0), (0, 90, 0), (0, -90, 0)]
+    rots = np.stack([cases.rotation(lrp, d) for d in degs])
+    srcs = [cases.hash_noise(in_h, in_w, 3, seed=40 + k) for k in range(4)]
+    pinned = [torch.from_numpy(s).pin_memory() for s in srcs]
+    wants = [[oracle.reproject(lin, s, lout, face, face, 1, BICUBIC, r) for r in rots] for s in srcs]
+    d_in = torch.zeros((in_h, in_w, 3), dtype=torch.float32, device="cuda")
+    d_outs = [torch.zeros((face, face, 3), dtype=torch.float32, device="cuda") for _ in degs]
+    im_in, im_outs = lrp.Image(lin, in_w, in_h, 3, d_in), [lrp.Image(lout, face, face, 3, t) for t in d_outs]
+    lrp.reproject_multi(im_in, im_outs, 1, BICUBIC, rots)  # tables
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    taken = [[torch.empty((face, face, 3), dtype=torch.float32).pin_memory() for _ in degs] for _ in range(12)]
+    with torch.cuda.stream(stream):
+        for it in range(12):
+            d_in.copy_(pinned[it % 4], non_blocking=True)
+            lrp.reproject_multi(im_in, im_outs, 1, BICUBIC, rots)
+            for t, h in zip(d_outs, taken[it]):
+                h.copy_(t, non_blocking=True)
+    stream.synchronize()
+    for it in range(12):
+        for k, d in enumerate(degs):
+            cases.assert_same_bits(taken[it][k].numpy(), wants[it % 4][k], f"round {it} face {d}")
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        lrp.reproject_multi(im_in, im_outs, 1, BICUBIC, rots)
+    for k in (2, 1):
+        d_in.copy_(pinned[k])
+        for t in d_outs:
+            t.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for j, d in enumerate(degs):
+            cases.assert_same_bits(d_outs[j].cpu().numpy(), wants[k][j], f"graph replay source {k} face {d}")
+
+
 def test_unsupported_dispatch_matches_reference_messages(lrp, torch_cuda):
     torch = torch_cuda
     t = torch.zeros((4, 4, 4), dtype=torch.float32, device="cuda")
