@@ -197,6 +197,15 @@ bool mirror_modes_enabled() {
   }();
   return on;
 }
+// LRP_WIN_EDGE=0: blocks of the window kernel beyond one side of the source gather per pixel instead of staging the one
+// source row / column they read (A/B checks).
+bool win_edge_enabled() {
+  static const bool on = [] {
+    const char *v = std::getenv("LRP_WIN_EDGE");
+    return !(v && std::strcmp(v, "0") == 0);
+  }();
+  return on;
+}
 // LRP_XSEP=0 in the environment switches the column-separable source x tables off (A/B checks).
 bool xsep_enabled() {
   static const bool on = [] {
@@ -275,6 +284,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
         out->lens.type == LRP_FISHEYE_EQUIDISTANT)
       P.quad = 2;
     P.win_coef = kernel_choice() == 2;
+    P.win_edge = (kernel_choice() == 2 && win_edge_enabled()) ? 1 : 0;
     // Mirror mode of the window kernel (lrp_kernel_v2.h QMode): both axes without a rotation; rows only for a pan,
     // columns only for a pitch into a rectilinear target.  Signed zeros count as zeros in the matrix tests.
     P.win_mode = P.quad == 1 ? 1 : 0;

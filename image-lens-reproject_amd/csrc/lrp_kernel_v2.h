@@ -1162,12 +1162,15 @@ __device__ __forceinline__ void win_lane_pixel(int lane, int &prow, int &pcol) {
 #ifndef LRP_WIN_CORNER
 #define LRP_WIN_CORNER 1 // blocks wholly beyond one corner of the source: one evaluation per block (0: per pixel)
 #endif
+#ifndef LRP_WIN_EDGE
+#define LRP_WIN_EDGE 1 // blocks wholly beyond one SIDE of the source (and inside it along the other axis): one source row / column staged (0: per-pixel gathers)
+#endif
 #ifndef LRP_WIN_STRIP_PLAN
 #define LRP_WIN_STRIP_PLAN 1 // mirrored strips: one reduction for the windows of all four mirror blocks (0: one per block)
 #endif
 
 #if defined(LRP_TIER_STATS) // diagnostic builds (tools/ablate.sh): blocks per tier (coefficients, raw taps, direct)
-__device__ unsigned g_tier_stats[4];
+__device__ unsigned g_tier_stats[8]; // coefficient, raw, direct, corner, beyond a row, beyond a column
 #endif
 
 // Source coordinates and window of one 16 x 16 block (4 pixels per lane).  Fat: the per-half plane offsets are
@@ -1190,7 +1193,13 @@ template <bool Fat> struct WinBlockT {
   __device__ __forceinline__ int staged() const { return tier & 1; }
   __device__ __forceinline__ int coef() const { return tier & 2; }
   __device__ __forceinline__ int whole() const { return tier & 4; }
-  __device__ __forceinline__ int corner() const { return tier >> 3; }
+  __device__ __forceinline__ int corner() const { return (tier >> 3) & 7; }
+  // bits 6-8 edge (0, or 1 + (beyond the high side) + 2 (the side is in x)): every pixel of the block lies beyond the same
+  // SIDE of the source along one axis and inside it along the other.  Beyond in y (1, 2): the four tap rows clamp to the
+  // first / last source row and the vertical weight to 0 / 1, the window is bw texels of that row (bh = 1, pitch = bw)
+  // followed by a plane of their vertical cubics.  Beyond in x (3, 4): the four tap columns clamp to the first / last
+  // source column and the horizontal weight to 0 / 1, the window is bh texels of that column (bw = 1, pitch = 1).
+  __device__ __forceinline__ int edge() const { return tier >> 6; }
   // coefficient tier: per half of the block (passes 0-1, 2-3) the first int(sy) and the number of distinct
   // int(sy) rows; a coefficient row has the window's pitch
   int iy0[2], iyn[2], c_plane, c_base; // plane size and first slot of plane 0 (behind the raw window + a margin)
@@ -1279,6 +1288,10 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   P.src = frame_src(0);
   P.dst = frame_dst(0);
   constexpr bool Loop = (InMode == kInEquirectLoop);
+  // Edge blocks (WinBlockT::edge) are compiled for the rectilinear source only: a narrow view inside a wider target is
+  // where whole blocks lie beyond one side of the source; in the other instantiations the extra code costs 2-3 % (measured:
+  // fisheye -> rectilinear 100 -> 102.5 us, fisheye -> fisheye 141.5 -> 146) and such blocks take the per-pixel gathers.
+  constexpr bool kEdge = LRP_WIN_EDGE != 0 && InMode == kInRect;
   constexpr int kPlanes = 3;
   __shared__ float4 s_win[kWinWaves][kWinCap];
 
@@ -1403,11 +1416,15 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   auto raw_slots = [](const WinBlock &b) { return CH == 5 ? b.pitch * b.bh + ((b.pitch * b.bh + 3) >> 2) : b.pitch * b.bh; };
   // Window of a block from the wave-wide extremes of its source coordinates (float bits, see below):
   // x range of the block, y ranges of its two halves.
-  auto plan_window = [&](WinBlock &b, int w_lo_x, int w_hi_x, int w_lo_ya, int w_hi_ya, int w_lo_yb, int w_hi_yb) {
+  // exact_x / exact_y: int(s + k) == int(s) + k, k = -1 .. 2, holds for every pixel's x / y (the exactness vote of coords())
+  auto plan_window = [&](WinBlock &b, int w_lo_x, int w_hi_x, int w_lo_ya, int w_hi_ya, int w_lo_yb, int w_hi_yb, bool exact_x,
+                         bool exact_y) {
     const int w_lo_y = min(w_lo_ya, w_lo_yb), w_hi_y = max(w_hi_ya, w_hi_yb);
     const int one = (int)f2u(1.0f);
     // 1 <= s < extent - 2 for every pixel: every tap index is int(s) - 1 .. int(s) + 2, unclamped
-    if (w_lo_x >= one && w_lo_y >= one && w_hi_x < (int)f2u(src.x_hi) && w_hi_y < (int)f2u(src.y_hi)) {
+    const bool in_x = exact_x && w_lo_x >= one && w_hi_x < (int)f2u(src.x_hi);
+    const bool in_y = exact_y && w_lo_y >= one && w_hi_y < (int)f2u(src.y_hi);
+    if (in_x && in_y) {
       // float -> int of the wave-uniform extremes (VALU has the converter)
       const int x_first = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_lo_x));
       const int x_last = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_hi_x));
@@ -1458,8 +1475,34 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
         if (lo >= (int)f2u((float)(extent + 1)) && hi < (int)f2u(2147483648.0f)) return 2;
         return 0;
       };
-      const int sx_side = side(w_lo_x, w_hi_x, P.in_w), sy_side = side(w_lo_y, w_hi_y, P.in_h);
+      // (the extremes are wave-uniform values in vector registers; what is derived from them and kept is made scalar)
+      const int sx_side = __builtin_amdgcn_readfirstlane(side(w_lo_x, w_hi_x, P.in_w));
+      const int sy_side = __builtin_amdgcn_readfirstlane(side(w_lo_y, w_hi_y, P.in_h));
       if (LRP_WIN_CORNER != 0 && sx_side != 0 && sy_side != 0) b.tier = (1 + (sx_side - 1) + 2 * (sy_side - 1)) << 3;
+      // ... beyond one SIDE only (a rectilinear view inside a panorama: the rows above and below the view and the
+      // columns left and right of it, another 37 % of the blocks): the same reasoning along one axis — all four tap
+      // rows (columns) are the first or the last source row (column), the weight of that axis is 0 or 1 — and the
+      // unclamped case along the other.  The block then reads ONE source row or column.
+      else if (kEdge && P.win_edge != 0 && sy_side != 0 && in_x) {
+        const int x_first = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_lo_x));
+        const int x_last = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_hi_x));
+        b.x_lo = x_first - 1;
+        b.bw = x_last + 2 - b.x_lo + 1;
+        b.y_lo = sy_side == 2 ? P.in_h - 1 : 0;
+        b.bh = 1;
+        b.pitch = b.bw;
+        b.c_base = raw_slots(b); // the plane of vertical cubics, one per window texel (RGBAZ: + a float plane behind it)
+        if (b.c_base + raw_slots(b) <= kWinCap) b.tier = 1 | ((1 + (sy_side - 1)) << 6);
+      } else if (kEdge && P.win_edge != 0 && sx_side != 0 && in_y) {
+        const int y_first = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_lo_y));
+        const int y_last = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_hi_y));
+        b.y_lo = y_first - 1;
+        b.bh = y_last + 2 - b.y_lo + 1;
+        b.x_lo = sx_side == 2 ? P.in_w - 1 : 0;
+        b.bw = 1;
+        b.pitch = 1;
+        if (raw_slots(b) <= kWinCap) b.tier = 1 | ((3 + (sx_side - 1)) << 6);
+      }
     }
   };
   auto clear_block = [](WinBlock &b) {
@@ -1595,7 +1638,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       if (((plan_exact >> mx) & (plan_exact >> (2 + my)) & 1u) != 0) {
         plan_window(b, __builtin_amdgcn_readlane(plan, 2 * mx), __builtin_amdgcn_readlane(plan, 2 * mx + 1),
                     __builtin_amdgcn_readlane(plan, 4 + 4 * my), __builtin_amdgcn_readlane(plan, 5 + 4 * my),
-                    __builtin_amdgcn_readlane(plan, 6 + 4 * my), __builtin_amdgcn_readlane(plan, 7 + 4 * my));
+                    __builtin_amdgcn_readlane(plan, 6 + 4 * my), __builtin_amdgcn_readlane(plan, 7 + 4 * my), true, true);
         return;
       }
     }
@@ -1612,16 +1655,33 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       // (shared rays: one pixel's rotation + source lens after the other — interleaved they do not fit the registers)
       if constexpr (kSharedRays) __builtin_amdgcn_sched_barrier(0);
     }
-    bool all_exact = wave_all((e.exact_x & e.exact_y) != 0);
-    if (!all_exact) { // the precise test, for the stripe of blocks next to a power-of-two coordinate
-      int ok = 1;
+    bool all_exact_x, all_exact_y;
+    if constexpr (kEdge) { // per axis: a block beyond one side of the source has no exact taps along that axis and needs none
+      all_exact_x = wave_all(e.exact_x != 0);
+      all_exact_y = wave_all(e.exact_y != 0);
+      if (!(all_exact_x && all_exact_y)) { // the precise test, for the stripe of blocks next to a power-of-two coordinate
+        int ok_x = 1, ok_y = 1;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) ok &= taps_consecutive(b.sx[k], 2.0f) & taps_consecutive(b.sy[k], 2.0f);
-      all_exact = wave_all(ok != 0);
+        for (int k = 0; k < 4; ++k) {
+          ok_x &= taps_consecutive(b.sx[k], 2.0f);
+          ok_y &= taps_consecutive(b.sy[k], 2.0f);
+        }
+        all_exact_x = wave_all(ok_x != 0);
+        all_exact_y = wave_all(ok_y != 0);
+      }
+    } else {
+      bool all_exact = wave_all((e.exact_x & e.exact_y) != 0);
+      if (!all_exact) { // the precise test, for the stripe of blocks next to a power-of-two coordinate
+        int ok = 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ok &= taps_consecutive(b.sx[k], 2.0f) & taps_consecutive(b.sy[k], 2.0f);
+        all_exact = wave_all(ok != 0);
+      }
+      all_exact_x = all_exact_y = all_exact;
     }
-    if (all_exact) {
+    if (kEdge ? true : (all_exact_x && all_exact_y)) {
       wave_box(e.lo_x, e.hi_x, e.lo_y[0], e.hi_y[0], e.lo_y[1], e.hi_y[1]);
-      plan_window(b, e.lo_x, e.hi_x, e.lo_y[0], e.hi_y[0], e.lo_y[1], e.hi_y[1]);
+      plan_window(b, e.lo_x, e.hi_x, e.lo_y[0], e.hi_y[0], e.lo_y[1], e.hi_y[1], all_exact_x, all_exact_y);
     }
   };
   // the one value of a corner block: sample_bicubic with all 16 taps on the corner texel (sample_direct's
@@ -1643,7 +1703,42 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
     }
   };
   auto issue = [&](const float *frame, const WinBlock &b) { // the window `b` of the source frame `frame`
-    if (b.staged()) {
+    if (kEdge && b.edge() != 0) {
+      // One source row (texels x_lo .. x_lo + bw - 1 of row y_lo) or one source column (rows y_lo .. y_lo + bh - 1 of
+      // column x_lo) into consecutive slots: 64 texels per instruction, the lane's byte offset along the row / column
+      // in a VGPR, the first texel's address in an SGPR pair.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const bool along_y = b.edge() >= 3;
+      const int n = along_y ? b.bh : b.bw;
+      const uint32_t step = along_y ? src.row_bytes : 4u * CH;
+      const uint32_t first_row = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)b.y_lo * src.row_bytes));
+      const uint32_t first_col = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)b.x_lo * (4u * CH)));
+      const char *first = reinterpret_cast<const char *>(frame) + ((size_t)first_row + (size_t)first_col);
+      const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win0;
+      for (int c0 = 0; c0 < n; c0 += 64) {
+        if (c0 + lane < n) {
+          const uint32_t lane_bytes = (uint32_t)(c0 + lane) * step;
+          const uint32_t lds = lds0 + (uint32_t)c0 * 16u;
+          if constexpr (CH == 3)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %2"
+                         :
+                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(first)
+                         : "memory", "m0");
+          else
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :
+                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(first)
+                         : "memory", "m0");
+          if constexpr (CH == 5) { // depth: the float plane behind the n colour slots
+            const uint32_t lds_d = lds0 + (uint32_t)n * 16u + (uint32_t)c0 * 4u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
+                         :
+                         : "s"(__builtin_amdgcn_readfirstlane(lds_d)), "v"(lane_bytes), "s"(first + 16)
+                         : "memory", "m0");
+          }
+        }
+      }
+    } else if (b.staged()) {
       // LDS-DMA, one window row per instruction, lanes beyond the width masked off.  The address is a wave-uniform row
       // base in an SGPR pair (advanced by scalar adds) plus one per-lane byte offset that is the same for every row and
       // every frame: no vector arithmetic per row.
@@ -1658,7 +1753,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
         uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win + (uint32_t)b.org() * 16u;
         const uint32_t lds_step = (uint32_t)(b.spitch() * 16); // dwordx3 too writes one 16-byte slot per lane
         const uint32_t lane_bytes = (uint32_t)(b.x_lo + lane) * (4u * CH);
-        const char *row = reinterpret_cast<const char *>(frame) + (size_t)((uint32_t)b.y_lo * src.row_bytes); // wave-uniform
+        const char *row = reinterpret_cast<const char *>(frame) + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)b.y_lo * src.row_bytes)); // wave-uniform
         for (int r = 0; r < b.bh; ++r) {
           if constexpr (CH == 4)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
@@ -1739,6 +1834,27 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
     }
   };
 
+  // Blocks beyond the first / last source row: k = cubic(t, t, t, t, fy) of every window texel t, fy = 0 / 1 the clamped
+  // weight (src/reproject.cpp:131), a lane per texel, into the plane behind the row.  Evaluated, not assumed to be t:
+  // with a non-finite texel it is not.
+  auto edge_plane = [&](const WinBlock &b) {
+    const float fyc = b.edge() == 2 ? 1.0f : 0.0f, hfyc = 0.5f * fyc;
+    float4 *const plane = win0 + b.c_base;
+    const float *const raw_d = reinterpret_cast<const float *>(win0 + b.bw);
+    float *const plane_d = reinterpret_cast<float *>(plane + b.bw);
+#pragma unroll 1
+    for (int i0 = 0; i0 < b.bw; i0 += 64) {
+      const int i = min(i0 + lane, b.bw - 1);
+      const Rgba t = as_rgba(win0[i]);
+      const Rgba k = cubic4(t, t, t, t, fyc, hfyc);
+      plane[i] = float4{k.lo.x, k.lo.y, k.hi.x, k.hi.y};
+      if constexpr (CH == 5) {
+        const float dz = raw_d[i];
+        plane_d[i] = catmull_rom(dz, dz, dz, dz, fyc, hfyc);
+      }
+    }
+  };
+
   // vmcnt retires in order, stores included: a store issued BEFORE the DMA of the next window
   // would have to be acknowledged by memory before that window counts as landed.  So the
   // DMA of window g+1 is issued inside the last pass of block g, right behind that pass's
@@ -1762,7 +1878,9 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   auto next_window = [&]() {
     // while this block's coefficient planes are still being read the next raw window must stay in front of them
     // (the same block's window in the next frame always does: planes sit behind the raw window)
-    dma_early = has_next() && (!(kWinCoef && cur.coef()) || f_loop + 1 < n_frames || raw_slots(nxt) <= cur.c_base);
+    // (likewise the plane of vertical cubics of a block beyond the first / last source row: edge() 1, 2)
+    const bool planes_live = (kWinCoef && cur.coef()) || (kEdge && cur.edge() != 0 && cur.edge() < 3);
+    dma_early = has_next() && (!planes_live || f_loop + 1 < n_frames || raw_slots(nxt) <= cur.c_base);
     if (dma_early) issue_next();
   };
   // The result of pass k of block g: num_samples == 1, (0.0f + s) * normalize (src/reproject.cpp:334-341), store.
@@ -1854,7 +1972,11 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
     const int tier = cur.tier;
 #endif
     const bool t_coef = kWinCoef && (tier & 2) != 0, t_staged = (tier & 1) != 0, t_whole = (tier & 4) != 0;
-    if ((tier >> 3) != 0) {
+    const int t_edge = kEdge ? (tier >> 6) : 0; // 1, 2: beyond the first / last source row; 3, 4: column
+#if defined(LRP_TIER_STATS)
+    if (lane == 0) atomicAdd(&g_tier_stats[((tier >> 3) & 7) != 0 ? 3 : (tier >> 6) != 0 ? ((tier >> 6) < 3 ? 4 : 5) : (kWinCoef && (tier & 2)) ? 0 : (tier & 1) ? 1 : 2], 1u);
+#endif
+    if (((tier >> 3) & 7) != 0) {
       // every pixel of this block is one value: no taps, no per-pixel arithmetic — four stores.  The next block's
       // window is requested in front of the last store, as in the last pass of an ordinary block.
       const Rgba cs = corner_value(cur);
@@ -1868,9 +1990,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       if (last_frame) cur = nxt;
       continue;
     }
-#if defined(LRP_TIER_STATS)
-    if (lane == 0) atomicAdd(&g_tier_stats[(kWinCoef && cur.coef()) ? 0 : (cur.staged() ? 1 : 2)], 1u);
-#endif
+    if (t_edge == 1 || t_edge == 2) edge_plane(cur);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #if !defined(LRP_SKIP_PLANES) // timing experiment (wrong results): the coefficient phase removed
@@ -1891,7 +2011,48 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
         // window plan, by construction)
         asm volatile("" : "+v"(psx), "+v"(psy));
         Rgba s;
-        if (t_coef) {
+        if (t_edge != 0) {
+          // sample_bicubic with one axis clamped (src/reproject.cpp:114-147): beyond the first / last source row the four
+          // taps of a column are one texel t and its vertical cubic k = cubic(t, t, t, t, 0 or 1) comes from the plane,
+          // leaving the horizontal cubic; beyond the first / last source column the four columns are one, their common
+          // vertical cubic K is evaluated once and the horizontal one is cubic(K, K, K, K, 0 or 1).
+          if (t_edge < 3) {
+            const float tx_ = __builtin_truncf(psx);
+            const float fx = psx - tx_, hfx = 0.5f * fx;
+            const int slot = (int)tx_ - 1 - cur.x_lo;
+            const float4 *kp = win + cur.c_base + slot;
+            const Rgba k0 = as_rgba(kp[0]), k1 = as_rgba(kp[1]), k2 = as_rgba(kp[2]), k3 = as_rgba(kp[3]);
+            float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (CH == 5) {
+              const float *kd = reinterpret_cast<const float *>(win + cur.c_base + cur.bw) + slot;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) d[j] = kd[j];
+            }
+            if (last_pass) next_window();
+            s = cubic4(k0, k1, k2, k3, fx, hfx);
+            if constexpr (CH == 5) s.e = catmull_rom(d[0], d[1], d[2], d[3], fx, hfx);
+          } else {
+            const float ty_ = __builtin_truncf(psy);
+            const float fy = psy - ty_, hfy = 0.5f * fy;
+            const float fxc = t_edge == 4 ? 1.0f : 0.0f, hfxc = 0.5f * fxc; // the clamped weight (:130)
+            const int slot = (int)ty_ - 1 - cur.y_lo;
+            const float4 *t = win + slot;
+            const Rgba t0 = as_rgba(t[0]), t1 = as_rgba(t[1]), t2 = as_rgba(t[2]), t3 = as_rgba(t[3]);
+            float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (CH == 5) {
+              const float *td = reinterpret_cast<const float *>(win + cur.bh) + slot;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) d[j] = td[j];
+            }
+            if (last_pass) next_window();
+            const Rgba kk = cubic4(t0, t1, t2, t3, fy, hfy);
+            s = cubic4(kk, kk, kk, kk, fxc, hfxc);
+            if constexpr (CH == 5) {
+              const float kd = catmull_rom(d[0], d[1], d[2], d[3], fy, hfy);
+              s.e = catmull_rom(kd, kd, kd, kd, fxc, hfxc);
+            }
+          }
+        } else if (t_coef) {
           const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
           const float fx = psx - tx_, fy = psy - ty_;
           const float hfx = 0.5f * fx, hfy = 0.5f * fy;

@@ -29,3 +29,11 @@ hipError_t launch_win_bicubic(const KParams &P, int out_idx, int in_mode, hipStr
   return table[P.channels - 3][P.win_mode](P, out_idx, in_mode, stream);
 }
 } // namespace lrp
+
+#if defined(LRP_TIER_STATS)
+extern "C" void lrp_debug_read_tiers_plain(unsigned out[8]) { // plain RGBA instantiations only
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lrp::g_tier_stats), sizeof(unsigned) * 8);
+  unsigned zero[8] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(lrp::g_tier_stats), zero, sizeof(zero));
+}
+#endif

@@ -8,9 +8,9 @@ hipError_t launch_win_bicubic_c4_m1(const KParams &P, int out_idx, int in_mode, 
 } // namespace lrp
 
 #if defined(LRP_TIER_STATS)
-extern "C" void lrp_debug_read_tiers(unsigned out[4]) { // mirrored RGBA instantiations only
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lrp::g_tier_stats), sizeof(unsigned) * 4);
-  unsigned zero[4] = {0, 0, 0, 0};
+extern "C" void lrp_debug_read_tiers(unsigned out[8]) { // mirrored RGBA instantiations only
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lrp::g_tier_stats), sizeof(unsigned) * 8);
+  unsigned zero[8] = {};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(lrp::g_tier_stats), zero, sizeof(zero));
 }
 #endif
