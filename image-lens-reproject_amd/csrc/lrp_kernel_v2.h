@@ -1162,6 +1162,9 @@ __device__ __forceinline__ void win_lane_pixel(int lane, int &prow, int &pcol) {
 #ifndef LRP_WIN_CORNER
 #define LRP_WIN_CORNER 1 // blocks wholly beyond one corner of the source: one evaluation per block (0: per pixel)
 #endif
+#ifndef LRP_OPAQUE_COL
+#define LRP_OPAQUE_COL 1 // plain blocks: the column terms are opaque to loop-invariant code motion (see coords())
+#endif
 #ifndef LRP_WIN_EDGE
 #define LRP_WIN_EDGE 1 // blocks wholly beyond one SIDE of the source (and inside it along the other axis): one source row / column staged (0: per-pixel gathers)
 #endif
@@ -1413,6 +1416,12 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   // stride) and, right behind it, depth (one float per texel, global_load_lds_dword from its fifth).
   // Everything written for RGBA then serves the colour channels unchanged; depth reads its 16 taps from
   // the float plane and runs the five cubics as scalar instructions.
+  // the thresholds of plan_window as float bits in scalar registers (an int -> float conversion is a vector instruction:
+  // left to the compiler its result stays in a vector register for the whole kernel, and spills)
+  const int x_hi_bits = __builtin_amdgcn_readfirstlane((int)f2u((float)(P.in_w - 2)));
+  const int y_hi_bits = __builtin_amdgcn_readfirstlane((int)f2u((float)(P.in_h - 2)));
+  const int beyond_x_bits = __builtin_amdgcn_readfirstlane((int)f2u((float)(P.in_w + 1)));
+  const int beyond_y_bits = __builtin_amdgcn_readfirstlane((int)f2u((float)(P.in_h + 1)));
   auto raw_slots = [](const WinBlock &b) { return CH == 5 ? b.pitch * b.bh + ((b.pitch * b.bh + 3) >> 2) : b.pitch * b.bh; };
   // Window of a block from the wave-wide extremes of its source coordinates (float bits, see below):
   // x range of the block, y ranges of its two halves.
@@ -1422,8 +1431,8 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
     const int w_lo_y = min(w_lo_ya, w_lo_yb), w_hi_y = max(w_hi_ya, w_hi_yb);
     const int one = (int)f2u(1.0f);
     // 1 <= s < extent - 2 for every pixel: every tap index is int(s) - 1 .. int(s) + 2, unclamped
-    const bool in_x = exact_x && w_lo_x >= one && w_hi_x < (int)f2u(src.x_hi);
-    const bool in_y = exact_y && w_lo_y >= one && w_hi_y < (int)f2u(src.y_hi);
+    const bool in_x = exact_x && w_lo_x >= one && w_hi_x < x_hi_bits;
+    const bool in_y = exact_y && w_lo_y >= one && w_hi_y < y_hi_bits;
     if (in_x && in_y) {
       // float -> int of the wave-uniform extremes (VALU has the converter)
       const int x_first = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_lo_x));
@@ -1470,14 +1479,14 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       // every pixel of the block is the same function of the same corner texel: evaluated once per block.
       // On the raw bits: negative floats order backwards as signed integers, -2.0 .. -inf is 0xC0000000 .. 0xFF800000
       // (a negative NaN lies above that range, a positive one above 2^31).
-      auto side = [](int lo, int hi, int extent) { // 0: not beyond one side; 1: beyond the low side; 2: beyond the high side
+      auto side = [](int lo, int hi, int beyond_bits) { // 0: not beyond one side; 1: beyond the low side; 2: beyond the high side
         if (lo >= (int)0xC0000000 && hi <= (int)0xFF800000) return 1;
-        if (lo >= (int)f2u((float)(extent + 1)) && hi < (int)f2u(2147483648.0f)) return 2;
+        if (lo >= beyond_bits && hi < (int)f2u(2147483648.0f)) return 2;
         return 0;
       };
       // (the extremes are wave-uniform values in vector registers; what is derived from them and kept is made scalar)
-      const int sx_side = __builtin_amdgcn_readfirstlane(side(w_lo_x, w_hi_x, P.in_w));
-      const int sy_side = __builtin_amdgcn_readfirstlane(side(w_lo_y, w_hi_y, P.in_h));
+      const int sx_side = __builtin_amdgcn_readfirstlane(side(w_lo_x, w_hi_x, beyond_x_bits));
+      const int sy_side = __builtin_amdgcn_readfirstlane(side(w_lo_y, w_hi_y, beyond_y_bits));
       if (LRP_WIN_CORNER != 0 && sx_side != 0 && sy_side != 0) b.tier = (1 + (sx_side - 1) + 2 * (sy_side - 1)) << 3;
       // ... beyond one SIDE only (a rectilinear view inside a panorama: the rows above and below the view and the
       // columns left and right of it, another 37 % of the blocks): the same reasoning along one axis — all four tap
@@ -1643,12 +1652,17 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       }
     }
     Extremes e;
+    // (plain blocks: everything derived from the column terms alone — their products with the rotation matrix, the
+    // column's share of the source lens — is loop-invariant, gets hoisted out of the block loop and then spilled to scratch
+    // for the whole kernel: 80-100 MB of scratch traffic per 4K frame.  Opaque here, those few multiplies run per block.)
+    ColTerms col_g = col;
+    if constexpr (!Quad && LRP_OPAQUE_COL != 0) asm volatile("" : "+v"(col_g.a), "+v"(col_g.b), "+v"(col_g.nx), "+v"(col_g.nz), "+v"(col_g.sx));
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int yk = y_lane + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
       const int ye = yk < qh ? yk : qh - 1;
       if (!quad)
-        pixel_source_rt<OutLens, InMode>(P, col, row_v[k], ye, 0, b.sx[k], b.sy[k]);
+        pixel_source_rt<OutLens, InMode>(P, col_g, row_v[k], ye, 0, b.sx[k], b.sy[k]);
       else
         quad_xy(gm, k, b.sx[k], b.sy[k]);
       note_pixel(e, k, b.sx[k], b.sy[k]);

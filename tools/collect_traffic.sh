@@ -10,4 +10,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out/$ctr" -- python3 "$R/tools/traffic_probe.py" "$out/order.json" > "$out/$ctr.log" 2>&1
   echo "$ctr pass rc=$?"
 done
+# cross-check of the read side: the L2's read requests to the fabric by size (no streaming-pattern factor involved)
+timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d "$out/RDREQ" -- python3 "$R/tools/traffic_probe.py" "$out/order.json" > "$out/RDREQ.log" 2>&1
+echo "RDREQ pass rc=$?"
 python3 "$R/tools/traffic_summary.py" "$out" "$R/gpurun_out/traffic_r03.json" > "$out/summary.log" 2>&1; tail -5 "$out/summary.log"

@@ -25,20 +25,21 @@ order = json.load(open(os.path.join(src_dir, "order.json")))
 SKIP = ("build_tables_kernel", "build_xsep_kernel", "synth_fill_kernel", "checksum_kernel", "__amd_rocclr")
 
 
-def dispatches(counter):
-    """[(dispatch id, kernel name, bytes)] in dispatch order."""
+def dispatches(counter, pass_dir=None, scale=1024.0):
+    """[(dispatch id, kernel name, value)] in dispatch order (FETCH_SIZE / WRITE_SIZE: KiB -> bytes)."""
     rows = {}
-    for f in glob.glob(os.path.join(src_dir, counter, "**", "*counter_collection.csv"), recursive=True):
+    for f in glob.glob(os.path.join(src_dir, pass_dir or counter, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
-                rows[int(r["Dispatch_Id"])] = (r["Kernel_Name"], float(r["Counter_Value"]) * 1024.0)
+                i = int(r["Dispatch_Id"])
+                rows[i] = (r["Kernel_Name"], rows.get(i, ("", 0.0))[1] + float(r["Counter_Value"]) * scale)
     return [(i, k, v) for i, (k, v) in sorted(rows.items()) if not any(s in k for s in SKIP)]
 
 
-def per_workload(counter):
+def per_workload(counter, pass_dir=None, scale=1024.0):
     """calibration average, {workload: (bytes per frame, kernel names, frames averaged)}"""
     groups, cal, cur = [], [], None
-    for _i, k, v in dispatches(counter):
+    for _i, k, v in dispatches(counter, pass_dir, scale):
         if "post_process_kernel" in k:
             cal.append(v)
             cur = []
@@ -66,6 +67,27 @@ result = {"_kernel_source_sha": bench.kernel_source_sha(),
           "_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/traffic_probe.py; KiB -> "
                      "bytes; reads scaled by the factor measured on the calibration kernel (guide: 2.0 for 16 B/lane "
                      "streams on gfx950), writes taken as reported; per FRAME of the workload (one launch; six for the cubemap)"}
+# Cross-check of the read side (optional third pass, tools/collect_traffic.sh): the L2's read requests to the fabric by
+# size, 32 / 64 / 128 bytes each.  No streaming-pattern factor is involved, so it also holds for the gathers.
+by_size = {}
+if glob.glob(os.path.join(src_dir, "RDREQ", "**", "*counter_collection.csv"), recursive=True):
+    parts = {n: per_workload(n, "RDREQ", 1.0) for n in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")}
+
+    def request_bytes(get):
+        vals = {n: get(parts[n]) for n in parts}
+        if any(v is None for v in vals.values()):
+            return None
+        n_all, n32, n64, n128 = (vals[n] for n in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"))
+        return {"requests": n_all, "of_32B": n32, "of_64B": n64, "of_128B": n128,
+                # requests the three size counters do not cover are taken as 64-byte ones
+                "bytes": 32.0 * n32 + 64.0 * n64 + 128.0 * n128 + 64.0 * max(0.0, n_all - n32 - n64 - n128)}
+
+    cal_rq = request_bytes(lambda p: p[0])
+    result["_calibration"]["read_requests_by_size"] = cal_rq
+    for o in order:
+        rq = request_bytes(lambda p, wl=o["workload"]: (p[1].get(wl) or (None,))[0])
+        if rq:
+            by_size[o["workload"]] = rq
 for o in order:
     wl = o["workload"]
     f, w = fetch.get(wl), write.get(wl)
@@ -74,5 +96,7 @@ for o in order:
     rd, wr = f[0] * read_factor, w[0]
     result[wl] = {"kernels": f[1], "frames_averaged": f[2], "launches_per_frame": o["launches_per_frame"], "FETCH_SIZE_bytes_raw": f[0],
                   "WRITE_SIZE_bytes_raw": w[0], "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
+    if wl in by_size:
+        result[wl]["read_requests_by_size"] = by_size[wl]
 json.dump(result, open(out_path, "w"), indent=1)
 print(json.dumps(result, indent=1))
