@@ -206,6 +206,15 @@ bool win_edge_enabled() {
   }();
   return on;
 }
+// LRP_WIN_SPLIT=0: blocks of the window kernel whose window exceeds the LDS buffer gather per pixel instead of staging the
+// windows of their two halves one after the other (A/B checks).
+bool win_split_enabled() {
+  static const bool on = [] {
+    const char *v = std::getenv("LRP_WIN_SPLIT");
+    return !(v && std::strcmp(v, "0") == 0);
+  }();
+  return on;
+}
 // LRP_XSEP=0 in the environment switches the column-separable source x tables off (A/B checks).
 bool xsep_enabled() {
   static const bool on = [] {
@@ -285,6 +294,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
       P.quad = 2;
     P.win_coef = kernel_choice() == 2;
     P.win_edge = (kernel_choice() == 2 && win_edge_enabled()) ? 1 : 0;
+    P.win_split = (kernel_choice() == 2 && win_split_enabled()) ? 1 : 0;
     // Mirror mode of the window kernel (lrp_kernel_v2.h QMode): both axes without a rotation; rows only for a pan,
     // columns only for a pitch into a rectilinear target.  Signed zeros count as zeros in the matrix tests.
     P.win_mode = P.quad == 1 ? 1 : 0;

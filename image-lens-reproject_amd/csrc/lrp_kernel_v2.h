@@ -1162,6 +1162,9 @@ __device__ __forceinline__ void win_lane_pixel(int lane, int &prow, int &pcol) {
 #ifndef LRP_WIN_CORNER
 #define LRP_WIN_CORNER 1 // blocks wholly beyond one corner of the source: one evaluation per block (0: per pixel)
 #endif
+#ifndef LRP_WIN_SPLIT
+#define LRP_WIN_SPLIT 1 // blocks whose window exceeds the buffer but whose two half-block windows fit stage those one after the other (0: per-pixel gathers)
+#endif
 #ifndef LRP_OPAQUE_COL
 #define LRP_OPAQUE_COL 1 // plain blocks: the column terms are opaque to loop-invariant code motion (see coords())
 #endif
@@ -1173,7 +1176,7 @@ __device__ __forceinline__ void win_lane_pixel(int lane, int &prow, int &pcol) {
 #endif
 
 #if defined(LRP_TIER_STATS) // diagnostic builds (tools/ablate.sh): blocks per tier (coefficients, raw taps, direct)
-__device__ unsigned g_tier_stats[8]; // coefficient, raw, direct, corner, beyond a row, beyond a column
+__device__ unsigned g_tier_stats[8]; // coefficient, raw, direct, corner, beyond a row, beyond a column, split
 #endif
 
 // Source coordinates and window of one 16 x 16 block (4 pixels per lane).  Fat: the per-half plane offsets are
@@ -1183,6 +1186,7 @@ __device__ unsigned g_tier_stats[8]; // coefficient, raw, direct, corner, beyond
 template <bool Fat> struct WinBlockT {
   float sx[4], sy[4];
   int x_lo, y_lo, bw, bh, pitch; // window origin, size and row pitch in texels (wave-uniform)
+  int y_lo2, bh2; // split blocks (tier bit 9): first row and height of the window of passes 2-3; y_lo / bh are those of passes 0-1
   __device__ __forceinline__ int spitch() const { return pitch; } // slot distance from window row r to r + 1
   __device__ __forceinline__ int org() const { return 0; }        // slot of window row 0
   // Wave-uniform state is kept small and integral: the kernel sits at the SGPR limit (every word held across the
@@ -1202,7 +1206,13 @@ template <bool Fat> struct WinBlockT {
   // first / last source row and the vertical weight to 0 / 1, the window is bw texels of that row (bh = 1, pitch = bw)
   // followed by a plane of their vertical cubics.  Beyond in x (3, 4): the four tap columns clamp to the first / last
   // source column and the horizontal weight to 0 / 1, the window is bh texels of that column (bw = 1, pitch = 1).
-  __device__ __forceinline__ int edge() const { return tier >> 6; }
+  __device__ __forceinline__ int edge() const { return (tier >> 6) & 7; }
+  // bit 9 split: the window of the whole block exceeds the buffer, the windows of its two halves (passes 0-1, 2-3) fit:
+  // they are staged one after the other, raw taps (mappings around 1:1 whose blocks are a little too large: 60 % of the
+  // blocks of an 8192^2 panorama -> 2048^2 cubemap face)
+  __device__ __forceinline__ int split() const { return tier & 512; }
+  __device__ __forceinline__ int rows_of(int half) const { return half ? bh2 : bh; }
+  __device__ __forceinline__ int first_row_of(int half) const { return half ? y_lo2 : y_lo; }
   // coefficient tier: per half of the block (passes 0-1, 2-3) the first int(sy) and the number of distinct
   // int(sy) rows; a coefficient row has the window's pitch
   int iy0[2], iyn[2], c_plane, c_base; // plane size and first slot of plane 0 (behind the raw window + a margin)
@@ -1295,6 +1305,12 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   // where whole blocks lie beyond one side of the source; in the other instantiations the extra code costs 2-3 % (measured:
   // fisheye -> rectilinear 100 -> 102.5 us, fisheye -> fisheye 141.5 -> 146) and such blocks take the per-pixel gathers.
   constexpr bool kEdge = LRP_WIN_EDGE != 0 && InMode == kInRect;
+  // Split blocks (WinBlockT::split) are compiled into the single-launch instantiations only: in the kernels with the frame
+  // loop the extra code costs 2-7 % on mappings that have no such block (measured: equirect -> rect 91 -> 98 us, rect ->
+  // equirect 212 -> 227), and what needs them — the 2048^2 faces of an 8192^2 panorama — arrives as single launches.
+  // ... and for panorama sources only (a large panorama rendered into smaller views is where blocks are a little too large;
+  // the rectilinear-source kernels lost 6 % to the extra code: rect -> equirect 210 -> 223 us).
+  constexpr bool kSplit = LRP_WIN_SPLIT != 0 && !Frames && (InMode == kInEquirect || InMode == kInEquirectLoop);
   constexpr int kPlanes = 3;
   __shared__ float4 s_win[kWinWaves][kWinCap];
 
@@ -1422,7 +1438,8 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   const int y_hi_bits = __builtin_amdgcn_readfirstlane((int)f2u((float)(P.in_h - 2)));
   const int beyond_x_bits = __builtin_amdgcn_readfirstlane((int)f2u((float)(P.in_w + 1)));
   const int beyond_y_bits = __builtin_amdgcn_readfirstlane((int)f2u((float)(P.in_h + 1)));
-  auto raw_slots = [](const WinBlock &b) { return CH == 5 ? b.pitch * b.bh + ((b.pitch * b.bh + 3) >> 2) : b.pitch * b.bh; };
+  auto slots_of_rows = [](int pitch, int rows) { return CH == 5 ? pitch * rows + ((pitch * rows + 3) >> 2) : pitch * rows; };
+  auto raw_slots = [&](const WinBlock &b) { return slots_of_rows(b.pitch, kSplit ? max(b.bh, b.bh2) : b.bh); }; // (bh2 == 0 unless split)
   // Window of a block from the wave-wide extremes of its source coordinates (float bits, see below):
   // x range of the block, y ranges of its two halves.
   // exact_x / exact_y: int(s + k) == int(s) + k, k = -1 .. 2, holds for every pixel's x / y (the exactness vote of coords())
@@ -1448,6 +1465,16 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       b.bh = y_last + 2 - b.y_lo + 1;
       b.pitch = b.bw | 1; // odd: consecutive window rows start an odd number of 16 B slots apart
       b.tier = (b.bw <= 64 && raw_slots(b) <= kWinCap) ? 1 : 0;
+      if (kSplit && P.win_split != 0 && b.tier == 0 && b.bw <= 64) {
+        const int a_lo = ya_first - 1, a_rows = ya_last + 2 - a_lo + 1, b_lo = yb_first - 1, b_rows = yb_last + 2 - b_lo + 1;
+        if (slots_of_rows(b.pitch, max(a_rows, b_rows)) <= kWinCap) {
+          b.y_lo = a_lo;
+          b.bh = a_rows;
+          b.y_lo2 = b_lo;
+          b.bh2 = b_rows;
+          b.tier = 1 | 512;
+        }
+      }
       // coefficient tier: three planes of pitch x iyn[h] tap-column origins behind the raw window
       b.iy0[0] = ya_first;
       b.iyn[0] = ya_last - ya_first + 1;
@@ -1455,13 +1482,13 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       b.iyn[1] = yb_last - yb_first + 1;
       // strongly magnified blocks have room for the planes of ALL their origin rows: one
       // precompute per block (fuller lanes: e.g. 132 origins in 3 trips instead of 2 x 77 in 4)
-      if (raw_slots(b) + kPlanes * b.pitch * (y_last - y_first + 1) <= kWinCap) b.tier |= 4;
+      if (!b.split() && raw_slots(b) + kPlanes * b.pitch * (y_last - y_first + 1) <= kWinCap) b.tier |= 4;
       if (b.whole()) {
         b.iy0[0] = b.iy0[1] = y_first;
         b.iyn[0] = b.iyn[1] = y_last - y_first + 1;
       }
       b.c_plane = b.pitch * max(b.iyn[0], b.iyn[1]);
-      if (kWinCoef && P.win_coef != 0 && b.staged() && raw_slots(b) + kPlanes * b.c_plane <= kWinCap) b.tier |= 2;
+      if (kWinCoef && P.win_coef != 0 && b.staged() && !b.split() && raw_slots(b) + kPlanes * b.c_plane <= kWinCap) b.tier |= 2;
       // planes behind the raw window plus, where there is room, one row and one column of slack:
       // the next block's (slightly different) window can then be requested while this block's
       // planes are still being read (see next_window)
@@ -1517,6 +1544,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   auto clear_block = [](WinBlock &b) {
     b.tier = 0;
     b.x_lo = b.y_lo = b.bw = b.bh = b.pitch = b.c_plane = b.c_base = b.tap_base = 0;
+    b.y_lo2 = b.bh2 = 0;
     b.c_delta_stored[0] = b.c_delta_stored[1] = 0;
     b.iy0[0] = b.iy0[1] = b.iyn[0] = b.iyn[1] = 0;
   };
@@ -1716,7 +1744,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       return cubic_px<4>(k, k, k, k, fx, hfx);
     }
   };
-  auto issue = [&](const float *frame, const WinBlock &b) { // the window `b` of the source frame `frame`
+  auto issue = [&](const float *frame, const WinBlock &b, int half = 0) { // the window `b` of the source frame `frame` (split blocks: of its half)
     if (kEdge && b.edge() != 0) {
       // One source row (texels x_lo .. x_lo + bw - 1 of row y_lo) or one source column (rows y_lo .. y_lo + bh - 1 of
       // column x_lo) into consecutive slots: 64 texels per instruction, the lane's byte offset along the row / column
@@ -1767,8 +1795,9 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
         uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win + (uint32_t)b.org() * 16u;
         const uint32_t lds_step = (uint32_t)(b.spitch() * 16); // dwordx3 too writes one 16-byte slot per lane
         const uint32_t lane_bytes = (uint32_t)(b.x_lo + lane) * (4u * CH);
-        const char *row = reinterpret_cast<const char *>(frame) + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)b.y_lo * src.row_bytes)); // wave-uniform
-        for (int r = 0; r < b.bh; ++r) {
+        const int n_rows = kSplit ? b.rows_of(half) : b.bh;
+        const char *row = reinterpret_cast<const char *>(frame) + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(kSplit ? b.first_row_of(half) : b.y_lo) * src.row_bytes)); // wave-uniform
+        for (int r = 0; r < n_rows; ++r) {
           if constexpr (CH == 4)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                          :
@@ -1779,7 +1808,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
             // (an instruction offset would move the LDS address as well as the global one: the fifth float's 16 bytes
             // go into the scalar base)
             const uint32_t lds_d = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win +
-                                   (uint32_t)(b.pitch * b.bh) * 16u + (uint32_t)(r * b.pitch) * 4u;
+                                   (uint32_t)(b.pitch * n_rows) * 16u + (uint32_t)(r * b.pitch) * 4u;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                          :
                          : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(row)
@@ -1945,8 +1974,8 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   // window slot of the pixel's first tap (int(sx) - 1, int(sy) - 1); bicubicInterpolate's order: four
   // vertical cubics, then the horizontal one (src/reproject.cpp:100-107).  In the last pass these are the
   // block's last reads of the window: the next window's DMA goes behind them.
-  auto depth_from_window = [&](const float4 *win, int slot, float fx, float fy, float hfx, float hfy, bool last_pass) {
-    const float *d = reinterpret_cast<const float *>(win + cur.pitch * cur.bh) + slot;
+  auto depth_from_window = [&](const float4 *win, int slot, float fx, float fy, float hfx, float hfy, bool last_pass, int half = 0) {
+    const float *d = reinterpret_cast<const float *>(win + cur.pitch * (kSplit ? cur.rows_of(half) : cur.bh)) + slot;
     float t[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -1986,9 +2015,10 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
     const int tier = cur.tier;
 #endif
     const bool t_coef = kWinCoef && (tier & 2) != 0, t_staged = (tier & 1) != 0, t_whole = (tier & 4) != 0;
-    const int t_edge = kEdge ? (tier >> 6) : 0; // 1, 2: beyond the first / last source row; 3, 4: column
+    const int t_edge = kEdge ? ((tier >> 6) & 7) : 0;
+    const bool t_split = kSplit && (tier & 512) != 0; // the window holds passes 0-1; that of passes 2-3 is fetched behind pass 1's taps // 1, 2: beyond the first / last source row; 3, 4: column
 #if defined(LRP_TIER_STATS)
-    if (lane == 0) atomicAdd(&g_tier_stats[((tier >> 3) & 7) != 0 ? 3 : (tier >> 6) != 0 ? ((tier >> 6) < 3 ? 4 : 5) : (kWinCoef && (tier & 2)) ? 0 : (tier & 1) ? 1 : 2], 1u);
+    if (lane == 0) atomicAdd(&g_tier_stats[((tier >> 3) & 7) != 0 ? 3 : (tier & 512) != 0 ? 6 : ((tier >> 6) & 7) != 0 ? (((tier >> 6) & 7) < 3 ? 4 : 5) : (kWinCoef && (tier & 2)) ? 0 : (tier & 1) ? 1 : 2], 1u);
 #endif
     if (((tier >> 3) & 7) != 0) {
       // every pixel of this block is one value: no taps, no per-pixel arithmetic — four stores.  The next block's
@@ -2148,9 +2178,13 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
           s = cubic4(k0, k1, k2, k3, fx, hfx);
           if constexpr (CH == 5) s.e = depth_from_window(win, tap - cur.spitch(), fx, fy, hfx, hfy, last_pass);
         } else if (t_staged) {
+          // (split blocks: h = 1 reads the window of passes 2-3, requested behind pass 1's taps — its arithmetic and store and
+          // the other wavefronts cover part of the round trip — and waited for in front of pass 2)
+          const int half = (t_split && h == 1) ? 1 : 0;
+          if (t_split && k == 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); // the DMA is older than every store behind it
           const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
           const float fx = psx - tx_, fy = psy - ty_;
-          const int slot0 = cur.org() + __mul24((int)ty_ - 1 - cur.y_lo, cur.spitch()) + ((int)tx_ - 1 - cur.x_lo);
+          const int slot0 = cur.org() + __mul24((int)ty_ - 1 - (kSplit ? cur.first_row_of(half) : cur.y_lo), cur.spitch()) + ((int)tx_ - 1 - cur.x_lo);
           const float4 *t = win + slot0;
           const float hfx = 0.5f * fx, hfy = 0.5f * fy;
           const float4 *t1 = t + cur.spitch(), *t2 = t1 + cur.spitch(), *t3 = t2 + cur.spitch();
@@ -2163,12 +2197,16 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
             q[j][3] = as_rgba(t3[j]);
           }
           if (last_pass && CH != 5) next_window();
+          if (t_split && k == 1 && CH != 5) issue(P.src, cur, 1);
           const Rgba k0 = cubic4(q[0][0], q[0][1], q[0][2], q[0][3], fy, hfy);
           const Rgba k1 = cubic4(q[1][0], q[1][1], q[1][2], q[1][3], fy, hfy);
           const Rgba k2 = cubic4(q[2][0], q[2][1], q[2][2], q[2][3], fy, hfy);
           const Rgba k3 = cubic4(q[3][0], q[3][1], q[3][2], q[3][3], fy, hfy);
           s = cubic4(k0, k1, k2, k3, fx, hfx);
-          if constexpr (CH == 5) s.e = depth_from_window(win, slot0, fx, fy, hfx, hfy, last_pass);
+          if constexpr (CH == 5) {
+            s.e = depth_from_window(win, slot0, fx, fy, hfx, hfy, last_pass, half);
+            if (t_split && k == 1) issue(P.src, cur, 1); // behind the depth taps: pass 1's last reads of the window
+          }
         } else {
           if (last_pass) next_window(); // nothing staged: no tap of this block reads the window
           if constexpr (CH == 5) {

@@ -24,5 +24,5 @@ for a, b, deg in [("eqr", "eqd", (30, -15, 5)), ("eqd", "eqd", (10, 5, 0)), ("eq
     lrp.reproject(lrp.Image(lenses[a], n, n, 4, src), lrp.Image(lenses[b], n, n, 4, dst), 1, 2, rot(deg))
     torch.cuda.synchronize()
     lib.lrp_debug_read_tiers_plain(out)
-    tot = sum(out[:6]) or 1
-    print(f"{a}->{b} rot={deg}: " + " ".join(f"{nm} {100.0 * out[i] / tot:.1f}%" for i, nm in enumerate(["coef", "raw", "direct", "corner", "edge-row", "edge-col"])), flush=True)
+    tot = sum(out[:7]) or 1
+    print(f"{a}->{b} rot={deg}: " + " ".join(f"{nm} {100.0 * out[i] / tot:.1f}%" for i, nm in enumerate(["coef", "raw", "direct", "corner", "edge-row", "edge-col", "split"])), flush=True)
