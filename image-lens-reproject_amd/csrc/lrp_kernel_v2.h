@@ -1165,6 +1165,9 @@ __device__ __forceinline__ void win_lane_pixel(int lane, int &prow, int &pcol) {
 #ifndef LRP_WIN_SPLIT
 #define LRP_WIN_SPLIT 1 // blocks whose window exceeds the buffer but whose two half-block windows fit stage those one after the other (0: per-pixel gathers)
 #endif
+#ifndef LRP_WIN_PASSWIN
+#define LRP_WIN_PASSWIN 1 // (with LRP_WIN_SPLIT) blocks whose half windows do not fit either try the window of each 16 x 4 pass
+#endif
 #ifndef LRP_OPAQUE_COL
 #define LRP_OPAQUE_COL 1 // plain blocks: the column terms are opaque to loop-invariant code motion (see coords())
 #endif
@@ -1311,6 +1314,9 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   // ... and for panorama sources only (a large panorama rendered into smaller views is where blocks are a little too large;
   // the rectilinear-source kernels lost 6 % to the extra code: rect -> equirect 210 -> 223 us).
   constexpr bool kSplit = LRP_WIN_SPLIT != 0 && !Frames && (InMode == kInEquirect || InMode == kInEquirectLoop);
+  // Pass windows (below) for rectilinear targets only — perspective views and cubemap faces out of a panorama; in the
+  // fisheye-target kernels the extra code cost 2.5 % (equirect -> fisheye single launches 247 -> 253 us).
+  constexpr bool kPassWin = kSplit && LRP_WIN_PASSWIN != 0 && OutLens == kRect;
   constexpr int kPlanes = 3;
   __shared__ float4 s_win[kWinWaves][kWinCap];
 
@@ -1988,6 +1994,63 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
     const f2 k23 = catmull_rom2(f2{t[2][0], t[3][0]}, f2{t[2][1], t[3][1]}, f2{t[2][2], t[3][2]}, f2{t[2][3], t[3][3]}, fy, hfy);
     return catmull_rom(k01.x, k01.y, k23.x, k23.y, fx, hfx);
   };
+  // Pass windows (kernels with split blocks): a block whose two half windows do not fit either (a pole face of a
+  // cubemap: the panorama's rows converge) still has passes — 16 x 4 pixels — whose own window fits.  Planned per pass
+  // from the wave-wide extremes of that pass's coordinates, fetched, waited for and read on the spot; the other
+  // wavefronts of the SIMD cover the round trip (requesting the window of pass k + 1 behind the taps of pass k, like the
+  // second half of a split block, measured slower: 120 against 112 us per pole face, 14 spilled registers).
+  // False: this pass gathers per pixel.
+  auto pass_window = [&](float psx, float psy, Rgba &s, bool last_pass) -> bool {
+    if (!all_interior(psx, psy, 1.0f, src.x_hi, src.y_hi, 2.0f)) return false;
+    int lo_x = (int)f2u(psx), hi_x = lo_x, lo_y = (int)f2u(psy), hi_y = lo_y, d0 = 0, d1 = 0;
+    wave_box(lo_x, hi_x, lo_y, hi_y, d0, d1); // (interior: the coordinates are >= 1, their bits order like integers)
+    WinBlock w;
+    clear_block(w);
+    w.x_lo = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)lo_x)) - 1;
+    w.y_lo = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)lo_y)) - 1;
+    w.bw = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)hi_x)) + 2 - w.x_lo + 1;
+    w.bh = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)hi_y)) + 2 - w.y_lo + 1;
+    w.pitch = w.bw | 1;
+    if (w.bw > 64 || slots_of_rows(w.pitch, w.bh) > kWinCap) return false;
+    w.tier = 1;
+    issue(P.src, w);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the window (and every older store)
+    const float4 *const win = win0;
+    const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
+    const float fx = psx - tx_, fy = psy - ty_;
+    const int slot0 = __mul24((int)ty_ - 1 - w.y_lo, w.pitch) + ((int)tx_ - 1 - w.x_lo);
+    const float4 *t = win + slot0;
+    const float hfx = 0.5f * fx, hfy = 0.5f * fy;
+    const float4 *t1 = t + w.pitch, *t2 = t1 + w.pitch, *t3 = t2 + w.pitch;
+    Rgba q[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      q[j][0] = as_rgba(t[j]);
+      q[j][1] = as_rgba(t1[j]);
+      q[j][2] = as_rgba(t2[j]);
+      q[j][3] = as_rgba(t3[j]);
+    }
+    float dz[4][4];
+    if constexpr (CH == 5) {
+      const float *d = reinterpret_cast<const float *>(win + w.pitch * w.bh) + slot0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dz[j][r] = d[r * w.pitch + j];
+    }
+    if (last_pass) next_window(); // behind the last reads of this pass's window
+    const Rgba k0 = cubic4(q[0][0], q[0][1], q[0][2], q[0][3], fy, hfy);
+    const Rgba k1 = cubic4(q[1][0], q[1][1], q[1][2], q[1][3], fy, hfy);
+    const Rgba k2 = cubic4(q[2][0], q[2][1], q[2][2], q[2][3], fy, hfy);
+    const Rgba k3 = cubic4(q[3][0], q[3][1], q[3][2], q[3][3], fy, hfy);
+    s = cubic4(k0, k1, k2, k3, fx, hfx);
+    if constexpr (CH == 5) {
+      const f2 k01 = catmull_rom2(f2{dz[0][0], dz[1][0]}, f2{dz[0][1], dz[1][1]}, f2{dz[0][2], dz[1][2]}, f2{dz[0][3], dz[1][3]}, fy, hfy);
+      const f2 k23 = catmull_rom2(f2{dz[2][0], dz[3][0]}, f2{dz[2][1], dz[3][1]}, f2{dz[2][2], dz[3][2]}, f2{dz[2][3], dz[3][3]}, fy, hfy);
+      s.e = catmull_rom(k01.x, k01.y, k23.x, k23.y, fx, hfx);
+    }
+    return true;
+  };
 #pragma unroll 1
   for (int g = 0; g < G; ++g) {
    g_loop = g;
@@ -2207,6 +2270,8 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
             s.e = depth_from_window(win, slot0, fx, fy, hfx, hfy, last_pass, half);
             if (t_split && k == 1) issue(P.src, cur, 1); // behind the depth taps: pass 1's last reads of the window
           }
+        } else if (kPassWin && P.win_split != 0 && pass_window(psx, psy, s, last_pass)) {
+          // (rendered from the window of this pass)
         } else {
           if (last_pass) next_window(); // nothing staged: no tap of this block reads the window
           if constexpr (CH == 5) {

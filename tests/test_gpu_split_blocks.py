@@ -53,6 +53,21 @@ def test_ratios_around_the_limit(lrp, oracle, torch_cuda, in_w, in_h, out_w, out
         render(lrp, torch_cuda, lin, src, lout, out_w, out_h, rot, channels, f"{in_name} {in_w}x{in_h} -> {out_w}x{out_h} C={channels} rot={deg}", want)
 
 
+@pytest.mark.parametrize("channels", [3, 4, 5])
+@pytest.mark.parametrize("deg", [(0.0, 90.0, 0.0), (0.0, -90.0, 0.0), (0.0, 60.0, 0.0), (20.0, 75.0, 10.0)])
+def test_pole_views_of_a_square_panorama(lrp, oracle, torch_cuda, channels, deg):
+    """The bench's configs[4] geometry (a SQUARE 8192^2 panorama -> 2048^2 faces) at an eighth of the size: towards the pole
+    neither the block's window nor its halves fit; the passes whose own 16 x 4 window fits stage that (pass windows), the
+    rest gathers per pixel."""
+    n, face = 1024, 256
+    src = cases.hash_noise(n, n, channels, seed=5 * channels + 3)
+    lin = cases.lenses(lrp, n, n)["eqr_full"]
+    lout = lrp.LensInfo.rectilinear(18.0, 36.0, face, face)
+    rot = cases.rotation(lrp, deg)
+    want = oracle.reproject(lin, src, lout, face, face, 1, BICUBIC, rot, threads=8)
+    render(lrp, torch_cuda, lin, src, lout, face, face, rot, channels, f"square eqr {n} -> rect {face} C={channels} rot={deg}", want)
+
+
 def test_faces_through_the_multi_output_entry_point_and_row_bands(lrp, oracle, torch_cuda):
     torch = torch_cuda
     in_w, in_h, face = 2048, 1024, 256
