@@ -1313,10 +1313,12 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   // equirect 212 -> 227), and what needs them — the 2048^2 faces of an 8192^2 panorama — arrives as single launches.
   // ... and for panorama sources only (a large panorama rendered into smaller views is where blocks are a little too large;
   // the rectilinear-source kernels lost 6 % to the extra code: rect -> equirect 210 -> 223 us).
-  constexpr bool kSplit = LRP_WIN_SPLIT != 0 && !Frames && (InMode == kInEquirect || InMode == kInEquirectLoop);
+  // (... and for the RGBAZ kernels of a rectilinear source: their per-pixel path is 20 gathers a pixel, and the pass windows
+  // below pay there — rect -> equirect RGBAZ 300 -> 288 us, BASELINE configs[3] — while RGBA / RGB lose 4-6 %.)
+  constexpr bool kSplit = LRP_WIN_SPLIT != 0 && !Frames && (InMode == kInEquirect || InMode == kInEquirectLoop || (InMode == kInRect && CH == 5));
   // Pass windows (below) for rectilinear targets only — perspective views and cubemap faces out of a panorama; in the
   // fisheye-target kernels the extra code cost 2.5 % (equirect -> fisheye single launches 247 -> 253 us).
-  constexpr bool kPassWin = kSplit && LRP_WIN_PASSWIN != 0 && OutLens == kRect;
+  constexpr bool kPassWin = kSplit && LRP_WIN_PASSWIN != 0 && (OutLens == kRect || (InMode == kInRect && CH == 5));
   constexpr int kPlanes = 3;
   __shared__ float4 s_win[kWinWaves][kWinCap];
 
