@@ -1323,7 +1323,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   __shared__ float4 s_win[kWinWaves][kWinCap];
 
   int tx, ty;
-  if (!xcd_tile(P.tiles_x, P.tiles_y, tx, ty)) return; // whole workgroup
+  if (!xcd_tile<kWinXcdBand>(P.tiles_x, P.tiles_y, tx, ty)) return; // whole workgroup
   // Alias pairs (LRP_WIN_ALIAS_PAIRS; mirrored strips of rectilinear -> equirectangular).  The reference has no
   // hemisphere test: the ray of panorama pixel (x + W/2, H-1-y) is the ray of (x, y) with x and z negated, and a
   // rectilinear projection divides by z — both pixels land on (nearly: different roundings) the same source
@@ -2422,7 +2422,7 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
   }
   const TileKernelFn fn = P.frames_per_wave > 1 ? WinKernelTable<QMode, CH, true>::get(out_idx, in_mode) : WinKernelTable<QMode, CH, false>::get(out_idx, in_mode);
   if (!fn) return hipErrorInvalidValue; // (the host never asks for a mode outside its cells)
-  hipLaunchKernelGGL(fn, dim3((unsigned)(kXcds * xcd_rows(P.tiles_y) * P.tiles_x), (unsigned)groups), dim3(kWinThreads), 0, stream, P);
+  hipLaunchKernelGGL(fn, dim3((unsigned)(kXcds * xcd_rows(P.tiles_y, kWinXcdBand) * P.tiles_x), (unsigned)groups), dim3(kWinThreads), 0, stream, P);
   return hipGetLastError();
 }
 
