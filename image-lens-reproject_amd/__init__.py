@@ -206,6 +206,33 @@ def debug_kernel(choice=-1):
     return _native.load().lrp_debug_kernel(int(choice))
 
 
+def debug_set(name, value=-1):
+    """lrp_debug_set: the named A/B switch ("xsep", "quad", "mirror_modes", "win_edge", "win_split", "geo_cache",
+    "batch_frames", "multi_fork", "kernel"); returns the previous value, -1 only queries."""
+    prev = _native.load().lrp_debug_set(str(name).encode(), int(value))
+    if prev < 0:
+        raise ValueError(f"unknown debug switch {name!r}")
+    return prev
+
+
+def geometry_cache_configure(max_bytes=-1, min_sightings=-1):
+    """lrp_geometry_cache_configure: bytes per device (0 switches the cache off and frees it), launches of a geometry
+    before it is cached; negative values keep the current setting."""
+    _check(_native.load().lrp_geometry_cache_configure(int(max_bytes), int(min_sightings)))
+
+
+def geometry_cache_stats():
+    """lrp_geometry_cache_stats as a dict: bytes, max_bytes, entries, fills, hits, bypasses, evictions."""
+    info = _native.LrpGeometryCacheInfo()
+    _native.load().lrp_geometry_cache_stats(ctypes.byref(info))
+    return {n: int(getattr(info, n)) for n, _ in info._fields_}
+
+
+def release_cached_tables():
+    """lrp_release_cached_tables: frees the lens tables and the geometry cache of every device."""
+    _native.load().lrp_release_cached_tables()
+
+
 def reproject(in_image, out_image, num_samples, interpolation, rotation_matrix=None, post=None, device=None,
               stream=None):
     """reproject::reproject (src/reproject.cpp:405-419).  `post=(exposure, reinhard)`

@@ -39,6 +39,10 @@ class LrpPost(ctypes.Structure):
     _fields_ = [("exposure", ctypes.c_float), ("reinhard", ctypes.c_float)]
 
 
+class LrpGeometryCacheInfo(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("bytes", "max_bytes", "entries", "fills", "hits", "bypasses", "evictions")]
+
+
 assert ctypes.sizeof(LrpLens) == 28
 assert ctypes.sizeof(LrpImage) == 56
 
@@ -49,7 +53,10 @@ SYMBOLS = {
     "lrp_abi_version": (ctypes.c_int, []),
     "lrp_device_count": (ctypes.c_int, []),
     "lrp_debug_kernel": (ctypes.c_int, [ctypes.c_int]),
+    "lrp_debug_set": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "lrp_release_cached_tables": (None, []),
+    "lrp_geometry_cache_configure": (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int]),
+    "lrp_geometry_cache_stats": (None, [ctypes.c_void_p]),
     "lrp_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "lrp_last_error": (ctypes.c_char_p, []),
     "lrp_reproject": (
@@ -171,7 +178,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.lrp_abi_version() != 2:
+    if lib.lrp_abi_version() != 3:
         raise ImportError("liblrp_hip.so ABI version mismatch")
     _lib = lib
     return lib

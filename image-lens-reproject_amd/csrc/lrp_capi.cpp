@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/lrp.h"
+#include "lrp_geocache.h"
 #include "lrp_params.h"
 #include "lrp_tables.h"
 
@@ -30,7 +31,7 @@ hipError_t launch_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_
 hipError_t launch_tile_nearest(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
 hipError_t launch_tile_bilinear(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
 hipError_t launch_tile_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
-hipError_t launch_win_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
+hipError_t launch_win_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // (P.geo_mode == 2: the GeoRead kernels)
 hipError_t launch_post_process(float *data, uint32_t n_pixels, int channels, float exposure, float reinhard,
                                hipStream_t stream);
 hipError_t launch_synth_fill(float *data, uint32_t n_elems, int channels, uint32_t seed, int depth_channel,
@@ -166,63 +167,51 @@ lrp::KParams make_params(const lrp_image *in, const lrp_image *out, int num_samp
   return P;
 }
 
-// Kernel selection.  The tile kernel (lrp_kernel_v2.h) serves RGBA images whose
-// tap indices fit its 16-bit packing; everything else — and everything when
-// LRP_KERNEL=pixel is set in the environment (A/B checks) — takes the
-// one-pixel-per-lane kernel (lrp_kernel_impl.h).  Both are HIP; there is no CPU path.
-// 0 = pixel kernel, 1 = tile kernel everywhere, 2 (default) = tile kernel with the
-// LDS-window kernel for bicubic, 3 = the same without its shared-coefficient tier.  Initialised from LRP_KERNEL=pixel|tile|window-raw, changed
-// at run time by lrp_debug_kernel().
-std::atomic<int> g_kernel_choice{[] {
-  const char *v = std::getenv("LRP_KERNEL");
-  if (v && std::strcmp(v, "pixel") == 0) return 0;
-  if (v && std::strcmp(v, "tile") == 0) return 1;
-  if (v && std::strcmp(v, "window-raw") == 0) return 3;
-  return 2;
-}()};
-int kernel_choice() { return g_kernel_choice.load(std::memory_order_relaxed); }
-// LRP_QUAD=0 switches the mirrored blocks of the window kernel off (A/B checks).
-bool quad_enabled() {
-  static const bool on = [] {
-    const char *v = std::getenv("LRP_QUAD");
-    return !(v && std::strcmp(v, "0") == 0);
-  }();
-  return on;
-}
-// LRP_MIRROR_MODES=0 keeps pan / pitch rotations on the plain blocks of the window kernel (A/B checks).
-bool mirror_modes_enabled() {
-  static const bool on = [] {
-    const char *v = std::getenv("LRP_MIRROR_MODES");
-    return !(v && std::strcmp(v, "0") == 0);
-  }();
-  return on;
-}
-// LRP_WIN_EDGE=0: blocks of the window kernel beyond one side of the source gather per pixel instead of staging the one
-// source row / column they read (A/B checks).
-bool win_edge_enabled() {
-  static const bool on = [] {
-    const char *v = std::getenv("LRP_WIN_EDGE");
-    return !(v && std::strcmp(v, "0") == 0);
-  }();
-  return on;
-}
-// LRP_WIN_SPLIT=0: blocks of the window kernel whose window exceeds the LDS buffer gather per pixel instead of staging the
-// windows of their two halves one after the other (A/B checks).
-bool win_split_enabled() {
-  static const bool on = [] {
-    const char *v = std::getenv("LRP_WIN_SPLIT");
-    return !(v && std::strcmp(v, "0") == 0);
-  }();
-  return on;
-}
-// LRP_XSEP=0 in the environment switches the column-separable source x tables off (A/B checks).
-bool xsep_enabled() {
-  static const bool on = [] {
-    const char *v = std::getenv("LRP_XSEP");
-    return !(v && std::strcmp(v, "0") == 0);
-  }();
-  return on;
-}
+// Kernel selection and the A/B switches of the sharing / staging paths.  All of them live in one table of atomics that
+// lrp_debug_set() reads and writes; the environment (LRP_KERNEL=pixel|tile|window-raw, LRP_XSEP, LRP_QUAD,
+// LRP_MIRROR_MODES, LRP_WIN_EDGE, LRP_WIN_SPLIT, LRP_BATCH_FRAMES, LRP_MULTI_FORK, LRP_GEO_CACHE) only supplies the
+// initial values, once, when the library is loaded — nothing on a launch path calls getenv.
+//   kernel: 0 = pixel kernel, 1 = tile kernel everywhere, 2 (default) = tile kernel with the LDS-window kernel for
+//   bicubic, 3 = the same without its shared-coefficient tier and without any work sharing.  All HIP; there is no CPU path.
+enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobCount };
+struct KnobSpec {
+  const char *name, *env;
+  int lo, hi, initial;
+};
+constexpr int kMaxSideStreams = 5;
+const KnobSpec kKnobs[kKnobCount] = {
+    {"kernel", "LRP_KERNEL", 0, 3, 2},
+    {"xsep", "LRP_XSEP", 0, 1, 1},                  // column-separable source x tables
+    {"quad", "LRP_QUAD", 0, 1, 1},                  // mirrored pixels / blocks (every mirror mode)
+    {"mirror_modes", "LRP_MIRROR_MODES", 0, 1, 1},  // window kernel: pan / pitch / shared-ray mirror modes
+    {"win_edge", "LRP_WIN_EDGE", 0, 1, 1},          // window kernel: blocks beyond one side of the source stage one row / column
+    {"win_split", "LRP_WIN_SPLIT", 0, 1, 1},        // window kernel: split blocks and pass windows
+    {"batch_frames", "LRP_BATCH_FRAMES", 0, lrp::kMaxBatch, 0}, // frames per wavefront of a batched launch (0: automatic)
+    {"multi_fork", "LRP_MULTI_FORK", 0, kMaxSideStreams, 1},    // side streams of lrp_reproject_multi_device
+    {"geo_cache", "LRP_GEO_CACHE", 0, 1, 1},        // geometry cache used by single launches (0: every launch computes)
+    {"geo_strip", "LRP_GEO_STRIP", 0, lrp::kGeoStripRows, 0}, // blocks per wavefront of a launch that reads the geometry cache (0: automatic)
+};
+std::atomic<int> g_knobs[kKnobCount];
+const bool g_knobs_initialised = [] { // the one place that reads the environment
+  for (int k = 0; k < kKnobCount; ++k) {
+    int v = kKnobs[k].initial;
+    if (const char *e = std::getenv(kKnobs[k].env)) {
+      if (k == kKnobKernel)
+        v = std::strcmp(e, "pixel") == 0 ? 0 : std::strcmp(e, "tile") == 0 ? 1 : std::strcmp(e, "window-raw") == 0 ? 3 : 2;
+      else if (*e)
+        v = std::min(kKnobs[k].hi, std::max(kKnobs[k].lo, std::atoi(e)));
+    }
+    g_knobs[k].store(v, std::memory_order_relaxed);
+  }
+  return true;
+}();
+int knob(int k) { return g_knobs[k].load(std::memory_order_relaxed); }
+int kernel_choice() { return knob(kKnobKernel); }
+bool quad_enabled() { return knob(kKnobQuad) != 0; }
+bool mirror_modes_enabled() { return knob(kKnobMirrorModes) != 0; }
+bool win_edge_enabled() { return knob(kKnobWinEdge) != 0; }
+bool win_split_enabled() { return knob(kKnobWinSplit) != 0; }
+bool xsep_enabled() { return knob(kKnobXsep) != 0; }
 
 // n_batch > 0: `in` / `out` are arrays of n_batch images of one geometry (checked by the caller);
 // the tile / window kernels render them in launches of up to kMaxBatch frames, the per-pixel
@@ -244,6 +233,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
   const int im = in_lens_mode(in->lens);
   hipError_t e;
   lrp::TableLease lease; // pins the cached tables until every launch of this call is enqueued (scope end)
+  lrp::GeoUse geo;       // this launch's use of the geometry cache (none unless set below)
   const bool tile_channels = out->channels >= 3 && out->channels <= 5;
   int symmetry = 0; // bit 0 / 1: the column / row terms of the output-lens tables are mirror images about the image centre
   bool tile = kernel_choice() != 0 && tile_channels && in->width <= 65535 && in->height <= 32767 &&
@@ -323,6 +313,30 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
       const bool yaw_only = !P.has_rot || (P.rot[1] == 0.0f && P.rot[3] == 0.0f && P.rot[5] == 0.0f && P.rot[7] == 0.0f);
       P.alias_pairs = std::fabs(turn - 6.2831855f) < 1e-3f && yaw_only;
     }
+    P.frames_per_wave = knob(kKnobBatchFrames); // 0: the launcher decides
+    // Geometry cache (lrp_geocache.h): a single whole-image launch of the window kernel loads the coordinates of its
+    // pixels and the window extremes of its blocks when an earlier launch of the same geometry has left them in HBM,
+    // and leaves them there when it is the first.  Both run plain blocks: the entry is a plain per-pixel map.
+    if (window && n_batch <= 0 && !band && kernel_choice() == 2 && knob(kKnobGeoCache) != 0) {
+      lrp::GeoKey key;
+      std::memset(&key, 0, sizeof(key));
+      key.device = device;
+      key.out_type = oi == 0 ? lrp::kRect : (oi == 1 ? lrp::kEquidistant : lrp::kEquirect);
+      key.in_mode = im;
+      key.out_w = out->width, key.out_h = out->height, key.in_w = in->width, key.in_h = in->height;
+      key.has_rot = P.has_rot;
+      key.out_lens = P.out_lens, key.in_lens = P.in_lens;
+      if (P.has_rot) std::memcpy(key.rot, P.rot, sizeof(key.rot));
+      lrp::geo_acquire(key, true, stream, &geo);
+      if (geo.mode != 0) {
+        P.geo_mode = geo.mode;
+        P.geo_xy = geo.xy;
+        P.geo_box = geo.box;
+        P.win_mode = 0;
+        P.blocks_per_wave = knob(kKnobGeoStrip); // 0: the launcher decides
+        P.rgbaz_runs = (out->lens.type == LRP_EQUIRECTANGULAR && in->lens.type == LRP_RECTILINEAR) ? 1 : 0;
+      }
+    }
     auto launch = [&]() {
       if (window) return lrp::launch_win_bicubic(P, oi, im, stream);
       if (interpolation == LRP_NEAREST) return lrp::launch_tile_nearest(P, oi, im, stream);
@@ -331,6 +345,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     };
     if (n_batch <= 0) {
       e = launch();
+      lrp::geo_launched(&geo, stream, e == hipSuccess);
     } else {
       e = hipSuccess;
       for (int first = 0; first < n_batch && e == hipSuccess; first += lrp::kMaxBatch) {
@@ -425,10 +440,41 @@ int lrp_abi_version(void) { return LRP_ABI_VERSION; }
 
 int lrp_debug_kernel(int choice) {
   if (choice < 0 || choice > 3) return kernel_choice();
-  return g_kernel_choice.exchange(choice, std::memory_order_relaxed);
+  return g_knobs[kKnobKernel].exchange(choice, std::memory_order_relaxed);
 }
 
-void lrp_release_cached_tables(void) { lrp::release_output_tables(); }
+int lrp_debug_set(const char *name, int value) {
+  if (!name) return -1;
+  for (int k = 0; k < kKnobCount; ++k)
+    if (std::strcmp(name, kKnobs[k].name) == 0) {
+      if (value < kKnobs[k].lo || value > kKnobs[k].hi) return knob(k);
+      return g_knobs[k].exchange(value, std::memory_order_relaxed);
+    }
+  return -1;
+}
+
+void lrp_release_cached_tables(void) {
+  lrp::geo_release_all();
+  lrp::release_output_tables();
+}
+
+int lrp_geometry_cache_configure(long long max_bytes, int min_sightings) {
+  lrp::geo_configure(max_bytes, min_sightings);
+  return LRP_OK;
+}
+
+void lrp_geometry_cache_stats(lrp_geometry_cache_info *out) {
+  if (!out) return;
+  lrp::GeoStats st{};
+  lrp::geo_stats(&st);
+  out->bytes = st.bytes;
+  out->max_bytes = st.max_bytes;
+  out->entries = st.entries;
+  out->fills = st.fills;
+  out->hits = st.hits;
+  out->bypasses = st.bypasses;
+  out->evictions = st.evictions;
+}
 
 int lrp_device_count(void) { return device_count_cached(); }
 
@@ -474,7 +520,7 @@ int lrp_reproject_rows_device(const lrp_image *in, lrp_image *out, int num_sampl
 
 namespace {
 // Side streams of lrp_reproject_multi_device, per device, created on first use and kept.
-constexpr int kMaxSide = 5;
+constexpr int kMaxSide = kMaxSideStreams;
 struct MultiFork {
   std::mutex busy; // one fork / join being enqueued at a time per device (the events are re-recorded by every call)
   hipStream_t side[kMaxSide] = {};
@@ -499,16 +545,9 @@ MultiFork *multi_fork(int device) { // null if the streams / events cannot be cr
   }
   return slot.get();
 }
-// LRP_MULTI_FORK=<n>: side streams lrp_reproject_multi_device deals its launches over besides the caller's (0 keeps
-// every launch on the caller's stream; default 1 — measured best, 588 -> 509 us per 8192^2 -> 6 x 2048^2 cubemap; 2-3: 522, 5: 549).
-int multi_fork_lanes() {
-  static const int n = [] {
-    const char *v = std::getenv("LRP_MULTI_FORK");
-    const int k = v && *v ? std::atoi(v) : 1;
-    return k < 0 ? 0 : k > kMaxSide ? kMaxSide : k;
-  }();
-  return n;
-}
+// Side streams lrp_reproject_multi_device deals its launches over besides the caller's (lrp_debug_set("multi_fork", n);
+// 0 keeps every launch on the caller's stream; default 1 — measured best, 588 -> 509 us per 8192^2 -> 6 x 2048^2 cubemap; 2-3: 522, 5: 549).
+int multi_fork_lanes() { return knob(kKnobMultiFork); }
 } // namespace
 
 int lrp_reproject_multi_device(const lrp_image *in, lrp_image *outs, int n_out, int num_samples,

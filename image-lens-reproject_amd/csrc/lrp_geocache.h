@@ -1,0 +1,58 @@
+// lrp_geocache.h — geometry-keyed coordinate cache in HBM (host side; layout in lrp_params.h).
+//
+// The reference calls reproject() once per file with one geometry for the whole run
+// (src/main.cpp:576-598): lenses, sizes and rotation do not change, only the pixels do.  Everything
+// the hot loop derives from the geometry alone (src/reproject.cpp:287-324: pixel -> ray -> rotation
+// -> source lens -> texel coordinates) is therefore the same in every call.  A batched launch shares
+// it between its frames in registers; single launches share it through this cache: the first launch
+// of a geometry writes the coordinates of every output pixel (and the window extremes of every block
+// of the bicubic window kernel) as a side output, later launches of the same geometry load them.
+// Loaded values are the stored ones, so the rendered bits do not change.
+//
+// Bounded (bytes per device, least recently used entries go first), opt-out through the C ABI
+// (lrp_geometry_cache_configure), freed by lrp_release_cached_tables.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "lrp_params.h"
+
+namespace lrp {
+
+// Everything the coordinates of src/reproject.cpp:323-324 depend on (compared byte for byte).
+struct GeoKey {
+  int32_t device;
+  int32_t out_type, in_mode; // output lens (kRect / kEquidistant / kEquirect), input mode (kIn*)
+  int32_t out_w, out_h, in_w, in_h;
+  int32_t has_rot;
+  LensP out_lens, in_lens;
+  float rot[9];
+};
+
+// What a launch does with the cache: P.geo_mode and the entry's pointers.
+struct GeoUse {
+  int mode = 0;          // 0: no cache for this launch; 1: write map + boxes; 3: write boxes only; 2: read
+  float *xy = nullptr;
+  int32_t *box = nullptr;
+  void *entry = nullptr; // opaque; pinned until geo_launched
+};
+
+// Decides, for a launch that is about to be enqueued on `stream` (device already selected), whether it reads the
+// entry of `key`, writes it, or runs without the cache; want_boxes: the launch is the window kernel (needs the
+// per-block extremes too).  A reader on another stream than the entry's writer is made to wait for the writer
+// (hipStreamWaitEvent).  Never fails: any problem (no memory, a capturing stream, the cache switched off) is mode 0.
+void geo_acquire(const GeoKey &key, bool want_boxes, hipStream_t stream, GeoUse *use);
+// After the launch has been enqueued (ok) or has failed to: publishes a written entry, unpins.
+void geo_launched(GeoUse *use, hipStream_t stream, bool ok);
+
+struct GeoStats {
+  uint64_t bytes, max_bytes, entries, fills, hits, bypasses, evictions;
+};
+// max_bytes < 0 / min_sightings < 1: keep the current value.  max_bytes == 0 switches the cache off (and frees it).
+void geo_configure(long long max_bytes, int min_sightings);
+void geo_stats(GeoStats *out);
+void geo_release_all(); // synchronises the devices that hold entries, frees everything unpinned
+
+} // namespace lrp

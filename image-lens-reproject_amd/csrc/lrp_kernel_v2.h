@@ -38,7 +38,6 @@
 #pragma once
 
 #include <algorithm>
-#include <cstdlib>
 
 #include "lrp_device.h"
 #include "lrp_source_axes.h"
@@ -284,6 +283,7 @@ __device__ __forceinline__ Rgba cubic4(const Rgba a, const Rgba b, const Rgba c,
 // kernel) and the immediates 0, T, 2T, 3T (T = texel bytes).  No per-tap address
 // arithmetic at all.  RGB texels are one dwordx3, RGBAZ a dwordx4 + a dword.
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef float vf2 __attribute__((ext_vector_type(2))); // (a native vector: what the nontemporal builtins take)
 typedef unsigned int u3 __attribute__((ext_vector_type(3)));
 template <int CH>
 __device__ __forceinline__ Px<CH> texel_at(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
@@ -1119,6 +1119,7 @@ __global__ __launch_bounds__(kT2Threads, Frames ? LRP_TILE_MINWAVES_FRAMES : LRP
 #ifndef LRP_WIN_COEF
 #define LRP_WIN_COEF 1
 #endif
+static_assert(LRP_WIN_STRIP <= kGeoStripRows, "geometry-cache entries hold block rows in multiples of kGeoStripRows (lrp_params.h)");
 constexpr bool kWinCoef = LRP_WIN_COEF != 0; // coefficient tier (below)
 constexpr int kWinCap = LRP_WIN_CAP; // float4 texels per window buffer: 10 KiB per wavefront, 40 KiB per workgroup -> 4 workgroups / CU
 #ifndef LRP_WIN_BLOCK_W
@@ -1268,7 +1269,13 @@ template <bool Fat> struct WinBlockT {
 // The host (lrp_capi.cpp win_mirror_mode) checks the matrix entries and the symmetry flags of the output-lens tables.
 // Frames: the instantiation for batched launches whose wavefronts walk several frames (the frame loop costs the
 // one-frame case registers, so single launches keep an instantiation without it).
-template <int OutLens, int InMode, int QMode, int CH, bool Frames = false>
+// GeoRead: the instantiation that LOADS the source coordinates of its pixels and the window extremes of its blocks from
+// a geometry-cache entry (lrp_params.h, lrp_geocache.h) instead of deriving them from the lenses: what the frames of a
+// batch share in registers, single launches of one geometry share through HBM.  The entry is written as a side output by
+// the plain-block instantiation (P.geo_mode == 1) the first time a geometry is rendered; the loaded values are the
+// stored ones, so the rendered bits are the same.  No lens math is compiled in: the output lens is irrelevant (kRect by
+// convention), plain blocks only.
+template <int OutLens, int InMode, int QMode, int CH, bool Frames = false, bool GeoRead = false>
 #ifndef LRP_WIN_MINWAVES5
 #define LRP_WIN_MINWAVES5 3 // RGBAZ: 168 VGPRs (the 80 registers of a direct-path tap set do not fit 128 without spilling)
 #endif
@@ -1291,6 +1298,9 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   static_assert(CH == 3 || CH == 4 || CH == 5, "window kernel: RGB, RGBA or RGBAZ");
   static_assert(QMode != 2 || (OutLens != kEquidistant && InMode != kInEquidistant), "rows-only mirroring goes through the column-separable source x");
   static_assert(QMode != 3 || OutLens == kRect, "columns-only mirroring needs vz == -1");
+  static_assert(!GeoRead || (QMode == 0 && !Frames && OutLens == kRect), "GeoRead: plain blocks, single launches, one instantiation per source mode");
+  constexpr bool kGeoWrite = !GeoRead && !Frames && QMode == 0 && kWinWaves == 1; // (P.geo_mode == 1: the side output)
+  const bool geo_write = kGeoWrite && (Pk.geo_mode == 1 || Pk.geo_mode == 3);     // wave-uniform (3: the extremes only — the map is there)
   // Frames of a batched launch share one geometry: the source coordinates of a pixel, the window of a block and its tier
   // are the same in every frame.  A wavefront therefore renders its strip for `frames_per_wave` consecutive frames
   // (blockIdx.y = group of frames) and runs everything that does not depend on the pixel DATA — stage 1 of the coordinate
@@ -1318,7 +1328,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   constexpr bool kSplit = LRP_WIN_SPLIT != 0 && !Frames && (InMode == kInEquirect || InMode == kInEquirectLoop || (InMode == kInRect && CH == 5));
   // Pass windows (below) for rectilinear targets only — perspective views and cubemap faces out of a panorama; in the
   // fisheye-target kernels the extra code cost 2.5 % (equirect -> fisheye single launches 247 -> 253 us).
-  constexpr bool kPassWin = kSplit && LRP_WIN_PASSWIN != 0 && (OutLens == kRect || (InMode == kInRect && CH == 5));
+  constexpr bool kPassWin = kSplit && LRP_WIN_PASSWIN != 0 && (OutLens == kRect || GeoRead || (InMode == kInRect && CH == 5));
   constexpr int kPlanes = 3;
   __shared__ float4 s_win[kWinWaves][kWinCap];
 
@@ -1336,7 +1346,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   // Plain strips (the tables of a panorama are not mirror images bit for bit, so this is the kernel that runs):
   // the strip of tile (t, r) and the strip of tile (t + tiles_x/2, tiles_y-1-r) are the pair, the second one
   // walks its blocks bottom-up.
-  constexpr bool kAliasPairs = LRP_WIN_ALIAS_PAIRS != 0 && OutLens == kEquirect && InMode == kInRect && kWinWaves == 1;
+  constexpr bool kAliasPairs = LRP_WIN_ALIAS_PAIRS != 0 && (OutLens == kEquirect || GeoRead) && InMode == kInRect && kWinWaves == 1;
   int g_flip = 0;        // mirrored strips: the mirror image rendered by loop iteration g is g ^ g_flip
   bool g_reverse = false; // plain strips: iteration g renders block G-1-g
   if (kAliasPairs && P.alias_pairs != 0) {
@@ -1358,8 +1368,13 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   }
   const int lane = (int)(threadIdx.x & 63u);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int G = P.blocks_per_wave;
+  const int Gs = P.blocks_per_wave; // blocks per strip of this launch
+  // blocks this strip renders.  (A block wholly below the image re-renders the image's last row — every lane stores — which is
+  // how the compute kernels keep their store count.  GeoRead skips such blocks: the entry holds extremes only for the block
+  // rows the WRITING launch walked, and that launch may have cut its strips differently.)
+  const int G = GeoRead ? min(Gs, (P.y_end - P.y_offset + kBlkH - 1) / kBlkH - ty * Gs) : Gs;
   auto block_row = [&](int g) { return (kAliasPairs && g_reverse) ? G - 1 - g : g; }; // block of a plain strip rendered by iteration g
+  auto geo_block = [&](int g) { return (uint32_t)(ty * Gs + block_row(g)) * (uint32_t)P.tiles_x + (uint32_t)tx; }; // geometry cache: box record of a plain block
   // Mirrored blocks (Quad instantiations, launched when P.quad).  Without a rotation the mapping is symmetric
   // about both image axes: the pixels (x, y), (W-1-x, y), (x, H-1-y), (W-1-x, H-1-y) have
   // rays that differ in the signs of vx / vy only, every operation between the ray and the
@@ -1378,7 +1393,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   int prow, pcol; // this lane's pixel of a pass
   win_lane_pixel(lane, prow, pcol);
   const int x = tx * (kBlkW * kWinWaves) + wave * kBlkW + pcol;
-  const int y_lane = P.y_offset + ty * (quad ? kBlkH : kBlkH * G) + prow; // + kBlkH * g + kPassRows * pass
+  const int y_lane = P.y_offset + ty * (quad ? kBlkH : kBlkH * Gs) + prow; // + kBlkH * g + kPassRows * pass
   const int xe = x < qw ? x : qw - 1;
   const int in_w = P.in_w;
   SrcView src = source_view<2, CH>(P);
@@ -1388,13 +1403,14 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
     src = source_view<2, CH>(P);
   };
   float4 *const win0 = s_win[wave];
-  constexpr bool kRunsEverywhere = CH == 5 && OutLens == kEquirect && InMode == kInRect;
+  constexpr bool kRunsEverywhere = CH == 5 && (OutLens == kEquirect || GeoRead) && InMode == kInRect; // (GeoRead: and P.rgbaz_runs)
   float *out_lds = nullptr; // RGBAZ: the wavefront's exchange buffer of store_rgbaz_run (three waves per SIMD: the LDS is there)
   if constexpr (CH == 5) {
     __shared__ __attribute__((aligned(16))) float s_out[kWinWaves][320];
     out_lds = s_out[wave];
   }
-  const ColTerms col = column_terms<OutLens>(P, xe, 0);
+  ColTerms col{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  if constexpr (!GeoRead) col = column_terms<OutLens>(P, xe, 0);
   ColTerms col_m = col; // the mirrored column
   if constexpr (MirX && !kSharedRays) col_m = column_terms<OutLens>(P, P.out_w - 1 - xe, 0);
   // Stage-1 results of the four quadrant pixels of this lane, kept for the whole strip:
@@ -1729,10 +1745,56 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       }
       all_exact_x = all_exact_y = all_exact;
     }
-    if (kEdge ? true : (all_exact_x && all_exact_y)) {
+    const bool planned = kEdge ? true : (all_exact_x && all_exact_y);
+    if (planned) {
       wave_box(e.lo_x, e.hi_x, e.lo_y[0], e.hi_y[0], e.lo_y[1], e.hi_y[1]);
       plan_window(b, e.lo_x, e.hi_x, e.lo_y[0], e.hi_y[0], e.lo_y[1], e.hi_y[1], all_exact_x, all_exact_y);
     }
+    if constexpr (kGeoWrite) {
+      if (geo_write) { // side output: this block's coordinates and the extremes its window was planned from
+        vf2 *const map = reinterpret_cast<vf2 *>(P.geo_xy);
+        if (Pk.geo_mode == 1) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int yk = y_lane + kBlkH * block_row(g) + kPassRows * k;
+            const int ye = yk < qh ? yk : qh - 1;
+            // (lanes / rows beyond the image hold the pixel they were clamped to and write its values to its place again)
+            map[(uint32_t)ye * (uint32_t)P.out_w + (uint32_t)xe] = vf2{b.sx[k], b.sy[k]};
+          }
+        }
+        const int words[7] = {planned ? e.lo_x : 0, planned ? e.hi_x : 0, planned ? e.lo_y[0] : 0, planned ? e.hi_y[0] : 0,
+                              planned ? e.lo_y[1] : 0, planned ? e.hi_y[1] : 0,
+                              (all_exact_x ? 1 : 0) | (all_exact_y ? 2 : 0) | (planned ? 4 : 0)};
+        int bv = 0; // lane i = word i (written once per geometry: plain selects will do)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) bv = lane == i ? words[i] : bv;
+        if (lane < 8) P.geo_box[geo_block(g) * 8u + (uint32_t)lane] = bv;
+      }
+    }
+  };
+  // GeoRead: the coordinates of block g and (geo_boxv, lane i = word i) its window extremes are requested by geo_fetch and
+  // turned into a window plan by geo_plan, a few hundred instructions later
+  int geo_boxv = 0;
+  auto geo_fetch = [&](int g, WinBlock &b) {
+    // (the extremes first: loads return in order, and the first block of a strip plans its window before anything else)
+    geo_boxv = __builtin_nontemporal_load(P.geo_box + (geo_block(g) * 8u + (uint32_t)(lane & 7)));
+    const vf2 *const map = reinterpret_cast<const vf2 *>(P.geo_xy);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yk = y_lane + kBlkH * block_row(g) + kPassRows * k;
+      const int ye = yk < qh ? yk : qh - 1;
+      const vf2 v = __builtin_nontemporal_load(map + ((uint32_t)ye * (uint32_t)P.out_w + (uint32_t)xe));
+      b.sx[k] = v.x;
+      b.sy[k] = v.y;
+    }
+  };
+  auto geo_plan = [&](WinBlock &b) {
+    clear_block(b);
+    const int flags = __builtin_amdgcn_readlane(geo_boxv, 6);
+    if ((flags & 4) != 0)
+      plan_window(b, __builtin_amdgcn_readlane(geo_boxv, 0), __builtin_amdgcn_readlane(geo_boxv, 1),
+                  __builtin_amdgcn_readlane(geo_boxv, 2), __builtin_amdgcn_readlane(geo_boxv, 3),
+                  __builtin_amdgcn_readlane(geo_boxv, 4), __builtin_amdgcn_readlane(geo_boxv, 5), (flags & 1) != 0, (flags & 2) != 0);
   };
   // the one value of a corner block: sample_bicubic with all 16 taps on the corner texel (sample_direct's
   // one-column-and-one-row case, same operations)
@@ -1914,7 +1976,12 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   // may still be outstanding when the next block waits: vmcnt(1).  (Every lane stores,
   // see below, so that store is always issued.)
   WinBlock cur, nxt;
-  coords(0, cur);
+  if constexpr (GeoRead) {
+    geo_fetch(0, cur);
+    geo_plan(cur);
+  } else {
+    coords(0, cur);
+  }
   issue(P.src, cur);
   int g_loop = 0, f_loop = 0;
   bool dma_early = false; // the pending window was requested before its block's last store
@@ -1935,7 +2002,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
     if (dma_early) issue_next();
   };
   // The result of pass k of block g: num_samples == 1, (0.0f + s) * normalize (src/reproject.cpp:334-341), store.
-  auto emit = [&](int g, int k, const Rgba &s, auto as_runs) {
+  auto emit = [&](int g, int k, const Rgba &s, auto as_runs, bool runs_rt = true) {
     Rgba a4 = px_zero<4>();
     px_add<4>(a4, s);
     if constexpr (CH == 5) a4.e = 0.0f + s.e;
@@ -1963,8 +2030,8 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       // view or gathers minified taps; 383 -> 334 us).  In the VALU-bound kernels that interpolate from the LDS
       // window the exchange costs more than the stores gain (measured: 4-7 % slower).
       const int x_blk = tx * (kBlkW * kWinWaves) + wave * kBlkW;
-      const int y_top = P.y_offset + ty * (quad ? kBlkH : kBlkH * G) + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
-      if (x_blk + kBlkW <= qw && y_top + kPassRows <= qh) {
+      const int y_top = P.y_offset + ty * (quad ? kBlkH : kBlkH * Gs) + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
+      if (runs_rt && x_blk + kBlkW <= qw && y_top + kPassRows <= qh) {
         const bool mxo = quad && (gm & 1), myo = quad && (gm >> 1);
         float c[5];
         finish_px<5, true>(P, a, c);
@@ -2058,18 +2125,24 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
    g_loop = g;
    // plain blocks: the next block's coordinates here, long before its window is requested in the
    // last pass; mirrored blocks derive theirs in a few instructions right there (fewer live registers)
-   if ((!Quad || kSharedRays) && g + 1 < G) coords(g + 1, nxt); // (shared rays: the rotation and the source lens run per image, as for a plain block)
+   // (GeoRead: the next block's record is requested behind this block's wait and planned in front of its last pass — the
+   // loads are then older than the next window's DMA and the hand-counted vmcnt(1) below still holds)
+   if constexpr (!GeoRead)
+     if ((!Quad || kSharedRays) && g + 1 < G) coords(g + 1, nxt); // (shared rays: the rotation and the source lens run per image, as for a plain block)
 #pragma unroll 1
    for (int f = 0; f < n_frames; ++f) {
     f_loop = f;
     if (n_frames > 1 || g == 0) set_frame(f);
     const bool last_frame = f + 1 == n_frames; // the next step is the next block
 #if !defined(LRP_NO_DMA_WAIT) // timing experiment (wrong results): how much of the frame is exposed DMA / store latency
-    if ((g == 0 && f == 0) || !dma_early)
+    // (a launch that writes the geometry cache has the stores of coords(g + 1) in flight as well: it waits for everything)
+    if ((g == 0 && f == 0) || !dma_early || geo_write)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the window was the last thing requested
     else
       asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); // window g has landed; block g-1's last store may be in flight
 #endif
+    if constexpr (GeoRead)
+      if (g + 1 < G) geo_fetch(g + 1, nxt);
     const float4 *const win = win0;
     // The tier of this block in a scalar register for the branches below: carried through the block loop inside `cur` it
     // ends up in a VGPR (the kernel is at the SGPR limit), and every test of it then costs a v_and + v_cmp and the
@@ -2090,6 +2163,8 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       // window is requested in front of the last store, as in the last pass of an ordinary block.
       const Rgba cs = corner_value(cur);
       if (Quad && !kSharedRays && last_frame && g + 1 < G) coords(g + 1, nxt);
+      if constexpr (GeoRead)
+        if (g + 1 < G) geo_plan(nxt);
       emit(g, 0, cs, std::true_type{});
       emit(g, 1, cs, std::true_type{});
       emit(g, 2, cs, std::true_type{});
@@ -2110,6 +2185,8 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
         const int k = 2 * h + kk;
         const bool last_pass = k == 3;
         if (Quad && !kSharedRays && k == 3 && last_frame && g + 1 < G) coords(g + 1, nxt); // only its box is kept
+        if constexpr (GeoRead)
+          if (k == 3 && g + 1 < G) geo_plan(nxt);
         float psx = cur.sx[k], psy = cur.sy[k];
         if constexpr (Quad && !kSharedRays) quad_xy(image_of(g), k, psx, psy); // re-derived (2-4 instructions) instead of held in registers
         // (where the coordinates of a mirror image are a plain selection of stored values the compiler would otherwise
@@ -2285,7 +2362,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
             s = sample_direct<2, Loop, 4, false, 4 * CH>(P, src, psx, psy);
           }
         }
-        emit(g, k, s, std::integral_constant<bool, kRunsEverywhere>{});
+        emit(g, k, s, std::integral_constant<bool, kRunsEverywhere>{}, !GeoRead || P.rgbaz_runs != 0);
       }
     }
     if (!dma_early && has_next()) issue_next(); // after the last read of the planes
@@ -2328,12 +2405,13 @@ template <int Interp> hipError_t launch_tile_interp(KParams P, int out_idx, int 
   // Frames per wavefront of a batched launch (nearest / bilinear, one sample per pixel): as many as leave at least two
   // rounds of workgroups on the chip.
   int groups = P.batch_n > 0 ? P.batch_n : 1;
+  const int frames_override = P.frames_per_wave; // on entry: 0 = automatic
   P.frames_per_wave = 1;
   if (Interp != 2 && P.num_samples == 1 && P.batch_n > 1 && P.quad == 0) { // (the plain path: any rotation; the mirrored paths are bound by memory)
     const long long units = (long long)n_tiles * P.batch_n;
     int F = (int)std::min<long long>(P.batch_n, std::max<long long>(1, units / 4096));
     if (out_idx == 2 && in_mode == kInRect) F = 1; // (see the window kernel: uneven tiles)
-    if (const char *e = std::getenv("LRP_BATCH_FRAMES")) F = std::max(1, std::min(P.batch_n, std::atoi(e))); // A/B runs
+    if (frames_override > 0) F = std::max(1, std::min(P.batch_n, frames_override)); // the caller's override (lrp_debug_set "batch_frames": A/B runs, tests)
     P.frames_per_wave = F;
     groups = (P.batch_n + F - 1) / F;
   }
@@ -2379,10 +2457,22 @@ template <int QMode, int CH, bool Frames> struct WinKernelTable {
   }
 };
 
+// The GeoRead instantiations (plain blocks, coordinates from the geometry cache): one per source mode.
+template <int CH> struct WinGeoKernelTable {
+  static TileKernelFn get(int in_mode) {
+    static const TileKernelFn table[4] = {
+        reproject_bicubic_win_kernel<kRect, kInRect, 0, CH, false, true>, reproject_bicubic_win_kernel<kRect, kInEquidistant, 0, CH, false, true>,
+        reproject_bicubic_win_kernel<kRect, kInEquirect, 0, CH, false, true>, reproject_bicubic_win_kernel<kRect, kInEquirectLoop, 0, CH, false, true>};
+    return table[in_mode];
+  }
+};
+
 // num_samples must be 1 (the pipeline keeps no accumulator across sub-samples).  QMode != 0: P.win_mode == QMode,
-// set by the host only for cells where the mode exists.
-template <int QMode, int CH>
+// set by the host only for cells where the mode exists.  GeoRead: P.geo_mode == 2, a single whole-image launch.
+template <int QMode, int CH, bool GeoRead = false>
 inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, hipStream_t stream) {
+  static_assert(!GeoRead || QMode == 0, "the geometry cache feeds plain blocks");
+  if (GeoRead && (P.batch_n > 0 || P.geo_mode != 2 || P.y_offset != 0 || P.y_end != P.out_h)) return hipErrorInvalidValue;
   const int rows = P.y_end - P.y_offset;
   if (QMode != 0) {
     // the launch enumerates the top-left quadrant (the top / the left half when one axis is mirrored); a wavefront
@@ -2397,10 +2487,12 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
     // strips of LRP_WIN_STRIP blocks when that still leaves >= 8 workgroups per CU, else shorter
     const int row_blocks = (rows + kBlkH - 1) / kBlkH;
     int G = LRP_WIN_STRIP;
+    if (GeoRead && P.blocks_per_wave > 0) G = std::min(P.blocks_per_wave, kGeoStripRows); // the caller's override (lrp_debug_set "geo_strip")
     // (a batch whose wavefronts walk several frames pipelines the windows of one block across its frames: one block per
     // wavefront measured 2-3 % faster there — equirect -> fisheye rotated 143 -> 139 us, rect -> rect 130.5 -> 128 —, four 5 % slower)
     if (P.batch_n > 1 && !(out_idx == 2 && in_mode == kInRect)) G = 1;
-    while (G > 1 && (long long)P.tiles_x * kWinWaves * ((row_blocks + G - 1) / G) < 8192) G >>= 1; // >= 2 rounds of wavefronts
+    const bool strip_forced = GeoRead && P.blocks_per_wave > 0;
+    while (!strip_forced && G > 1 && (long long)P.tiles_x * kWinWaves * ((row_blocks + G - 1) / G) < 8192) G >>= 1; // >= 2 rounds of wavefronts
     P.blocks_per_wave = G;
     P.tiles_y = (row_blocks + G - 1) / G;
   }
@@ -2409,6 +2501,7 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
   // Frames per wavefront of a batched launch: as many as leave at least two rounds of wavefronts on the chip
   // (4096 wave slots), so that a 4K batch of 16 runs every strip through all 16 frames and small images keep the chip full.
   int groups = P.batch_n > 0 ? P.batch_n : 1;
+  const int frames_override = P.frames_per_wave; // on entry: 0 = automatic
   P.frames_per_wave = 1;
   if (P.batch_n > 1) {
     const long long units = (long long)n_tiles * kWinWaves * P.batch_n;
@@ -2416,11 +2509,15 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
     // a rectilinear view inside a panorama: a quarter of the strips (the ones in view) carry most of the frame's time and
     // gain nothing from shared coordinates (they wait for gathers) — 16 frames long they unbalance the launch (223 -> 256 us)
     if (out_idx == 2 && in_mode == kInRect) F = 1;
-    if (const char *e = std::getenv("LRP_BATCH_FRAMES")) F = std::max(1, std::min(P.batch_n, std::atoi(e))); // A/B runs
+    if (frames_override > 0) F = std::max(1, std::min(P.batch_n, frames_override)); // the caller's override (lrp_debug_set "batch_frames": A/B runs, tests)
     P.frames_per_wave = F;
     groups = (P.batch_n + F - 1) / F;
   }
-  const TileKernelFn fn = P.frames_per_wave > 1 ? WinKernelTable<QMode, CH, true>::get(out_idx, in_mode) : WinKernelTable<QMode, CH, false>::get(out_idx, in_mode);
+  TileKernelFn fn;
+  if constexpr (GeoRead)
+    fn = WinGeoKernelTable<CH>::get(in_mode);
+  else
+    fn = P.frames_per_wave > 1 ? WinKernelTable<QMode, CH, true>::get(out_idx, in_mode) : WinKernelTable<QMode, CH, false>::get(out_idx, in_mode);
   if (!fn) return hipErrorInvalidValue; // (the host never asks for a mode outside its cells)
   hipLaunchKernelGGL(fn, dim3((unsigned)(kXcds * xcd_rows(P.tiles_y, kWinXcdBand) * P.tiles_x), (unsigned)groups), dim3(kWinThreads), 0, stream, P);
   return hipGetLastError();

@@ -88,6 +88,35 @@ struct KParams {
   int32_t win_mode;                 // window kernel: 0 plain blocks, 1 blocks mirrored in both axes (== quad 1), 2 rows only (pan), 3 columns only (pitch), 4 shared rays (equidistant target, any rotation)
   int32_t win_edge;    // window kernel: blocks beyond one side of the source stage one source row / column (LRP_WIN_EDGE=0: per-pixel gathers)
   int32_t win_split;   // window kernel: blocks whose window exceeds the buffer stage the windows of their two halves one after the other (LRP_WIN_SPLIT=0: per-pixel gathers)
+  // Geometry cache (lrp_geocache.h): what a single launch would re-derive from the geometry alone — the source
+  // coordinates of every output pixel and, for the window kernel, the window extremes of every 16 x 16 block — kept in
+  // HBM between calls.  geo_mode 0: not used; 1: this launch computes as usual and writes the entry as a side output;
+  // 2: it loads instead of computing (the GeoRead instantiations; same values, hence the same bits).
+  int32_t geo_mode;
+  float *geo_xy;       // [out_h][out_w] (sx, sy): the top-left-origin source texel coordinates of src/reproject.cpp:323-324
+  int32_t *geo_box;    // window kernel: [block rows][blocks_x][8] (geo_layout below)
+  int32_t rgbaz_runs;  // GeoRead window kernel, RGBAZ: every block leaves as 16-byte chunks (what the rectilinear -> panorama instantiations do at compile time)
 };
+
+// A geometry-cache entry (num_samples == 1, whole images): the coordinate map and, for the window kernel, per 16 x 16
+// block (block row * blocks_x + block column) 8 words — lo_x, hi_x, lo_y / hi_y of passes 0-1, lo_y / hi_y of passes 2-3
+// (float bits of the wave-wide extremes of the block's coordinates), flags (bit 0 / 1: the taps of every pixel are
+// consecutive in x / y, bit 2: a window was planned from these), 0.
+constexpr int kGeoStripRows = 16; // block rows are allocated in multiples of the longest strip a GeoRead launch may walk
+struct GeoLayout {
+  size_t xy_bytes, box_bytes;
+  size_t bytes() const { return xy_bytes + box_bytes; }
+};
+inline GeoLayout geo_layout(int out_w, int out_h, bool with_boxes) {
+  GeoLayout L{};
+  L.xy_bytes = (size_t)out_w * (size_t)out_h * 8;
+  if (with_boxes) {
+    const size_t bx = (size_t)(out_w + 15) / 16;
+    size_t by = (size_t)(out_h + 15) / 16;
+    by = (by + kGeoStripRows - 1) / kGeoStripRows * kGeoStripRows;
+    L.box_bytes = bx * by * 32;
+  }
+  return L;
+}
 
 } // namespace lrp

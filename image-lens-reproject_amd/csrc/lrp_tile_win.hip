@@ -17,9 +17,18 @@ hipError_t launch_win_bicubic_c5_m0(const KParams &P, int out_idx, int in_mode, 
 hipError_t launch_win_bicubic_c5_m1(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winq5.hip
 hipError_t launch_win_bicubic_c5_m2(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winy5.hip
 hipError_t launch_win_bicubic_c5_m3(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winx5.hip
+hipError_t launch_win_bicubic_geo_c3(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_wing3.hip
+hipError_t launch_win_bicubic_geo_c4(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_wing.hip
+hipError_t launch_win_bicubic_geo_c5(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_wing5.hip
 // P.channels must be 3, 4 or 5, P.num_samples 1; P.win_mode = the mirror mode (lrp_kernel_v2.h QMode).
+// P.geo_mode == 2: the instantiations that load their coordinates from the geometry cache (plain blocks).
 hipError_t launch_win_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream) {
   using Fn = hipError_t (*)(const KParams &, int, int, hipStream_t);
+  if (P.geo_mode == 2) {
+    static const Fn geo_table[3] = {launch_win_bicubic_geo_c3, launch_win_bicubic_geo_c4, launch_win_bicubic_geo_c5};
+    if (P.win_mode != 0) return hipErrorInvalidValue;
+    return geo_table[P.channels - 3](P, out_idx, in_mode, stream);
+  }
   static const Fn table[3][5] = {
       {launch_win_bicubic_c3_m0, launch_win_bicubic_c3_m1, launch_win_bicubic_c3_m2, launch_win_bicubic_c3_m3, launch_win_bicubic_c3_m4},
       {[](const KParams &Q, int o, int i, hipStream_t s) { return launch_win_bicubic_impl<0, 4>(Q, o, i, s); }, launch_win_bicubic_c4_m1,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LRP_ABI_VERSION 2
+#define LRP_ABI_VERSION 3
 
 /* ---- enums: numbering identical to the reference's ------------------------ */
 
@@ -114,9 +114,38 @@ const char *lrp_last_error(void);
  * threads and returns the previous one; an out-of-range value only queries.
  * The environment variable LRP_KERNEL=pixel|tile|window-raw sets the initial value. */
 int lrp_debug_kernel(int choice);
-/* Frees the cached per-output-lens tables of every device (after synchronising
- * them).  Optional: the cache is bounded and reused across calls. */
+/* The other testing / A-B switches, by name: "kernel" (as lrp_debug_kernel), "xsep", "quad", "mirror_modes",
+ * "win_edge", "win_split", "geo_cache" (0 / 1: a sharing or staging path of the tile / window kernels off / on — the bits
+ * do not change), "batch_frames" (frames per wavefront of a batched launch, 0 = automatic),
+ * "multi_fork" (side streams of lrp_reproject_multi_device, 0-5).  Sets the value for subsequent calls of all threads
+ * and returns the previous one; a value outside the switch's range only queries; an unknown name returns -1.  The
+ * environment variables LRP_XSEP, LRP_QUAD, ... supply the initial values once, when the library is loaded. */
+int lrp_debug_set(const char *name, int value);
+/* Frees the cached per-output-lens tables and the geometry cache of every device (after
+ * synchronising them).  Optional: both caches are bounded and reused across calls. */
 void lrp_release_cached_tables(void);
+
+/* ---- geometry cache ---------------------------------------------------------- */
+
+/* The reference renders a whole run with ONE geometry — lenses, sizes and rotation are command-line
+ * constants, only the pixels change from file to file (src/main.cpp:576-598) — and derives the source
+ * coordinates of every output pixel again for every file (src/reproject.cpp:287-324).  Here the first
+ * single-image bicubic launch of a geometry (lrp_reproject, lrp_reproject_device,
+ * lrp_reproject_multi_device, lrp_context_submit*) leaves those coordinates in device memory as a side
+ * output (8 bytes per output pixel + 2 per 16 pixels) and later launches of the same geometry on that device load them
+ * instead of computing them: same values, same rendered bits, 1.2-1.9x the kernel rate.  Keyed on
+ * (device, both lenses, both sizes, rotation); least recently used entries are dropped when
+ * `max_bytes` per device would be exceeded; a launch being captured into a hipGraph does not use it.
+ *   max_bytes      bytes per device (default 1 GiB); 0 switches the cache off and frees it; < 0 keeps the value
+ *   min_sightings  a geometry is cached from its n-th launch on (default 1; 2 suits callers whose
+ *                  rotation changes with every call — the library switches to 2 by itself after
+ *                  evicting several entries that were never read); < 1 keeps the value */
+int lrp_geometry_cache_configure(long long max_bytes, int min_sightings);
+typedef struct lrp_geometry_cache_info {
+  uint64_t bytes, max_bytes, entries; /* device memory held now (all devices), the per-device limit, geometries held */
+  uint64_t fills, hits, bypasses, evictions; /* launches that wrote an entry / read one / ran without the cache; entries dropped */
+} lrp_geometry_cache_info;
+void lrp_geometry_cache_stats(lrp_geometry_cache_info *out);
 
 /* ---- one image, host buffers (the reference's calling convention) ---------- */
 

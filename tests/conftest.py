@@ -77,6 +77,21 @@ def pytest_sessionfinish(session, exitstatus):
         session.exitstatus = 1
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _geometry_cache_scope(request):
+    """The geometry cache turns every single bicubic launch into "plain blocks + side output" (first call of a geometry)
+    or "coordinates from HBM" (later calls).  The modules written for the compute kernels — mirror modes, edge / split
+    blocks, the kernel families — switch it off so that they keep testing those; tests/test_gpu_geocache.py and
+    tests/test_gpu_knobs.py (USES_GEO_CACHE = True) run with the product's default."""
+    if "gpu" not in getattr(request.module, "__name__", "") or getattr(request.module, "USES_GEO_CACHE", False):
+        yield
+        return
+    mod = importlib.import_module("image-lens-reproject_amd")
+    prev = mod.debug_set("geo_cache", 0)
+    yield
+    mod.debug_set("geo_cache", prev)
+
+
 @pytest.fixture(scope="session")
 def torch_cuda():
     import torch

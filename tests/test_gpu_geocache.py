@@ -1,0 +1,283 @@
+"""-m gpu: the geometry cache (csrc/lrp_geocache.cpp, the GeoRead window kernels).
+
+The first single bicubic launch of a geometry writes the source coordinates of every output pixel and the window
+extremes of every block as a side output; later launches of the same geometry load them.  Both must give the
+reference's bits: every comparison here is against COMMITTED oracle digests (tests/golden/), once for the launch that
+fills an entry and once for a launch that reads it — with different pixels in between, the geometry is what is cached."""
+import importlib
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import cases
+import fullframe_cases as ffc
+import golden_cases
+
+pytestmark = pytest.mark.gpu
+USES_GEO_CACHE = True
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "fullframe_golden.json")) as _f:
+    FULL = json.load(_f)
+with open(os.path.join(HERE, "golden", "oracle_golden.json")) as _f:
+    SMALL = json.load(_f)
+
+
+@pytest.fixture(autouse=True)
+def _fresh_cache(lrp):
+    lrp.debug_set("geo_cache", 1)
+    lrp.geometry_cache_configure(1 << 30, 1)
+    lrp.release_cached_tables()
+    yield
+    lrp.geometry_cache_configure(1 << 30, 1)
+    lrp.release_cached_tables()
+
+
+class _DeviceSynth:
+    def __init__(self, lrp, torch):
+        self.lrp, self.torch = lrp, torch
+
+    def synth_frame(self, width, height, channels, seed, depth_channel=-1):
+        t = self.torch.empty((height, width, channels), dtype=self.torch.float32, device="cuda")
+        self.lrp.synth_fill(t, width, height, channels, seed, depth_channel)
+        self.torch.cuda.synchronize()
+        return t.cpu().numpy()
+
+
+def _bicubic_cases(lrp):
+    return [(n, c) for n, c in golden_cases.all_cases(lrp) if c["interp"] == 2 and c["ns"] == 1]
+
+
+def _small_setup(lrp, torch, case):
+    src = golden_cases.planted_input(_DeviceSynth(lrp, torch), case["iw"], case["ih"], case["c"], case["seed"])
+    lin = cases.lenses(lrp, case["iw"], case["ih"])[case["inp"]]
+    lout = cases.lenses(lrp, case["ow"], case["oh"])[case["out"]]
+    rot = cases.rotation(lrp, golden_cases.ROTS[case["rot"]])
+    return src, lin, lout, rot
+
+
+def _small_render(lrp, torch, case, d_in, lin, lout, rot, stream=None):
+    d_out = torch.full((case["oh"], case["ow"], case["c"]), -12345.0, dtype=torch.float32, device="cuda")
+    lrp.reproject(lrp.Image(lin, case["iw"], case["ih"], case["c"], d_in),
+                  lrp.Image(lout, case["ow"], case["oh"], case["c"], d_out), 1, 2, rot, stream=stream)
+    return d_out
+
+
+def test_small_matrix_fill_then_read(lrp, torch_cuda):
+    """Every single-sample bicubic case of the 216-case matrix: the launch that fills the entry, a launch on OTHER
+    pixels that reads it, and a third launch on the case's pixels that reads it again."""
+    torch = torch_cuda
+    todo = _bicubic_cases(lrp)
+    assert len(todo) >= 20
+    for name, case in todo:
+        src, lin, lout, rot = _small_setup(lrp, torch, case)
+        d_in = torch.from_numpy(src).cuda()
+        before = lrp.geometry_cache_stats()
+        first = _small_render(lrp, torch, case, d_in, lin, lout, rot)
+        other = torch.rand_like(d_in)
+        _small_render(lrp, torch, case, other, lin, lout, rot)
+        again = _small_render(lrp, torch, case, d_in, lin, lout, rot)
+        torch.cuda.synchronize()
+        after = lrp.geometry_cache_stats()
+        assert after["fills"] == before["fills"] + 1 and after["hits"] == before["hits"] + 2, (name, before, after)
+        assert golden_cases.digest(first.cpu().numpy()) == SMALL["reproject"][name], f"{name}: the filling launch"
+        assert golden_cases.digest(again.cpu().numpy()) == SMALL["reproject"][name], f"{name}: the reading launch"
+
+
+@pytest.mark.parametrize("channels", [3, 4, 5])
+def test_lens_pairs_channels_rotations_against_the_live_oracle(lrp, oracle, torch_cuda, channels):
+    """The committed matrix only holds RGB cases for single-sample bicubic: every lens pair x rotation for RGB, RGBA and
+    RGBAZ against the oracle run here — filling launch, reading launch, and every strip length of the reading kernel."""
+    torch = torch_cuda
+    k = 0
+    for out_name in ("rect", "eqd180", "eqr_full"):
+        for in_name in ("rect", "eqd180", "eqr_full", "eqr_part"):
+            k += 1
+            rot_name = list(golden_cases.ROTS)[k % 5]
+            iw, ih, ow, oh = (61, 47, 53, 41) if k % 2 else (96, 80, 72, 67)
+            case = dict(iw=iw, ih=ih, ow=ow, oh=oh, out=out_name, inp=in_name, interp=2, c=channels, ns=1, rot=rot_name,
+                        seed=0x6E0 + 16 * k + channels)
+            want = golden_cases.run_oracle(oracle, lrp, case)
+            src, lin, lout, rot = _small_setup(lrp, torch, case)
+            d_in = torch.from_numpy(src).cuda()
+            first = _small_render(lrp, torch, case, d_in, lin, lout, rot)
+            torch.cuda.synchronize()
+            cases.assert_same_bits(first.cpu().numpy(), want, f"fill {out_name} <- {in_name} C={channels} {rot_name}")
+            for strip in (0, 1, 2, 4):
+                prev = lrp.debug_set("geo_strip", strip)
+                again = _small_render(lrp, torch, case, d_in, lin, lout, rot)
+                torch.cuda.synchronize()
+                lrp.debug_set("geo_strip", prev)
+                cases.assert_same_bits(again.cpu().numpy(), want, f"read (strip {strip}) {out_name} <- {in_name} C={channels} {rot_name}")
+
+
+FRAMES = ["config1_4k_eqd_rect_bc", "northstar_4k_eqr_rect_bc", "scaling_4k_eqr_eqd_bc_rot", "config3_4k_rgbaz_rect_eqr_bc_post",
+          "config3_4k_rgbz_rect_eqr_bc_post", "config4_8k_rgb_face0", "config4_8k_rgb_face1", "config4_8k_rgb_face4",
+          "4k_eqr_rect_bc_rot", "4k_eqr_rect_bc_pan90", "4k_eqr_rect_bc_pitch90", "4k_rect_rect_bc_rot", "4k_eqd_eqd_bc_rot",
+          "4k_eqr_eqr_bc_rot", "4k_rect_eqr_bc", "4k_rgb_eqd_rect_bc", "4k_rgb_eqr_rect_bc_rot", "4k_rgbaz_eqd_rect_bc",
+          "4k_rgbaz_eqr_rect_bc_rot"]
+
+
+def _frame(lrp, torch, case, seed):
+    n, m, c = case["size"], case["out_size"], case["c"]
+    d_in = torch.empty((n, n, c), dtype=torch.float32, device="cuda")
+    lrp.synth_fill(d_in, n, n, c, seed, case.get("depth", -1))
+    lin, lout = cases.lenses(lrp, n, n)[case["inp"]], cases.lenses(lrp, m, m)[case["out"]]
+    d_out = torch.full((m, m, c), -12345.0, dtype=torch.float32, device="cuda")
+    lrp.reproject(lrp.Image(lin, n, n, c, d_in), lrp.Image(lout, m, m, c, d_out), 1, case["interp"],
+                  cases.rotation(lrp, case["deg"]), post=tuple(case["post"]) if case.get("post") else None)
+    torch.cuda.synchronize()
+    return d_out
+
+
+@pytest.mark.parametrize("name", FRAMES)
+def test_whole_frames_filled_and_read(lrp, torch_cuda, name):
+    """Whole frames at BASELINE.json's sizes: the entry is filled by a launch on another frame (seed + 99), then the
+    case's frame is rendered from the cached coordinates and must reproduce the committed oracle digest, band by band."""
+    torch = torch_cuda
+    case, want = ffc.frame_cases()[name], FULL["frames"][name]
+    _frame(lrp, torch, case, case["seed"] + 99)
+    st = lrp.geometry_cache_stats()
+    assert st["fills"] >= 1 and st["entries"] == 1, st
+    d_out = _frame(lrp, torch, case, case["seed"])
+    assert lrp.geometry_cache_stats()["hits"] == st["hits"] + 1
+    sha, bands, n_nan = ffc.frame_digests(d_out.cpu().numpy())
+    bad = [b for b in range(ffc.BANDS) if bands[b] != want["bands"][b]]
+    assert not bad, f"{name}: row bands {bad} of {ffc.BANDS} differ from the committed oracle digest (cached coordinates)"
+    assert sha == want["sha256"] and n_nan == want["nan"]
+
+
+def test_filling_launch_equals_committed_digest(lrp, torch_cuda):
+    """... and the launch that FILLS the entry (plain blocks + side output) on the case's own pixels."""
+    torch = torch_cuda
+    for name in ("config1_4k_eqd_rect_bc", "config3_4k_rgbaz_rect_eqr_bc_post", "config4_8k_rgb_face4"):
+        case, want = ffc.frame_cases()[name], FULL["frames"][name]
+        fills = lrp.geometry_cache_stats()["fills"]
+        d_out = _frame(lrp, torch, case, case["seed"])
+        assert lrp.geometry_cache_stats()["fills"] == fills + 1
+        assert ffc.frame_digests(d_out.cpu().numpy())[0] == want["sha256"], name
+
+
+def test_eviction_under_a_small_cap(lrp, torch_cuda):
+    """Three geometries alternate under a cap that holds two: entries are evicted and re-filled, the bits stay."""
+    torch = torch_cuda
+    todo = _bicubic_cases(lrp)[:3]
+    assert len(todo) == 3
+    setups = []
+    for name, case in todo:
+        src, lin, lout, rot = _small_setup(lrp, torch, case)
+        setups.append((name, case, torch.from_numpy(src).cuda(), lin, lout, rot))
+    one = 53 * 41 * 8 + 4 * 16 * 32  # bytes of one entry of the odd-sized cases (map + boxes, rows of blocks padded to 16)
+    lrp.geometry_cache_configure(int(2.5 * one), 1)
+    before = lrp.geometry_cache_stats()
+    for rnd in range(4):
+        for name, case, d_in, lin, lout, rot in setups:
+            out = _small_render(lrp, torch, case, d_in, lin, lout, rot)
+            out2 = _small_render(lrp, torch, case, d_in, lin, lout, rot)
+            torch.cuda.synchronize()
+            assert golden_cases.digest(out.cpu().numpy()) == SMALL["reproject"][name], (rnd, name)
+            assert golden_cases.digest(out2.cpu().numpy()) == SMALL["reproject"][name], (rnd, name)
+    after = lrp.geometry_cache_stats()
+    assert after["evictions"] > before["evictions"] and after["entries"] <= 2 and after["bytes"] <= after["max_bytes"], after
+    assert after["hits"] >= before["hits"] + 12
+
+
+def test_min_sightings_and_switch(lrp, torch_cuda):
+    torch = torch_cuda
+    name, case = _bicubic_cases(lrp)[0]
+    src, lin, lout, rot = _small_setup(lrp, torch, case)
+    d_in = torch.from_numpy(src).cuda()
+    lrp.geometry_cache_configure(-1, 2)
+    s0 = lrp.geometry_cache_stats()
+    outs = [_small_render(lrp, torch, case, d_in, lin, lout, rot) for _ in range(3)]
+    torch.cuda.synchronize()
+    s1 = lrp.geometry_cache_stats()
+    assert (s1["bypasses"] - s0["bypasses"], s1["fills"] - s0["fills"], s1["hits"] - s0["hits"]) == (1, 1, 1)
+    prev = lrp.debug_set("geo_cache", 0)
+    outs.append(_small_render(lrp, torch, case, d_in, lin, lout, rot))
+    torch.cuda.synchronize()
+    lrp.debug_set("geo_cache", prev)
+    assert lrp.geometry_cache_stats()["hits"] == s1["hits"]
+    lrp.geometry_cache_configure(0, -1)  # off: frees everything, every launch computes
+    assert lrp.geometry_cache_stats()["entries"] == 0
+    outs.append(_small_render(lrp, torch, case, d_in, lin, lout, rot))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert golden_cases.digest(o.cpu().numpy()) == SMALL["reproject"][name]
+
+
+def test_concurrent_callers_share_entries(lrp, torch_cuda):
+    """Four host threads, each with its own stream, render the same three geometries at the same time (the reference's
+    -j N pool threads, src/main.cpp:538-544): one of them fills each entry, the others wait for it on the device or
+    compute for themselves, everybody gets the oracle's bits."""
+    torch = torch_cuda
+    todo = _bicubic_cases(lrp)[:3]
+    setups = []
+    for name, case in todo:
+        src, lin, lout, rot = _small_setup(lrp, torch, case)
+        setups.append((name, case, torch.from_numpy(src).cuda(), lin, lout, rot))
+    errors = []
+    barrier = threading.Barrier(4)
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream()
+            barrier.wait()
+            for rnd in range(6):
+                for name, case, d_in, lin, lout, rot in setups[k % 3:] + setups[:k % 3]:
+                    out = _small_render(lrp, torch, case, d_in, lin, lout, rot, stream=stream)
+                    stream.synchronize()
+                    if golden_cases.digest(out.cpu().numpy()) != SMALL["reproject"][name]:
+                        errors.append((k, rnd, name))
+        except Exception as exc:  # noqa: BLE001
+            errors.append((k, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    st = lrp.geometry_cache_stats()
+    assert st["entries"] == 3 and st["hits"] > 0
+
+
+def test_concurrent_whole_frames_on_two_streams(lrp, torch_cuda):
+    """A reader on another stream than the writer's must wait for the writer on the DEVICE: the fill of a 4K frame
+    takes ~200 us, the second stream's launch is enqueued microseconds later."""
+    torch = torch_cuda
+    name = "4k_eqr_rect_bc_rot"
+    case, want = ffc.frame_cases()[name], FULL["frames"][name]
+    n, c = case["size"], case["c"]
+    lin, lout = cases.lenses(lrp, n, n)[case["inp"]], cases.lenses(lrp, n, n)[case["out"]]
+    rot = cases.rotation(lrp, case["deg"])
+    d_in = torch.empty((n, n, c), dtype=torch.float32, device="cuda")
+    lrp.synth_fill(d_in, n, n, c, case["seed"])
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = [torch.full((n, n, c), -1.0, dtype=torch.float32, device="cuda") for _ in range(4)]
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        lrp.reproject(lrp.Image(lin, n, n, c, d_in), lrp.Image(lout, n, n, c, o), 1, 2, rot, stream=(s1 if i % 2 == 0 else s2))
+    torch.cuda.synchronize()
+    st = lrp.geometry_cache_stats()
+    assert st["fills"] >= 1 and st["hits"] >= 2, st
+    for o in outs:
+        assert ffc.frame_digests(o.cpu().numpy())[0] == want["sha256"]
+
+
+def test_host_buffer_entry_points_use_the_cache(lrp, torch_cuda):
+    """lrp_reproject (what the C++ drop-in calls) and the batch context on host buffers."""
+    name, case = _bicubic_cases(lrp)[3]
+    src, lin, lout, rot = _small_setup(lrp, torch_cuda, case)
+    s0 = lrp.geometry_cache_stats()
+    for _ in range(3):
+        out = np.full((case["oh"], case["ow"], case["c"]), -1.0, dtype=np.float32)
+        lrp.reproject(lrp.Image(lin, case["iw"], case["ih"], case["c"], src), lrp.Image(lout, case["ow"], case["oh"], case["c"], out),
+                      1, 2, rot)
+        assert golden_cases.digest(out) == SMALL["reproject"][name]
+    s1 = lrp.geometry_cache_stats()
+    assert s1["fills"] == s0["fills"] + 1 and s1["hits"] == s0["hits"] + 2

@@ -7,8 +7,9 @@
 //
 // Build (tools/build_kbench.sh):
 //   hipcc -O2 -std=c++17 tools/kbench.cpp -Iinclude -L<pkg>/lib -llrp_hip -Wl,-rpath,<pkg>/lib -o tools/kbench
-// Usage: kbench [--size N] [--reps R] [--warmup W] [--distinct D] [--channels C] [--ns S] [--batch B] [--sum] [workload ...]
+// Usage: kbench [--size N] [--reps R] [--warmup W] [--distinct D] [--channels C] [--ns S] [--batch B] [--geo 0|1] [--set name=value] [--sum] [workload ...]
 //   --batch B: every launch renders B frames (lrp_reproject_batch_device, B <= distinct); times are per launch / B
+//   --geo 0: single launches compute their coordinates in every launch (geometry cache off); --set: lrp_debug_set
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
@@ -114,6 +115,15 @@ int main(int argc, char **argv) {
     else if (a == "--channels") channels = next();
     else if (a == "--ns") ns = next();
     else if (a == "--batch") batch = next();
+    else if (a == "--geo") lrp_debug_set("geo_cache", next());
+    else if (a == "--set" && i + 1 < argc) {
+      std::string kv = argv[++i];
+      const size_t eq = kv.find('=');
+      if (eq == std::string::npos || lrp_debug_set(kv.substr(0, eq).c_str(), atoi(kv.c_str() + eq + 1)) < 0) {
+        fprintf(stderr, "bad --set %s\n", kv.c_str());
+        return 1;
+      }
+    }
     else if (a == "--sum") sum = true;
     else if (a == "--post") post = true;
     else names.push_back(a);
@@ -156,8 +166,8 @@ int main(int argc, char **argv) {
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
   const char *kv = getenv("LRP_KERNEL");
-  printf("# size %d -> %d, C=%d, ns=%d, reps=%d, distinct=%d, LRP_KERNEL=%s\n", size, out_size, channels, ns, reps, distinct,
-         kv ? kv : "(default)");
+  printf("# size %d -> %d, C=%d, ns=%d, reps=%d, distinct=%d, batch=%d, LRP_KERNEL=%s, geo_cache=%d\n", size, out_size, channels, ns, reps,
+         distinct, batch, kv ? kv : "(default)", lrp_debug_set("geo_cache", -1));
   for (const auto &nm : names) {
     const Workload *W = nullptr;
     for (const auto &w : kWorkloads)
