@@ -317,7 +317,10 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     // Geometry cache (lrp_geocache.h): a single whole-image launch of the window kernel loads the coordinates of its
     // pixels and the window extremes of its blocks when an earlier launch of the same geometry has left them in HBM,
     // and leaves them there when it is the first.  Both run plain blocks: the entry is a plain per-pixel map.
-    if (window && n_batch <= 0 && !band && kernel_choice() == 2 && knob(kKnobGeoCache) != 0) {
+    // (... and the batched launches of a rectilinear view rendered into a panorama, whose wavefronts render one frame each:
+    // the in-view strips of that mapping wait for gathers and gain nothing from walking several frames.)
+    const bool batch_by_frame = n_batch > 0 && oi == 2 && im == lrp::kInRect;
+    if (window && (n_batch <= 0 || batch_by_frame) && !band && kernel_choice() == 2 && knob(kKnobGeoCache) != 0) {
       lrp::GeoKey key;
       std::memset(&key, 0, sizeof(key));
       key.device = device;
@@ -345,7 +348,6 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     };
     if (n_batch <= 0) {
       e = launch();
-      lrp::geo_launched(&geo, stream, e == hipSuccess);
     } else {
       e = hipSuccess;
       for (int first = 0; first < n_batch && e == hipSuccess; first += lrp::kMaxBatch) {
@@ -355,8 +357,10 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
           P.batch_dst[i] = out[first + i].data;
         }
         e = launch();
+        if (P.geo_mode == 1 || P.geo_mode == 3) P.geo_mode = 2; // the first launch wrote the entry; the rest of this call follows it on the same stream
       }
     }
+    lrp::geo_launched(&geo, stream, e == hipSuccess);
   } else {
     const int n = n_batch > 0 ? n_batch : 1;
     e = hipSuccess;

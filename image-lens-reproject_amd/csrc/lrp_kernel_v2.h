@@ -1288,7 +1288,10 @@ template <int OutLens, int InMode, int QMode, int CH, bool Frames = false, bool 
 #ifndef LRP_WIN_MINWAVES_FRAMES
 #define LRP_WIN_MINWAVES_FRAMES 4 // the instantiations with the frame loop
 #endif
-__global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode == 4 ? LRP_WIN_MINWAVES_RAYS : (Frames ? LRP_WIN_MINWAVES_FRAMES : (QMode >= 2 ? LRP_WIN_MINWAVES_AXIS : LRP_WIN_MINWAVES)))) void reproject_bicubic_win_kernel(const KParams Pk) {
+#ifndef LRP_WIN_CAP_BIG
+#define LRP_WIN_CAP_BIG 1280 // window slots of the big-window GeoRead variant: 20 KiB per wavefront, two wavefronts per SIMD
+#endif
+__global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 : CH == 5 ? LRP_WIN_MINWAVES5 : (QMode == 4 ? LRP_WIN_MINWAVES_RAYS : (Frames ? LRP_WIN_MINWAVES_FRAMES : (QMode >= 2 ? LRP_WIN_MINWAVES_AXIS : LRP_WIN_MINWAVES)))) void reproject_bicubic_win_kernel(const KParams Pk) {
   constexpr bool Quad = QMode != 0;
   constexpr bool MirX = QMode == 1 || QMode == 3 || QMode == 4, MirY = QMode == 1 || QMode == 2 || QMode == 4;
   constexpr bool kSharedRays = QMode == 4; // only the ray through the output lens is shared: per-image coordinates are stored like a plain block's
@@ -1298,9 +1301,19 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   static_assert(CH == 3 || CH == 4 || CH == 5, "window kernel: RGB, RGBA or RGBAZ");
   static_assert(QMode != 2 || (OutLens != kEquidistant && InMode != kInEquidistant), "rows-only mirroring goes through the column-separable source x");
   static_assert(QMode != 3 || OutLens == kRect, "columns-only mirroring needs vz == -1");
-  static_assert(!GeoRead || (QMode == 0 && !Frames && OutLens == kRect), "GeoRead: plain blocks, single launches, one instantiation per source mode");
+  static_assert(!GeoRead || (QMode == 0 && !Frames && (OutLens == kRect || (OutLens == kEquirect && InMode == kInRect))),
+                "GeoRead: plain blocks, no frame loop, one instantiation per source mode (+ the big-window variant of the rectilinear source)");
+  // The big-window variant (GeoRead, "OutLens" kEquirect by convention; chosen by the host for a rectilinear view rendered
+  // into a panorama, BASELINE configs[3]): the in-view blocks of that mapping are minified 3-5 x 1.5-3 — the window of a 16 x 4
+  // PASS is ~67 x 11 texels, too wide for one DMA instruction per row and too large for 10 KiB next to three other
+  // wavefronts' — so this variant holds 20 KiB per wavefront (two wavefronts per SIMD, no register limit to speak of) and
+  // stages pass windows up to 128 texels wide.  tools/microbench/row_gather.hip: rows of that shape arrive at 7.7 TB/s by
+  // LDS-DMA with 8 wavefronts per CU, a window each in flight; per-pixel gathers of the same bytes at 4.5 TB/s in this kernel.
+  constexpr bool kBigWin = GeoRead && OutLens == kEquirect;
+  constexpr int kCap = kBigWin ? LRP_WIN_CAP_BIG : kWinCap; // 16-byte slots of this instantiation's window buffer
+  constexpr int kMaxPassCols = kBigWin ? 128 : 64;          // widest pass window (texels): DMA instructions per window row = ceil(bw / 64)
   constexpr bool kGeoWrite = !GeoRead && !Frames && QMode == 0 && kWinWaves == 1; // (P.geo_mode == 1: the side output)
-  const bool geo_write = kGeoWrite && (Pk.geo_mode == 1 || Pk.geo_mode == 3);     // wave-uniform (3: the extremes only — the map is there)
+  const bool geo_write = kGeoWrite && (Pk.geo_mode == 1 || Pk.geo_mode == 3) && blockIdx.y == 0; // wave-uniform (3: the extremes only — the map is there; a batched launch: its first frame writes)
   // Frames of a batched launch share one geometry: the source coordinates of a pixel, the window of a block and its tier
   // are the same in every frame.  A wavefront therefore renders its strip for `frames_per_wave` consecutive frames
   // (blockIdx.y = group of frames) and runs everything that does not depend on the pixel DATA — stage 1 of the coordinate
@@ -1328,9 +1341,9 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   constexpr bool kSplit = LRP_WIN_SPLIT != 0 && !Frames && (InMode == kInEquirect || InMode == kInEquirectLoop || (InMode == kInRect && CH == 5));
   // Pass windows (below) for rectilinear targets only — perspective views and cubemap faces out of a panorama; in the
   // fisheye-target kernels the extra code cost 2.5 % (equirect -> fisheye single launches 247 -> 253 us).
-  constexpr bool kPassWin = kSplit && LRP_WIN_PASSWIN != 0 && (OutLens == kRect || GeoRead || (InMode == kInRect && CH == 5));
+  constexpr bool kPassWin = (kSplit || (GeoRead && OutLens == kEquirect)) && LRP_WIN_PASSWIN != 0 && (OutLens == kRect || GeoRead || (InMode == kInRect && CH == 5));
   constexpr int kPlanes = 3;
-  __shared__ float4 s_win[kWinWaves][kWinCap];
+  __shared__ float4 s_win[kWinWaves][kCap];
 
   int tx, ty;
   if (!xcd_tile<kWinXcdBand>(P.tiles_x, P.tiles_y, tx, ty)) return; // whole workgroup
@@ -1488,10 +1501,10 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       b.bw = x_last + 2 - b.x_lo + 1;
       b.bh = y_last + 2 - b.y_lo + 1;
       b.pitch = b.bw | 1; // odd: consecutive window rows start an odd number of 16 B slots apart
-      b.tier = (b.bw <= 64 && raw_slots(b) <= kWinCap) ? 1 : 0;
+      b.tier = (b.bw <= 64 && raw_slots(b) <= kCap) ? 1 : 0;
       if (kSplit && P.win_split != 0 && b.tier == 0 && b.bw <= 64) {
         const int a_lo = ya_first - 1, a_rows = ya_last + 2 - a_lo + 1, b_lo = yb_first - 1, b_rows = yb_last + 2 - b_lo + 1;
-        if (slots_of_rows(b.pitch, max(a_rows, b_rows)) <= kWinCap) {
+        if (slots_of_rows(b.pitch, max(a_rows, b_rows)) <= kCap) {
           b.y_lo = a_lo;
           b.bh = a_rows;
           b.y_lo2 = b_lo;
@@ -1506,17 +1519,17 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       b.iyn[1] = yb_last - yb_first + 1;
       // strongly magnified blocks have room for the planes of ALL their origin rows: one
       // precompute per block (fuller lanes: e.g. 132 origins in 3 trips instead of 2 x 77 in 4)
-      if (!b.split() && raw_slots(b) + kPlanes * b.pitch * (y_last - y_first + 1) <= kWinCap) b.tier |= 4;
+      if (!b.split() && raw_slots(b) + kPlanes * b.pitch * (y_last - y_first + 1) <= kCap) b.tier |= 4;
       if (b.whole()) {
         b.iy0[0] = b.iy0[1] = y_first;
         b.iyn[0] = b.iyn[1] = y_last - y_first + 1;
       }
       b.c_plane = b.pitch * max(b.iyn[0], b.iyn[1]);
-      if (kWinCoef && P.win_coef != 0 && b.staged() && !b.split() && raw_slots(b) + kPlanes * b.c_plane <= kWinCap) b.tier |= 2;
+      if (kWinCoef && P.win_coef != 0 && b.staged() && !b.split() && raw_slots(b) + kPlanes * b.c_plane <= kCap) b.tier |= 2;
       // planes behind the raw window plus, where there is room, one row and one column of slack:
       // the next block's (slightly different) window can then be requested while this block's
       // planes are still being read (see next_window)
-      b.c_base = min(raw_slots(b) + b.pitch + b.bh + 1, kWinCap - kPlanes * b.c_plane);
+      b.c_base = min(raw_slots(b) + b.pitch + b.bh + 1, kCap - kPlanes * b.c_plane);
       b.tap_base = b.org() - b.y_lo * b.spitch() - (1 + b.x_lo);
       if constexpr (Quad) {
         b.c_delta_stored[0] = b.c_delta_value(0);
@@ -1552,7 +1565,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
         b.bh = 1;
         b.pitch = b.bw;
         b.c_base = raw_slots(b); // the plane of vertical cubics, one per window texel (RGBAZ: + a float plane behind it)
-        if (b.c_base + raw_slots(b) <= kWinCap) b.tier = 1 | ((1 + (sy_side - 1)) << 6);
+        if (b.c_base + raw_slots(b) <= kCap) b.tier = 1 | ((1 + (sy_side - 1)) << 6);
       } else if (kEdge && P.win_edge != 0 && sx_side != 0 && in_y) {
         const int y_first = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_lo_y));
         const int y_last = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)w_hi_y));
@@ -1561,7 +1574,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
         b.x_lo = sx_side == 2 ? P.in_w - 1 : 0;
         b.bw = 1;
         b.pitch = 1;
-        if (raw_slots(b) <= kWinCap) b.tier = 1 | ((3 + (sx_side - 1)) << 6);
+        if (raw_slots(b) <= kCap) b.tier = 1 | ((3 + (sx_side - 1)) << 6);
       }
     }
   };
@@ -1861,10 +1874,13 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
       // at the top of the block loop.  M0 = LDS byte address of the row (+ 16 B per lane).
       // the reads of the window issued so far have returned before anything overwrites it
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane < b.bw) {
-        uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win + (uint32_t)b.org() * 16u;
+      // (windows wider than 64 texels — pass windows of the big-window variant — take one instruction per 64 columns and row)
+      const int n_chunks = kMaxPassCols > 64 ? (b.bw + 63) >> 6 : 1;
+      for (int chunk = 0; chunk < n_chunks; ++chunk)
+      if (chunk * 64 + lane < b.bw) {
+        uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win + (uint32_t)(b.org() + chunk * 64) * 16u;
         const uint32_t lds_step = (uint32_t)(b.spitch() * 16); // dwordx3 too writes one 16-byte slot per lane
-        const uint32_t lane_bytes = (uint32_t)(b.x_lo + lane) * (4u * CH);
+        const uint32_t lane_bytes = (uint32_t)(b.x_lo + chunk * 64 + lane) * (4u * CH);
         const int n_rows = kSplit ? b.rows_of(half) : b.bh;
         const char *row = reinterpret_cast<const char *>(frame) + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(kSplit ? b.first_row_of(half) : b.y_lo) * src.row_bytes)); // wave-uniform
         for (int r = 0; r < n_rows; ++r) {
@@ -1878,7 +1894,7 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
             // (an instruction offset would move the LDS address as well as the global one: the fifth float's 16 bytes
             // go into the scalar base)
             const uint32_t lds_d = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win +
-                                   (uint32_t)(b.pitch * n_rows) * 16u + (uint32_t)(r * b.pitch) * 4u;
+                                   (uint32_t)(b.pitch * n_rows) * 16u + (uint32_t)(r * b.pitch + chunk * 64) * 4u;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                          :
                          : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(row)
@@ -2069,21 +2085,8 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
   // wavefronts of the SIMD cover the round trip (requesting the window of pass k + 1 behind the taps of pass k, like the
   // second half of a split block, measured slower: 120 against 112 us per pole face, 14 spilled registers).
   // False: this pass gathers per pixel.
-  auto pass_window = [&](float psx, float psy, Rgba &s, bool last_pass) -> bool {
-    if (!all_interior(psx, psy, 1.0f, src.x_hi, src.y_hi, 2.0f)) return false;
-    int lo_x = (int)f2u(psx), hi_x = lo_x, lo_y = (int)f2u(psy), hi_y = lo_y, d0 = 0, d1 = 0;
-    wave_box(lo_x, hi_x, lo_y, hi_y, d0, d1); // (interior: the coordinates are >= 1, their bits order like integers)
-    WinBlock w;
-    clear_block(w);
-    w.x_lo = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)lo_x)) - 1;
-    w.y_lo = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)lo_y)) - 1;
-    w.bw = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)hi_x)) + 2 - w.x_lo + 1;
-    w.bh = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)hi_y)) + 2 - w.y_lo + 1;
-    w.pitch = w.bw | 1;
-    if (w.bw > 64 || slots_of_rows(w.pitch, w.bh) > kWinCap) return false;
-    w.tier = 1;
-    issue(P.src, w);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the window (and every older store)
+  // taps of one pixel from a staged pass window `w` and the five cubics (bicubicInterpolate's order, src/reproject.cpp:100-107)
+  auto window_sample = [&](const WinBlock &w, float psx, float psy, bool last_pass) -> Rgba {
     const float4 *const win = win0;
     const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
     const float fx = psx - tx_, fy = psy - ty_;
@@ -2112,12 +2115,36 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
     const Rgba k1 = cubic4(q[1][0], q[1][1], q[1][2], q[1][3], fy, hfy);
     const Rgba k2 = cubic4(q[2][0], q[2][1], q[2][2], q[2][3], fy, hfy);
     const Rgba k3 = cubic4(q[3][0], q[3][1], q[3][2], q[3][3], fy, hfy);
-    s = cubic4(k0, k1, k2, k3, fx, hfx);
+    Rgba s = cubic4(k0, k1, k2, k3, fx, hfx);
     if constexpr (CH == 5) {
       const f2 k01 = catmull_rom2(f2{dz[0][0], dz[1][0]}, f2{dz[0][1], dz[1][1]}, f2{dz[0][2], dz[1][2]}, f2{dz[0][3], dz[1][3]}, fy, hfy);
       const f2 k23 = catmull_rom2(f2{dz[2][0], dz[3][0]}, f2{dz[2][1], dz[3][1]}, f2{dz[2][2], dz[3][2]}, f2{dz[2][3], dz[3][3]}, fy, hfy);
       s.e = catmull_rom(k01.x, k01.y, k23.x, k23.y, fx, hfx);
     }
+    return s;
+  };
+  // window of one pass (or of two passes that read the same source rows) from the wave-wide extremes of its coordinates;
+  // false: too wide or too large for the buffer
+  auto plan_pass_window = [&](WinBlock &w, int lo_x, int hi_x, int lo_y, int hi_y) -> bool {
+    int d0 = 0, d1 = 0;
+    wave_box(lo_x, hi_x, lo_y, hi_y, d0, d1); // (interior: the coordinates are >= 1, their bits order like integers)
+    clear_block(w);
+    w.x_lo = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)lo_x)) - 1;
+    w.y_lo = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)lo_y)) - 1;
+    w.bw = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)hi_x)) + 2 - w.x_lo + 1;
+    w.bh = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)hi_y)) + 2 - w.y_lo + 1;
+    w.pitch = w.bw | 1;
+    if (w.bw > kMaxPassCols || slots_of_rows(w.pitch, w.bh) > kCap) return false;
+    w.tier = 1;
+    return true;
+  };
+  auto pass_window = [&](float psx, float psy, Rgba &s, bool last_pass) -> bool {
+    if (!all_interior(psx, psy, 1.0f, src.x_hi, src.y_hi, 2.0f)) return false;
+    WinBlock w;
+    if (!plan_pass_window(w, (int)f2u(psx), (int)f2u(psx), (int)f2u(psy), (int)f2u(psy))) return false;
+    issue(P.src, w);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the window (and every older store)
+    s = window_sample(w, psx, psy, last_pass);
     return true;
   };
 #pragma unroll 1
@@ -2183,10 +2210,10 @@ __global__ __launch_bounds__(kWinThreads, CH == 5 ? LRP_WIN_MINWAVES5 : (QMode =
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int k = 2 * h + kk;
-        const bool last_pass = k == 3;
         if (Quad && !kSharedRays && k == 3 && last_frame && g + 1 < G) coords(g + 1, nxt); // only its box is kept
         if constexpr (GeoRead)
           if (k == 3 && g + 1 < G) geo_plan(nxt);
+        const bool last_pass = k == 3;
         float psx = cur.sx[k], psy = cur.sy[k];
         if constexpr (Quad && !kSharedRays) quad_xy(image_of(g), k, psx, psy); // re-derived (2-4 instructions) instead of held in registers
         // (where the coordinates of a mirror image are a plain selection of stored values the compiler would otherwise
@@ -2459,10 +2486,11 @@ template <int QMode, int CH, bool Frames> struct WinKernelTable {
 
 // The GeoRead instantiations (plain blocks, coordinates from the geometry cache): one per source mode.
 template <int CH> struct WinGeoKernelTable {
-  static TileKernelFn get(int in_mode) {
+  static TileKernelFn get(int in_mode, bool big_windows) {
     static const TileKernelFn table[4] = {
         reproject_bicubic_win_kernel<kRect, kInRect, 0, CH, false, true>, reproject_bicubic_win_kernel<kRect, kInEquidistant, 0, CH, false, true>,
         reproject_bicubic_win_kernel<kRect, kInEquirect, 0, CH, false, true>, reproject_bicubic_win_kernel<kRect, kInEquirectLoop, 0, CH, false, true>};
+    if (big_windows && in_mode == kInRect) return reproject_bicubic_win_kernel<kEquirect, kInRect, 0, CH, false, true>;
     return table[in_mode];
   }
 };
@@ -2472,7 +2500,7 @@ template <int CH> struct WinGeoKernelTable {
 template <int QMode, int CH, bool GeoRead = false>
 inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, hipStream_t stream) {
   static_assert(!GeoRead || QMode == 0, "the geometry cache feeds plain blocks");
-  if (GeoRead && (P.batch_n > 0 || P.geo_mode != 2 || P.y_offset != 0 || P.y_end != P.out_h)) return hipErrorInvalidValue;
+  if (GeoRead && (P.geo_mode != 2 || P.y_offset != 0 || P.y_end != P.out_h)) return hipErrorInvalidValue;
   const int rows = P.y_end - P.y_offset;
   if (QMode != 0) {
     // the launch enumerates the top-left quadrant (the top / the left half when one axis is mirrored); a wavefront
@@ -2490,7 +2518,7 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
     if (GeoRead && P.blocks_per_wave > 0) G = std::min(P.blocks_per_wave, kGeoStripRows); // the caller's override (lrp_debug_set "geo_strip")
     // (a batch whose wavefronts walk several frames pipelines the windows of one block across its frames: one block per
     // wavefront measured 2-3 % faster there — equirect -> fisheye rotated 143 -> 139 us, rect -> rect 130.5 -> 128 —, four 5 % slower)
-    if (P.batch_n > 1 && !(out_idx == 2 && in_mode == kInRect)) G = 1;
+    if (!GeoRead && P.batch_n > 1 && !(out_idx == 2 && in_mode == kInRect)) G = 1;
     const bool strip_forced = GeoRead && P.blocks_per_wave > 0;
     while (!strip_forced && G > 1 && (long long)P.tiles_x * kWinWaves * ((row_blocks + G - 1) / G) < 8192) G >>= 1; // >= 2 rounds of wavefronts
     P.blocks_per_wave = G;
@@ -2503,7 +2531,7 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
   int groups = P.batch_n > 0 ? P.batch_n : 1;
   const int frames_override = P.frames_per_wave; // on entry: 0 = automatic
   P.frames_per_wave = 1;
-  if (P.batch_n > 1) {
+  if (P.batch_n > 1 && !GeoRead) { // (GeoRead: a frame per wavefront; its coordinates come from HBM either way)
     const long long units = (long long)n_tiles * kWinWaves * P.batch_n;
     int F = (int)std::min<long long>(P.batch_n, std::max<long long>(1, units / 8192));
     // a rectilinear view inside a panorama: a quarter of the strips (the ones in view) carry most of the frame's time and
@@ -2515,7 +2543,7 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
   }
   TileKernelFn fn;
   if constexpr (GeoRead)
-    fn = WinGeoKernelTable<CH>::get(in_mode);
+    fn = WinGeoKernelTable<CH>::get(in_mode, P.rgbaz_runs != 0);
   else
     fn = P.frames_per_wave > 1 ? WinKernelTable<QMode, CH, true>::get(out_idx, in_mode) : WinKernelTable<QMode, CH, false>::get(out_idx, in_mode);
   if (!fn) return hipErrorInvalidValue; // (the host never asks for a mode outside its cells)

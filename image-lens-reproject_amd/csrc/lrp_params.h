@@ -95,7 +95,7 @@ struct KParams {
   int32_t geo_mode;
   float *geo_xy;       // [out_h][out_w] (sx, sy): the top-left-origin source texel coordinates of src/reproject.cpp:323-324
   int32_t *geo_box;    // window kernel: [block rows][blocks_x][8] (geo_layout below)
-  int32_t rgbaz_runs;  // GeoRead window kernel, RGBAZ: every block leaves as 16-byte chunks (what the rectilinear -> panorama instantiations do at compile time)
+  int32_t rgbaz_runs;  // GeoRead window kernel: a rectilinear view rendered into a panorama — the big-window variant; RGBAZ: every block leaves as 16-byte chunks (what the compute instantiations of that mapping do at compile time)
 };
 
 // A geometry-cache entry (num_samples == 1, whole images): the coordinate map and, for the window kernel, per 16 x 16

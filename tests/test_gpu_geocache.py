@@ -114,6 +114,26 @@ def test_lens_pairs_channels_rotations_against_the_live_oracle(lrp, oracle, torc
                 cases.assert_same_bits(again.cpu().numpy(), want, f"read (strip {strip}) {out_name} <- {in_name} C={channels} {rot_name}")
 
 
+@pytest.mark.parametrize("channels", [3, 4, 5])
+def test_big_window_variant_against_the_live_oracle(lrp, oracle, torch_cuda, channels):
+    """A rectilinear view rendered into a panorama: the reading launch is the big-window variant (20 KiB of LDS per
+    wavefront, pass windows up to 128 texels wide).  Minifying and magnifying views, with and without a pan."""
+    torch = torch_cuda
+    for (iw, ih, ow, oh), in_name, rot_name in (((256, 192, 64, 48), "rect", "none"), ((320, 320, 128, 64), "rect", "pan180"),
+                                                ((64, 64, 128, 96), "rect_tele", "ident"), ((300, 200, 96, 64), "rect", "none"),
+                                                ((700, 500, 90, 61), "rect", "r30")):
+        case = dict(iw=iw, ih=ih, ow=ow, oh=oh, out="eqr_full", inp=in_name, interp=2, c=channels, ns=1, rot=rot_name,
+                    seed=0x9A1 + iw + channels)
+        want = golden_cases.run_oracle(oracle, lrp, case)
+        src, lin, lout, rot = _small_setup(lrp, torch, case)
+        d_in = torch.from_numpy(src).cuda()
+        first = _small_render(lrp, torch, case, d_in, lin, lout, rot)
+        again = _small_render(lrp, torch, case, d_in, lin, lout, rot)
+        torch.cuda.synchronize()
+        cases.assert_same_bits(first.cpu().numpy(), want, f"fill {in_name} {iw}x{ih} -> {ow}x{oh} C={channels} {rot_name}")
+        cases.assert_same_bits(again.cpu().numpy(), want, f"read {in_name} {iw}x{ih} -> {ow}x{oh} C={channels} {rot_name}")
+
+
 FRAMES = ["config1_4k_eqd_rect_bc", "northstar_4k_eqr_rect_bc", "scaling_4k_eqr_eqd_bc_rot", "config3_4k_rgbaz_rect_eqr_bc_post",
           "config3_4k_rgbz_rect_eqr_bc_post", "config4_8k_rgb_face0", "config4_8k_rgb_face1", "config4_8k_rgb_face4",
           "4k_eqr_rect_bc_rot", "4k_eqr_rect_bc_pan90", "4k_eqr_rect_bc_pitch90", "4k_rect_rect_bc_rot", "4k_eqd_eqd_bc_rot",
