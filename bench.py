@@ -83,32 +83,34 @@ DEFAULT_SECONDARY = ("equirect_to_rect_bicubic,equirect_to_rect_bicubic_rot,equi
 INTERP_NAMES = {0: "nearest", 1: "bilinear", 2: "bicubic"}
 KERNEL_NAMES = {0: "reproject_tile_kernel (nearest)", 1: "reproject_tile_kernel (bilinear)",
                 2: "reproject_bicubic_win_kernel (LDS window)"}
-# sources whose contents decide what the kernels do: the PMC traffic file is only valid for them
-KERNEL_SOURCES = ["lrp_kernel_v2.h", "lrp_device.h", "lrp_math.h", "lrp_source_axes.h", "lrp_params.h", "lrp_tables.hip",
-                  "lrp_capi.cpp"]
+TRAFFIC_FILE = os.path.join("profiles", "traffic_r04.json")
 
 
 def kernel_source_sha():
+    """Hash of everything that decides which kernel a workload runs and what it does: every source, header and the build
+    script (per-unit code generation options) of csrc/.  The PMC traffic file is only valid for the sources it was measured on."""
     h = hashlib.sha256()
-    for name in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, "image-lens-reproject_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
+    csrc = os.path.join(ROOT, "image-lens-reproject_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".h", ".hip", ".cpp", ".sh")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode())
+                h.update(f.read())
     return h.hexdigest()[:16]
 
 
 def measured_traffic(workload):
-    """HBM bytes per single-frame launch of the dominant kernel from the committed rocprofv3 PMC
-    summary (profiles/traffic_r03.json; tools/collect_traffic.sh on an MI355X).  The file is stamped
-    with the hash of the kernel sources it was measured on; a stale file yields None."""
-    path = os.path.join(ROOT, "profiles", "traffic_r03.json")
+    """(per 16-frame launch, per single-frame launch) HBM bytes of the dominant kernel from the committed rocprofv3 PMC
+    summary (profiles/traffic_r04.json; tools/collect_traffic.sh on an MI355X: both launch shapes are profiled).  The
+    file is stamped with the hash of the kernel sources it was measured on; a stale file yields (None, None)."""
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
             d = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, None
     if d.get("_kernel_source_sha") != kernel_source_sha():
-        return None
-    return d.get(workload)
+        return None, None
+    return d.get(workload + "@batch16"), d.get(workload)
 
 
 def make_lens(pkg, kind, w, h):
@@ -216,6 +218,33 @@ def cpu_baseline(pkg, wl, seconds_target):
     }
 
 
+def staged_rates():
+    """Host-buffer (PCIe-inclusive) rates of the batch pipeline — what a caller with frames in host memory sees, never
+    `value` —: tools/staged_bench on 4096^2 RGBA frames, best stream count per format.  A separate ~3 s process, after
+    the timed region.  None if the tool is not built."""
+    import re
+
+    exe = os.path.join(ROOT, "tools", "staged_bench")
+    if not os.path.exists(exe):
+        return None
+    try:
+        text = subprocess.run([exe, "6"], capture_output=True, text=True, timeout=120).stdout
+    except (OSError, subprocess.TimeoutExpired):
+        return None
+    best = {}
+    for line in text.splitlines():
+        m = re.match(r"(.*?)\s+streams=(\d+): (\d+) Mpix/s staged", line)
+        if m:
+            key = {"pinned=0": "f32_pageable", "pinned=1": "f32_pinned"}.get(m.group(1).strip(), None)
+            if key is None:
+                key = "binary16_pinned" if "binary16" in m.group(1) else ("rgba8_pinned" if "RGBA8" in m.group(1) else m.group(1).strip())
+            best[key] = max(best.get(key, 0.0), float(m.group(3)))
+    if not best:
+        return None
+    return {"unit": "Mpix/s", "workload": "fisheye_to_rect_bicubic 4096^2 RGBA, host buffers in and out (lrp_context_submit*)", **best,
+            "note": "PCIe-inclusive: upload + kernel + download pipelined over three streams; bound by the PCIe link, not by the kernel"}
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -227,7 +256,8 @@ def free_port():
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=0,
+                    help="timed steps (default: 20, more when a rank's shard is small so that the timed region is >= ~0.5 s)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256,
                     help="images per step: the whole job's batch (strong scaling, sharded over the ranks in static "
@@ -253,6 +283,7 @@ def parse_args():
                     help="untimed launches of the workload before the warm-up steps: the chip takes its sustained "
                          "(power-limited) clock only after a while under load, and a first launch after idle is 10-25 %% slower")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-staged", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg (tools/staged_bench)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -333,18 +364,28 @@ def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_
             batched(i)
         torch.cuda.synchronize()
         b_avg, b_min = time_launches(torch, stream, batched, 32)
+    # single-frame launches — the call the reference's worker makes once per file (src/main.cpp:597): with the geometry
+    # cache (the first launch of the geometry fills it, the timed ones read it) and with every launch computing its coordinates
     for i in range(16):
         single(i)
     torch.cuda.synchronize()
     s_avg, s_min = time_launches(torch, stream, single, 64)
+    prev_geo = pkg.debug_set("geo_cache", 0)
+    for i in range(8):
+        single(i)
+    torch.cuda.synchronize()
+    u_avg, _u_min = time_launches(torch, stream, single, 32)
+    pkg.debug_set("geo_cache", prev_geo)
     # (inW*inH + outW*outH)*C*4 per launch that reads the source; a cubemap is six such launches
     launch_bytes = (size * size + out_size * out_size) * c * 4
     frame_bytes = launch_bytes * (len(faces) if faces else 1)
     read_bytes = size * size * c * 4 * (len(faces) if faces else 1)
     algo = frame_bytes * nb
     achieved = algo / (b_avg * 1e-3) / 1e9
-    traffic = measured_traffic(name) if size == wl["size"] else None
-    hbm_bytes = (traffic or {}).get("hbm_bytes_per_launch")
+    traffic_b, traffic_s = measured_traffic(name) if size == wl["size"] else (None, None)
+    if faces:  # (a cubemap "frame" is its own launch shape: six launches)
+        traffic_b = traffic_s
+    hbm_bytes = (traffic_b or {}).get("hbm_bytes_per_launch")
     out = {
         "bound": "hbm",
         "achieved": achieved,
@@ -354,9 +395,9 @@ def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_
         "frac_read_only": read_bytes * nb / (b_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
         # the bytes the PMC counters saw cross the HBM interface / time / peak: what the memory system actually sustains
         # (below frac whenever the view does not look at the whole source)
-        "frac_measured_hbm": (hbm_bytes * nb / (b_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if hbm_bytes else None,
-        "traffic": (hbm_bytes or 0) * nb or None,
-        "traffic_detail": traffic,
+        "frac_measured_hbm": (hbm_bytes / (b_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if hbm_bytes else None,
+        "traffic": hbm_bytes or None,
+        "traffic_detail": {"batched_launch": traffic_b, "single_launch": traffic_s},
         "kernel": "six launches of reproject_bicubic_win_kernel (LDS window) over one resident source" if faces else KERNEL_NAMES[wl["interp"]],
         "workload": name,
         "kernel_ms_avg": b_avg,
@@ -369,12 +410,20 @@ def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_
         "single_launch_us": s_avg * 1e3,
         "single_launch_us_min": s_min * 1e3,
         "single_launch_frac": frame_bytes / (s_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "traffic_note": "PMC bytes measured per single-frame launch (traffic_detail) x frames_per_launch; null when "
-                        "profiles/traffic_r03.json was measured on other kernel sources",
+        "single_launch_us_uncached": u_avg * 1e3,
+        "single_launch_frac_uncached": frame_bytes / (u_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "single_launch_note": "one frame per launch, what reproject::reproject() makes per file: coordinates from the geometry cache "
+                              "(default) / computed in every launch (lrp_debug_set geo_cache 0)",
+        "traffic_note": f"PMC bytes of one {nb}-frame launch as timed here (rocprofv3 FETCH_SIZE / WRITE_SIZE passes over that launch "
+                        f"shape; single-frame launches in traffic_detail); null when {TRAFFIC_FILE} was measured on other kernel sources",
     }
     if faces:
-        out["note"] = ("a frame is one cubemap: six 2048^2 faces from one resident 8192^2 RGB source; algorithmic bytes count the "
-                       "whole source once per face launch as SURVEY 8d prescribes, although a 90-degree face looks at a sixth of it")
+        # the source read ONCE + the six faces written: what a cubemap has to move (SURVEY 8d's figure counts the whole source per face)
+        once = size * size * c * 4 + len(faces) * out_size * out_size * c * 4
+        out["frac_source_once"] = once / (b_avg * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out["note"] = ("a frame is one cubemap: six 2048^2 faces from one resident 8192^2 RGB source; `frac` counts the whole source once per "
+                       "face launch as SURVEY 8d prescribes (it exceeds 1: a 90-degree face looks at a sixth of the source); "
+                       "frac_source_once = (source once + six faces) / time / peak is the honest roofline fraction")
     return out
 
 
@@ -436,6 +485,10 @@ def main():
         first, last = rank * args.batch, (rank + 1) * args.batch
         total_images = args.batch * world
     shard = list(range(first, last))
+    if args.steps <= 0:
+        # 20 steps of a 256-image shard are 0.5 s; a rank of an 8-GPU job renders 32 images per step (3.3 ms): more steps, so
+        # that barrier skew and launch latency do not dominate what the driver's clock sees
+        args.steps = 20 if len(shard) >= 64 else min(160, 20 * -(-64 // max(len(shard), 1)))
 
     # resident frames: the whole shard when it fits (288 GB of HBM: 256 x 2 x 256 MiB = 128 GiB), else a
     # ring of at least 16 pairs — far beyond the 256 MiB Infinity Cache either way
@@ -497,8 +550,15 @@ def main():
     for s_i in range(args.steps):
         step(s_i)
     barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(elapsed, dist, dev if args.dist_backend == "nccl" else None)
+    elapsed_rank = time.perf_counter() - t0
+    # device time of this rank's timed launches alone (first event to last event on its stream): what the rank would need
+    # without the barriers; the difference to elapsed_rank is host / barrier time
+    busy_rank = events[0][0][0].elapsed_time(events[-1][-1][1]) * 1e-3 if events and events[0] else None
+    per_rank = [(elapsed_rank, busy_rank)]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, (elapsed_rank, busy_rank))
+    elapsed = sharding.max_over_ranks(elapsed_rank, dist, dev if args.dist_backend == "nccl" else None)
     # full 16-frame launches of the timed region (a shard's last launch may hold fewer frames)
     timed_ms = [a.elapsed_time(b) for per_step in events for (a, b), g in zip(per_step, groups) if g._n == FRAMES_PER_LAUNCH]
 
@@ -547,6 +607,10 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "timed_region_s": elapsed,
+            # one entry per rank: wall seconds between its barriers, device seconds of its own launches; skew = slowest - fastest
+            "per_rank_elapsed_s": [e for e, _b in per_rank],
+            "per_rank_device_busy_s": [b for _e, b in per_rank],
+            "rank_skew_s": max(e for e, _b in per_rank) - min(e for e, _b in per_rank),
             "settle_seconds": args.settle_seconds,
             "higher_is_better": True,
             "scaling": args.scaling,
@@ -571,6 +635,8 @@ def main():
             "roofline": roof,
             "secondary": secondary,
         }
+        if world == 1 and not args.no_staged:
+            out["staged"] = staged_rates()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, wl, args.cpu_seconds)
         print(json.dumps(out), flush=True)

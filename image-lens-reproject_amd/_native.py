@@ -6,6 +6,7 @@ by callers only as plumbing (device memory, streams, torch.distributed).
 """
 import ctypes
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblrp_hip.so")
@@ -173,6 +174,15 @@ def load():
             f"{LIB_PATH} not found: build it with image-lens-reproject_amd/csrc/build.sh "
             "(or __graft_entry__.build()); the HIP library is the only implementation"
         )
+    # One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so and load it by path; liblrp_hip.so
+    # names libamdhip64.so.7 and, loaded FIRST, would bring in /opt/rocm's copy — two runtimes in one process, and the second
+    # one to initialise finds no device ("No HIP GPUs are available" / LRP_ERR_NO_DEVICE).  Callers hand this package torch
+    # tensors and streams, so where torch is installed its runtime is loaded first and the library binds to it.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

@@ -112,6 +112,15 @@ lrp::LensP pack_lens(const lrp_lens &L) {
 }
 
 size_t image_bytes(const lrp_image &im) { return (size_t)im.width * (size_t)im.height * (size_t)im.channels * 4u; }
+// The reference addresses texels with `int` (src/reproject.cpp:49-51,134-142: ly * pitch + lx * channels + c): an image of
+// up to 2^31 floats (8 GiB) is what it can render; beyond that its index overflows.  Same limit here.
+constexpr unsigned long long kMaxImageFloats = 1ull << 31;
+bool image_addressable(const lrp_image &im) {
+  return (unsigned long long)im.width * (unsigned long long)im.height * (unsigned long long)im.channels <= kMaxImageFloats;
+}
+// The tile / window kernels address texels through 32-bit byte offsets (buffer descriptors, LDS-DMA): images below 4 GiB.
+// Larger ones — [4 GiB, 8 GiB] — take the one-pixel-per-lane kernel, whose element offsets are 32-bit and pointers 64-bit.
+bool image_fits_byte_offsets(const lrp_image &im) { return (unsigned long long)image_bytes(im) < (1ull << 32); }
 
 // Checks in the order the reference dispatches: output lens
 // (src/reproject.cpp:408-418), input lens (:378-398), interpolation (:352-367);
@@ -126,9 +135,8 @@ int validate(const lrp_image *in, const lrp_image *out, int interpolation, bool 
     return fail(LRP_ERR_CHANNELS, "in->channels must equal out->channels and be >= 1");
   if (in->width < 1 || in->height < 1 || out->width < 1 || out->height < 1)
     return fail(LRP_ERR_BAD_DIMS, "image dimensions must be positive");
-  const unsigned long long lim = 1ull << 32;
-  if ((unsigned long long)image_bytes(*in) >= lim || (unsigned long long)image_bytes(*out) >= lim)
-    return fail(LRP_ERR_BAD_DIMS, "images of 4 GiB or more are not supported");
+  if (!image_addressable(*in) || !image_addressable(*out))
+    return fail(LRP_ERR_BAD_DIMS, "an image of more than 2^31 floats (8 GiB) cannot be addressed (the reference indexes texels with int, src/reproject.cpp:49-51)");
   if (need_data && (!in->data || !out->data)) return fail(LRP_ERR_NULL, "null image data");
   return LRP_OK;
 }
@@ -236,7 +244,8 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
   lrp::GeoUse geo;       // this launch's use of the geometry cache (none unless set below)
   const bool tile_channels = out->channels >= 3 && out->channels <= 5;
   int symmetry = 0; // bit 0 / 1: the column / row terms of the output-lens tables are mirror images about the image centre
-  bool tile = kernel_choice() != 0 && tile_channels && in->width <= 65535 && in->height <= 32767 &&
+  bool tile = kernel_choice() != 0 && tile_channels && image_fits_byte_offsets(*in) && image_fits_byte_offsets(*out) &&
+              in->width <= 65535 && in->height <= 32767 &&
               (long long)out->width * num_samples < (1ll << 30) && (long long)out->height * num_samples < (1ll << 30);
   if (tile && out->lens.type != LRP_FISHEYE_EQUIDISTANT) {
     // separable output-lens terms (cached per device / lens / size / num_samples)
@@ -654,8 +663,18 @@ int lrp_reproject_multi(const lrp_image *in, lrp_image *outs, int n_out, int num
   for (MultiPeer *p : order) locks.emplace_back(p->busy);
 
   const size_t in_bytes = image_bytes(*in);
-  // every participant renders band d of every output: its output buffer holds its bands back to back
-  auto band = [&](const lrp_image &o, int d, int &first, int &count) {
+  // With at least as many outputs as participants whole outputs are dealt round-robin (output i -> participant i % n): a
+  // whole image keeps the kernels that share work between mirror images and the geometry cache.  With fewer outputs than
+  // participants every participant renders band d of every output (rows are independent, src/reproject.cpp:284).  Either
+  // way a participant's output buffer holds its pieces back to back.
+  const bool whole_outputs = n_out >= n_devices;
+  auto band = [&](int i, int d, int &first, int &count) {
+    const lrp_image &o = outs[i];
+    if (whole_outputs) {
+      first = 0;
+      count = (i % n_devices == d) ? o.height : 0;
+      return;
+    }
     first = (int)((long long)o.height * d / n_devices);
     count = (int)((long long)o.height * (d + 1) / n_devices) - first;
   };
@@ -675,7 +694,7 @@ int lrp_reproject_multi(const lrp_image *in, lrp_image *outs, int n_out, int num
     size_t out_bytes = 0;
     for (int i = 0; i < n_out; ++i) {
       int first, count;
-      band(outs[i], d, first, count);
+      band(i, d, first, count);
       out_bytes += (size_t)count * (size_t)outs[i].width * (size_t)outs[i].channels * 4u;
     }
     result = p.src.reserve(in_bytes);
@@ -713,7 +732,7 @@ int lrp_reproject_multi(const lrp_image *in, lrp_image *outs, int n_out, int num
     size_t cursor = 0; // floats into p.out
     for (int i = 0; i < n_out && result == LRP_OK; ++i) {
       int first, count;
-      band(outs[i], d, first, count);
+      band(i, d, first, count);
       if (count == 0) continue;
       const size_t row_floats = (size_t)outs[i].width * (size_t)outs[i].channels;
       lrp_image din = *in, dout = outs[i];
@@ -759,7 +778,7 @@ int lrp_reproject_batch_device(const lrp_image *ins, lrp_image *outs, int n, int
 int lrp_post_process_device(lrp_image *img, float exposure, float reinhard, int device, void *stream) {
   if (!img || !img->data) return fail(LRP_ERR_NULL, "null image");
   if (img->width < 1 || img->height < 1 || img->channels < 1) return fail(LRP_ERR_BAD_DIMS, "bad image dimensions");
-  if ((unsigned long long)image_bytes(*img) >= (1ull << 32)) return fail(LRP_ERR_BAD_DIMS, "image too large");
+  if (!image_addressable(*img)) return fail(LRP_ERR_BAD_DIMS, "image too large (more than 2^31 floats)");
   int st = select_device(device);
   if (st != LRP_OK) return st;
   hipError_t e = lrp::launch_post_process(img->data, (uint32_t)img->width * (uint32_t)img->height, img->channels,
@@ -974,7 +993,7 @@ int lrp_reproject(const lrp_image *in, lrp_image *out, int num_samples, int inte
 int lrp_post_process(lrp_image *img, float exposure, float reinhard, int device) {
   if (!img || !img->data) return fail(LRP_ERR_NULL, "null image");
   if (img->width < 1 || img->height < 1 || img->channels < 1) return fail(LRP_ERR_BAD_DIMS, "bad image dimensions");
-  if ((unsigned long long)image_bytes(*img) >= (1ull << 32)) return fail(LRP_ERR_BAD_DIMS, "image too large");
+  if (!image_addressable(*img)) return fail(LRP_ERR_BAD_DIMS, "image too large (more than 2^31 floats)");
   lrp_context *c = nullptr;
   int st = borrow_context(device, &c);
   if (st != LRP_OK) return st;
@@ -1042,7 +1061,7 @@ int lrp_synth_fill_device(float *data, int width, int height, int channels, uint
   if (!data) return fail(LRP_ERR_NULL, "null data");
   if (width < 1 || height < 1 || channels < 1) return fail(LRP_ERR_BAD_DIMS, "bad image dimensions");
   const unsigned long long n = (unsigned long long)width * height * channels;
-  if (n >= (1ull << 30)) return fail(LRP_ERR_BAD_DIMS, "image too large");
+  if (n > kMaxImageFloats) return fail(LRP_ERR_BAD_DIMS, "image too large (more than 2^31 floats)");
   int st = select_device(device);
   if (st != LRP_OK) return st;
   hipError_t e = lrp::launch_synth_fill(data, (uint32_t)n, channels, seed, depth_channel, (hipStream_t)stream);

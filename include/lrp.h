@@ -54,7 +54,7 @@ typedef enum lrp_status {
   LRP_ERR_INPUT_LENS = 2,    /* "Input lens type not supported.",  src/reproject.cpp:395-397 */
   LRP_ERR_INTERPOLATION = 3, /* "Interpolation method not supported.", src/reproject.cpp:364-366 */
   LRP_ERR_CHANNELS = 4,      /* in->channels != out->channels (unchecked precondition in the reference) or < 1 */
-  LRP_ERR_BAD_DIMS = 5,      /* non-positive size, or an image of 4 GiB or more */
+  LRP_ERR_BAD_DIMS = 5,      /* non-positive size, or an image of more than 2^31 floats (what the reference's int indexing addresses) */
   LRP_ERR_NULL = 6,          /* NULL image / data pointer */
   LRP_ERR_NO_DEVICE = 7,     /* no HIP device, or device index out of range */
   LRP_ERR_HIP = 8,           /* a HIP runtime call failed; see lrp_last_error() */
@@ -204,9 +204,9 @@ int lrp_reproject_batch_device(const lrp_image *ins, lrp_image *outs, int n, int
  * cubemap job — six reference invocations over one 8192^2 panorama — on `n_devices` GPUs.
  * The source is uploaded ONCE, to devices[0], and copied to the other GPUs device to device
  * (hipMemcpyPeerAsync over xGMI where peer access is available, a second upload where not);
- * every GPU then renders band d of n_devices of EVERY output (rows are independent; a pole
- * face costs three times a side face, bands of every face balance that) and downloads its bands
- * straight into outs[i].data.  No collective, no exchange of results.  The bytes are those of
+ * with n_out >= n_devices whole outputs are dealt round-robin over the GPUs (output i on
+ * devices[i % n_devices]), with fewer outputs than GPUs every GPU renders band d of n_devices of
+ * EVERY output (rows are independent); results are downloaded straight into outs[i].data.  No collective, no exchange of results.  The bytes are those of
  * n_out lrp_reproject calls on one GPU.  devices may name a GPU more than once. */
 int lrp_reproject_multi(const lrp_image *in, lrp_image *outs, int n_out, int num_samples, int interpolation,
                         const float *rotations, const lrp_post *post, const int *devices, int n_devices);

@@ -55,7 +55,16 @@ def test_one_rank_and_two_ranks_render_identical_images(lrp, oracle, torch_cuda,
         assert f"{lrp.checksum_host(want):016x}" == sums2["checksums"][i], f"image {i}"
     for rec in (one, two):
         assert rec["roofline"]["frac"] > 0 and rec["roofline"]["single_launch_us"] > 0
+        assert rec["roofline"]["single_launch_us_uncached"] > 0 and rec["roofline"]["single_launch_frac_uncached"] > 0
         assert 0 < rec["roofline"]["frac_read_only"] < rec["roofline"]["frac"]
+        # per-rank times (what explains a bad scaling line): one entry per rank, the whole-job time is the slowest rank's
+        n = rec["n_gpus"]
+        assert len(rec["per_rank_elapsed_s"]) == n and len(rec["per_rank_device_busy_s"]) == n
+        assert abs(max(rec["per_rank_elapsed_s"]) - rec["timed_region_s"]) < 1e-9
+        assert rec["rank_skew_s"] == pytest.approx(max(rec["per_rank_elapsed_s"]) - min(rec["per_rank_elapsed_s"]))
+        assert all(0 < b <= e * 1.05 for e, b in zip(rec["per_rank_elapsed_s"], rec["per_rank_device_busy_s"]))
+    assert one["staged"] is None or one["staged"]["f32_pinned"] > 0  # (N = 1 only; None when tools/staged_bench is not built)
+    assert "staged" not in two
 
 
 @pytest.mark.gpu

@@ -145,7 +145,7 @@ def test_batched_launch_equals_single_calls(lrp, torch_cuda, channels, interp, d
 ])
 def test_batched_launch_with_several_frames_per_wavefront(lrp, torch_cuda, frames, channels, in_name, out_name, deg):
     """Bicubic batches: a wavefront of the window kernel renders its strip for several consecutive frames and shares the
-    coordinate math and the window plan between them (LRP_BATCH_FRAMES forces the count; by default small images keep
+    coordinate math and the window plan between them (lrp_debug_set "batch_frames" forces the count; by default small images keep
     one frame per wavefront).  21 frames (so that the last group is short: 21 = 16 + 5 launches, groups of 2 / 3 / 16)
     against 21 single calls, bit for bit, in every mirror mode."""
     import os
@@ -161,17 +161,13 @@ def test_batched_launch_with_several_frames_per_wavefront(lrp, torch_cuda, frame
     batched = [torch.full((out_h, out_w, channels), -2.0, dtype=torch.float32, device="cuda") for _ in range(n)]
     for s, d in zip(srcs, single):
         lrp.reproject(lrp.Image(lin, in_w, in_h, channels, s), lrp.Image(lout, out_w, out_h, channels, d), 1, 2, rot, post=(2.0, 4.0))
-    prev = os.environ.get("LRP_BATCH_FRAMES")
-    os.environ["LRP_BATCH_FRAMES"] = frames
+    prev = lrp.debug_set("batch_frames", int(frames))
     try:
         lrp.reproject_batch([lrp.Image(lin, in_w, in_h, channels, s) for s in srcs],
                             [lrp.Image(lout, out_w, out_h, channels, d) for d in batched], 1, 2, rot, post=(2.0, 4.0))
         torch.cuda.synchronize()
     finally:
-        if prev is None:
-            del os.environ["LRP_BATCH_FRAMES"]
-        else:
-            os.environ["LRP_BATCH_FRAMES"] = prev
+        lrp.debug_set("batch_frames", prev)
     for i in range(n):
         assert bool(torch.equal(single[i].view(torch.int32), batched[i].view(torch.int32))), f"frame {i} differs"
 
@@ -196,17 +192,13 @@ def test_batched_nearest_and_bilinear_with_several_frames_per_wavefront(lrp, tor
     batched = [torch.full((out_h, out_w, channels), -2.0, dtype=torch.float32, device="cuda") for _ in range(n)]
     for s, d in zip(srcs, single):
         lrp.reproject(lrp.Image(lin, in_w, in_h, channels, s), lrp.Image(lout, out_w, out_h, channels, d), 1, interp, rot)
-    prev = os.environ.get("LRP_BATCH_FRAMES")
-    os.environ["LRP_BATCH_FRAMES"] = frames
+    prev = lrp.debug_set("batch_frames", int(frames))
     try:
         lrp.reproject_batch([lrp.Image(lin, in_w, in_h, channels, s) for s in srcs],
                             [lrp.Image(lout, out_w, out_h, channels, d) for d in batched], 1, interp, rot)
         torch.cuda.synchronize()
     finally:
-        if prev is None:
-            del os.environ["LRP_BATCH_FRAMES"]
-        else:
-            os.environ["LRP_BATCH_FRAMES"] = prev
+        lrp.debug_set("batch_frames", prev)
     for i in range(n):
         assert bool(torch.equal(single[i].view(torch.int32), batched[i].view(torch.int32))), f"frame {i} differs"
 

@@ -92,10 +92,10 @@ def test_batches_and_row_bands(lrp, oracle, torch_cuda, channels):
     srcs = [cases.hash_noise(in_h, in_w, channels, seed=300 + 7 * k + channels) for k in range(n)]
     wants = [oracle.reproject(lin, s, lout, out_w, out_h, 1, BICUBIC, rot, threads=8) for s in srcs]
     d_in = [torch.from_numpy(s).cuda() for s in srcs]
-    prev = os.environ.get("LRP_BATCH_FRAMES")
+    prev = lrp.debug_set("batch_frames", -1)
     try:
         for frames in ("1", "2", "3", "5"):
-            os.environ["LRP_BATCH_FRAMES"] = frames
+            lrp.debug_set("batch_frames", int(frames))
             d_out = [torch.full((out_h, out_w, channels), -777.0, dtype=torch.float32, device="cuda") for _ in range(n)]
             lrp.reproject_batch([lrp.Image(lin, in_w, in_h, channels, t) for t in d_in],
                                 [lrp.Image(lout, out_w, out_h, channels, t) for t in d_out], 1, BICUBIC, rot)
@@ -103,10 +103,7 @@ def test_batches_and_row_bands(lrp, oracle, torch_cuda, channels):
             for k in range(n):
                 cases.assert_same_bits(d_out[k].cpu().numpy(), wants[k], f"batch frame {k}, {frames} frames per wavefront, C={channels}")
     finally:
-        if prev is None:
-            os.environ.pop("LRP_BATCH_FRAMES", None)
-        else:
-            os.environ["LRP_BATCH_FRAMES"] = prev
+        lrp.debug_set("batch_frames", prev)
     d_out = torch.full((out_h, out_w, channels), -777.0, dtype=torch.float32, device="cuda")
     im_in, im_out = lrp.Image(lin, in_w, in_h, channels, d_in[0]), lrp.Image(lout, out_w, out_h, channels, d_out)
     for first, count in ((0, 40), (40, 100), (140, 116)):

@@ -202,3 +202,46 @@ def test_bench_launch_shape_16_frames_of_4k_against_oracle(lrp, oracle, torch_cu
         single = render(lrp, torch, lin, srcs[i], lout, n, n, 1, BICUBIC, rot)
         assert same_bytes(torch, single, dsts[i]), f"frame {i}: batched launch differs from the single-frame launch"
         del single
+
+
+def test_images_of_4_gib_and_the_int_index_limit(lrp, oracle, torch_cuda):
+    """The reference addresses texels with `int` (src/reproject.cpp:49-51): up to 2^31 floats.  A 16384 x 16384 RGBA source
+    is 2^30 floats = 4 GiB — beyond the 32-bit byte offsets of the tile / window kernels, which hand such an image to the
+    one-pixel-per-lane kernel (32-bit ELEMENT offsets, 64-bit pointers).  Rendered for all three samplers into a 1024^2
+    view and compared with oracle rows; an image of more than 2^31 floats is refused with a clear error, like nothing the
+    reference could have addressed either."""
+    torch = torch_cuda
+    n, m, c = 16384, 1024, 4
+    free_b, _total = torch.cuda.mem_get_info()
+    if free_b < 6 * (1 << 30):
+        pytest.skip("less than 6 GiB of device memory free")
+    d_in = gpu_frame(lrp, torch, n, n, c, 0x5EED4A11)
+    src = oracle.synth_frame(n, n, c, 0x5EED4A11)
+    assert src.nbytes == 1 << 32
+    # the far end of the buffer is the far end of the image: the last texel, bit for bit
+    assert np.array_equal(d_in[n - 1, n - 64:].cpu().numpy().view(np.uint32), src[n - 1, n - 64:].view(np.uint32))
+    lin, lout = lrp.LensInfo.equirectangular(), lrp.LensInfo.rectilinear(18.0, 36.0, m, m)
+    for interp, deg in ((BICUBIC, (30.0, -15.0, 5.0)), (BILINEAR, (200.0, 60.0, 0.0)), (NEAREST, (0.0, -89.0, 10.0))):
+        rot = cases.rotation(lrp, deg)
+        d_out = render(lrp, torch, lin, d_in, lout, m, m, 1, interp, rot)
+        check_rows(oracle, lin, src, lout, m, m, 1, interp, rot, d_out, f"4 GiB source, interp {interp}", n=10)
+    del d_in, src
+    torch.cuda.empty_cache()
+    # 2^31 floats + one row: not addressable (straight through the C ABI: the sizes are checked before any data is touched)
+    import ctypes
+
+    nat, lib = lrp._native, lrp._native.load()
+    tiny = torch.zeros((4, 4, 4), dtype=torch.float32, device="cuda")
+
+    def c_image(lens, w, h):
+        im = nat.LrpImage()
+        im.lens, im.width, im.height, im.channels, im.data = lens.to_c(), w, h, 4, tiny.data_ptr()
+        return im
+
+    small = c_image(lout, 2, 2)
+    st = lib.lrp_reproject_device(ctypes.byref(c_image(lin, 32768, 16385)), ctypes.byref(small), 1, BICUBIC, None, None, 0, None)
+    assert st == int(lrp.Status.BAD_DIMS) and b"2^31" in lib.lrp_last_error()
+    # exactly 2^31 floats passes the size check (dispatch errors come first, as in the reference: the unsupported lens is what is reported)
+    st = lib.lrp_reproject_device(ctypes.byref(c_image(lrp.LensInfo(lrp.LensType.FISHEYE_EQUISOLID, (10.0, 3.0)), 32768, 16384)),
+                                  ctypes.byref(small), 1, BICUBIC, None, None, 0, None)
+    assert st == int(lrp.Status.INPUT_LENS)

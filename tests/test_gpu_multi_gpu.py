@@ -2,7 +2,7 @@
 (SURVEY §8e "intra-image split", BASELINE configs[4]: an 8192^2 panorama -> six cubemap faces on 8 GPUs).
 Rows of the reference loop are independent (src/reproject.cpp:284): a row band rendered alone must carry
 the bytes of the same rows of a whole-image call, and lrp_reproject_multi — source uploaded once, copied
-device to device, band d of every output on GPU d — must give the bytes of n_out single calls.  On a
+device to device, whole outputs dealt round-robin or band d of every output on GPU d — must give the bytes of n_out single calls.  On a
 one-GPU box the device list names GPU 0 several times, which runs the same code (peer copy = device copy)."""
 import numpy as np
 import pytest
@@ -45,9 +45,10 @@ def test_row_bands_carry_the_bytes_of_the_whole_image(lrp, oracle, torch_cuda, c
         lrp.reproject_rows(im_in, im_out, 1, interp, 140, 20, rot)
 
 
-@pytest.mark.parametrize("devices", [(0,), (0, 0, 0), "all"])
+@pytest.mark.parametrize("devices", [(0,), (0, 0, 0), (0,) * 8, "all"])
 def test_cubemap_job_over_a_device_list(lrp, oracle, torch_cuda, devices):
-    """Six 90-degree faces from one panorama (the reference: six invocations with --rotation), bicubic, RGB."""
+    """Six 90-degree faces from one panorama (the reference: six invocations with --rotation), bicubic, RGB.  Up to six
+    participants get whole faces (round-robin), eight participants get row bands of every face."""
     if devices == "all":
         devices = tuple(range(torch_cuda.cuda.device_count())) * 2  # every visible GPU, twice
     in_w, in_h, face = 768, 384, 160

@@ -3,9 +3,10 @@
 --pmc WRITE_SIZE; see tools/collect_traffic.sh).  For every bench workload: one launch of the
 calibration kernel (stand-alone post_process on a 4096^2 RGBA frame: reads and writes every byte
 of the 256 MiB frame exactly once with 16-byte accesses, so its byte counts are known — it also
-separates the workloads in the dispatch sequence), then REPS frames of the workload's dominant
-kernel on device-resident frames (a frame of the cubemap workload is six launches), cycling over
-more distinct frames than the 256 MiB Infinity Cache holds.  The order is written next to the
+separates the workloads in the dispatch sequence), then REPS single-frame launches of the workload's
+dominant kernel on device-resident frames (a frame of the cubemap workload is six launches), then —
+behind another calibration launch — three 16-frame launches (lrp_reproject_batch_device: what bench.py
+times), cycling over more distinct frames than the 256 MiB Infinity Cache holds.  The order is written next to the
 counters (argv[1]) for tools/traffic_summary.py."""
 import importlib
 import json
@@ -19,7 +20,8 @@ import bench  # noqa: E402
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-REPS = 7  # the first frame of each workload is dropped by the summary (table builds, cold caches)
+REPS = 8  # single-frame launches per workload; the summary drops the first two (table builds; the launch that fills the geometry cache)
+BATCH, BATCH_LAUNCHES = 16, 3  # then 16-frame launches (what bench.py times); the summary drops the first
 order_path = sys.argv[1]
 names = sys.argv[2:] or [n for n in bench.WORKLOADS]
 pkg = importlib.import_module("image-lens-reproject_amd")
@@ -27,28 +29,41 @@ dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream()
 cal = torch.empty((4096, 4096, 4), dtype=torch.float32, device=dev)
 pkg.synth_fill(cal, 4096, 4096, 4, 0x5EED0000)
+
+
+def separator():
+    torch.cuda.synchronize()
+    pkg.post_process(pkg.Image(pkg.LensInfo.equirectangular(), 4096, 4096, 4, cal), 1.0009765625, 4.0)  # separator + calibration
+    torch.cuda.synchronize()
+
+
 order = []
 for name in names:
     wl = bench.WORKLOADS[name]
     size = wl["size"]
-    n_res = 2 if wl.get("faces") else 3
+    faces = wl.get("faces")
+    n_res = 2 if faces else BATCH
     srcs, dsts = bench.resident_frames(torch, pkg, wl, size, n_res, dev, 0x5EED2000)
     out_size = dsts[0][0].shape[0]
     c = wl["channels"]
     lin, lout = bench.make_lens(pkg, wl["in_lens"], size, size), bench.make_lens(pkg, wl["out_lens"], out_size, out_size)
-    torch.cuda.synchronize()
-    pkg.post_process(pkg.Image(pkg.LensInfo.equirectangular(), 4096, 4096, 4, cal), 1.0009765625, 4.0)  # separator + calibration
-    torch.cuda.synchronize()
+    ins = [pkg.Image(lin, size, size, c, s) for s in srcs]
+    outs = [[pkg.Image(lout, out_size, out_size, c, d) for d in ds] for ds in dsts]
+    separator()
     for i in range(REPS):
-        im_in = pkg.Image(lin, size, size, c, srcs[i % n_res])
-        outs = [pkg.Image(lout, out_size, out_size, c, d) for d in dsts[i % n_res]]
-        if wl.get("faces"):
-            pkg.reproject_multi(im_in, outs, 1, wl["interp"], np.stack([bench.make_rot(pkg, f) for f in wl["faces"]]), post=wl.get("post"))
+        if faces:
+            pkg.reproject_multi(ins[i % n_res], outs[i % n_res], 1, wl["interp"], np.stack([bench.make_rot(pkg, f) for f in faces]), post=wl.get("post"))
         else:
-            pkg.reproject(im_in, outs[0], 1, wl["interp"], bench.make_rot(pkg, wl["rot"]), post=wl.get("post"))
+            pkg.reproject(ins[i % n_res], outs[i % n_res][0], 1, wl["interp"], bench.make_rot(pkg, wl["rot"]), post=wl.get("post"))
         torch.cuda.synchronize()
-    order.append({"workload": name, "frames": REPS, "launches_per_frame": len(wl.get("faces") or [None])})
-    del srcs, dsts
+    order.append({"workload": name, "frames": REPS, "drop": 2, "launches_per_frame": len(faces or [None])})
+    if not faces:
+        separator()
+        for i in range(BATCH_LAUNCHES):
+            pkg.reproject_batch(ins, [o[0] for o in outs], 1, wl["interp"], bench.make_rot(pkg, wl["rot"]), post=wl.get("post"))
+            torch.cuda.synchronize()
+        order.append({"workload": name + "@batch16", "frames": BATCH_LAUNCHES, "drop": 1, "launches_per_frame": 1})
+    del srcs, dsts, ins, outs
     torch.cuda.empty_cache()
 with open(order_path, "w") as f:
     json.dump(order, f)

@@ -8,7 +8,7 @@ The probe therefore launches a calibration kernel with known traffic in front of
 (stand-alone post_process on a 4096^2 RGBA frame: 268435456 B read, 268435456 B written) and the
 read-side factor measured on it is applied to the reprojection kernels.  The dispatches are
 attributed to workloads by their ORDER (tools/traffic_probe.py writes it): the calibration
-launches separate them; the first frame of each workload is dropped."""
+launches separate them; the first frames of each group are dropped."""
 import collections
 import csv
 import glob
@@ -48,12 +48,12 @@ def per_workload(counter, pass_dir=None, scale=1024.0):
             cur.append((k, v))
     out = {}
     for o, g in zip(order, groups):
-        lpf, frames = o["launches_per_frame"], o["frames"]
+        lpf, frames, drop = o["launches_per_frame"], o["frames"], o.get("drop", 1)
         if len(g) != lpf * frames:
             out[o["workload"]] = None  # the launch sequence is not what the probe says: do not guess
             continue
-        kept = g[lpf:]  # drop the first frame
-        out[o["workload"]] = (sum(v for _k, v in kept) / (frames - 1), sorted({k for k, _v in kept}), frames - 1)
+        kept = g[lpf * drop:]  # drop the first frame(s): table builds, the launch that fills the geometry cache
+        out[o["workload"]] = (sum(v for _k, v in kept) / (frames - drop), sorted({k for k, _v in kept}), frames - drop)
     return (sum(cal) / len(cal) if cal else None), out
 
 
