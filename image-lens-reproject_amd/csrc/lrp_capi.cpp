@@ -283,12 +283,15 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
              (!in_eqr || P.xsep_tab != nullptr);
     // A batch of nearest-neighbour frames shares its coordinates between up to 16 frames (the plain path of the tile
     // kernel keeps them in registers), which beats sharing them between four mirror pixels: 71 -> 66 us per 4K frame.
-    if (P.quad && n_batch >= 4 && interpolation == LRP_NEAREST) P.quad = 0;
+    // ... and likewise for bilinear (same-box A/B, 16-frame launches: equirect -> rect 91.7 -> 83.7 us, fisheye -> rect 90.9 ->
+    // 84.2, equirect -> fisheye rotated 127.4 -> 118.6 with plain pixels + frames instead of mirrored pixels / rays).
+    const bool batch_plain = n_batch >= 4 && interpolation != LRP_BICUBIC && num_samples == 1;
+    if (P.quad && batch_plain) P.quad = 0;
     const bool window = interpolation == LRP_BICUBIC && kernel_choice() >= 2 && num_samples == 1 &&
                         (out->channels == 4 || out->channels == 3 || out->channels == 5);
     // Equidistant target, rotated (or an equirectangular source): the four mirror pixels still
     // share the ray through the output lens (tile kernels only).
-    if (!band && !P.quad && !window && quad_enabled() && kernel_choice() != 3 && num_samples == 1 &&
+    if (!band && !P.quad && !window && !batch_plain && quad_enabled() && kernel_choice() != 3 && num_samples == 1 &&
         out->lens.type == LRP_FISHEYE_EQUIDISTANT)
       P.quad = 2;
     P.win_coef = kernel_choice() == 2;
@@ -328,8 +331,16 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     // and leaves them there when it is the first.  Both run plain blocks: the entry is a plain per-pixel map.
     // (... and the batched launches of a rectilinear view rendered into a panorama, whose wavefronts render one frame each:
     // the in-view strips of that mapping wait for gathers and gain nothing from walking several frames.)
+    // Nearest / bilinear single launches (tile kernel, one sample per pixel) use the coordinate map of the same entries.
     const bool batch_by_frame = n_batch > 0 && oi == 2 && im == lrp::kInRect;
-    if (window && (n_batch <= 0 || batch_by_frame) && !band && kernel_choice() == 2 && knob(kKnobGeoCache) != 0) {
+    // (nearest without a rotation: the mirrored pixels of the compute kernel are as fast as a load per pixel — 75.8 against 78.2 us
+    // per 4K frame — and need no entry)
+    // (... and a rectilinear source under a rectilinear / equirectangular target: four divides a pixel cost less than the 8 bytes
+    // a pixel the map adds to these memory-bound kernels — rect -> equirect nearest 105 -> 117 us, bilinear 144 -> 159 with it)
+    const bool cheap_coordinates = im == lrp::kInRect && out->lens.type != LRP_FISHEYE_EQUIDISTANT;
+    const bool tile_single = !window && interpolation != LRP_BICUBIC && num_samples == 1 && n_batch <= 0 &&
+                             !(interpolation == LRP_NEAREST && P.quad != 0) && !cheap_coordinates;
+    if (((window && (n_batch <= 0 || batch_by_frame)) || tile_single) && !band && kernel_choice() == 2 && knob(kKnobGeoCache) != 0) {
       lrp::GeoKey key;
       std::memset(&key, 0, sizeof(key));
       key.device = device;
@@ -339,12 +350,13 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
       key.has_rot = P.has_rot;
       key.out_lens = P.out_lens, key.in_lens = P.in_lens;
       if (P.has_rot) std::memcpy(key.rot, P.rot, sizeof(key.rot));
-      lrp::geo_acquire(key, true, stream, &geo);
+      lrp::geo_acquire(key, window, stream, &geo);
       if (geo.mode != 0) {
         P.geo_mode = geo.mode;
         P.geo_xy = geo.xy;
         P.geo_box = geo.box;
         P.win_mode = 0;
+        P.quad = 0; // (tile kernels: the plain path writes / the GeoRead kernels read the map)
         P.blocks_per_wave = knob(kKnobGeoStrip); // 0: the launcher decides
         P.rgbaz_runs = (out->lens.type == LRP_EQUIRECTANGULAR && in->lens.type == LRP_RECTILINEAR) ? 1 : 0;
       }

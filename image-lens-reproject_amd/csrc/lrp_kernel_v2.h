@@ -873,9 +873,13 @@ __device__ __forceinline__ void store_tile_row(const KParams &P, float *run_lds,
 #ifndef LRP_TILE_MINWAVES_FRAMES
 #define LRP_TILE_MINWAVES_FRAMES 4 // the frame-loop instantiations keep <= 128 VGPRs: they are bound by memory and need the wavefronts
 #endif
-template <int OutLens, int InMode, int Interp, int CH, bool Frames = false>
-__global__ __launch_bounds__(kT2Threads, Frames ? LRP_TILE_MINWAVES_FRAMES : LRP_TILE_MINWAVES) void reproject_tile_kernel(const KParams Pk) {
+// GeoRead: the instantiation whose pixels LOAD their source coordinates from a geometry-cache entry (lrp_geocache.h; the
+// map is written as a side output by the plain path below when P.geo_mode == 1): nearest / bilinear, one sample per pixel,
+// whole images; no lens math compiled in, the output lens is irrelevant (kRect by convention).
+template <int OutLens, int InMode, int Interp, int CH, bool Frames = false, bool GeoRead = false>
+__global__ __launch_bounds__(kT2Threads, (Frames || GeoRead) ? LRP_TILE_MINWAVES_FRAMES : LRP_TILE_MINWAVES) void reproject_tile_kernel(const KParams Pk) {
   constexpr bool Loop = (InMode == kInEquirectLoop);
+  static_assert(!GeoRead || (!Frames && Interp != 2 && OutLens == kRect), "GeoRead tile kernel: nearest / bilinear, single launches");
   const int frames_per_wave = Frames ? (Pk.frames_per_wave > 0 ? Pk.frames_per_wave : 1) : 1;
   const int frame0 = Pk.batch_n > 0 ? (int)blockIdx.y * frames_per_wave : 0;
   const int n_frames = (Frames && Pk.batch_n > 0) ? min(frames_per_wave, Pk.batch_n - frame0) : 1;
@@ -889,7 +893,7 @@ __global__ __launch_bounds__(kT2Threads, Frames ? LRP_TILE_MINWAVES_FRAMES : LRP
   if (!xcd_tile(P.tiles_x, P.tiles_y, tx, ty)) return; // whole workgroup
   // Alias pairs (see the window kernel): a rectilinear view rendered into a panorama appears a second time behind
   // the camera, from the same source texels; consecutive workgroups of an XCD take the two tiles that read them.
-  if constexpr (LRP_WIN_ALIAS_PAIRS != 0 && OutLens == kEquirect && InMode == kInRect) {
+  if constexpr (LRP_WIN_ALIAS_PAIRS != 0 && (OutLens == kEquirect || GeoRead) && InMode == kInRect) {
     if (P.alias_pairs == 0) {
       // (a partial panorama has no second copy: raster order keeps neighbouring tiles together, 1-3 % faster there)
     } else if (P.quad == 1) { // quadrant tiles: columns from both ends inwards (tile t shares its texels with tile tiles_x-1-t)
@@ -942,6 +946,27 @@ __global__ __launch_bounds__(kT2Threads, Frames ? LRP_TILE_MINWAVES_FRAMES : LRP
       }
     }
   };
+  if constexpr (GeoRead) {
+    const int xg = x < P.out_w ? x : P.out_w - 1;
+    const vf2 *const map = reinterpret_cast<const vf2 *>(P.geo_xy);
+    auto coords = [&](int k, float &sx, float &sy) {
+      const int yk = y_first + k;
+      const vf2 v = __builtin_nontemporal_load(map + ((uint32_t)(yk < P.y_end ? yk : P.y_end - 1) * (uint32_t)P.out_w + (uint32_t)xg));
+      sx = v.x;
+      sy = v.y;
+    };
+    auto finish = [&](int k, const Px<CH> &sample) {
+      const int yk = y_first + k;
+      Px<CH> a = px_zero<CH>();
+      px_add<CH>(a, sample); // :334-336
+      const bool row_inside = yk < P.y_end; // wave-uniform
+      const uint32_t row_first = (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x0;
+      store_tile_row<CH, true>(P, run_lds, row_inside && x0 + kT2W <= P.out_w, row_inside && x < P.out_w, lane, row_first,
+                               row_first + (uint32_t)lane, a);
+    };
+    sample_pixels<Interp, Loop, CH, kT2Rows>(P, src, coords, finish);
+    return;
+  }
   if (P.quad == 2) {
     // Mirrored rays (equidistant target, num_samples == 1, any rotation): the ray through the
     // OUTPUT lens — a square root, sincosf and three divides per pixel that no table can hold,
@@ -1037,9 +1062,13 @@ __global__ __launch_bounds__(kT2Threads, Frames ? LRP_TILE_MINWAVES_FRAMES : LRP
   if (ns == 1 && Interp != 2) {
     // one sample per pixel, any rotation: the rows of this lane with their tap requests ahead of the arithmetic
     const ColTerms col = column_terms<OutLens>(P, xe, 0);
+    const bool geo_write = !Frames && P.geo_mode == 1 && blockIdx.y == 0; // side output: the coordinate map of the geometry cache
     auto coords = [&](int k, float &sx, float &sy) {
       const int yk = y_first + k;
-      pixel_source<OutLens, InMode>(P, col, yk < P.y_end ? yk : P.y_end - 1, 0, sx, sy); // (row: wave-uniform)
+      const int ye = yk < P.y_end ? yk : P.y_end - 1; // (row: wave-uniform)
+      pixel_source<OutLens, InMode>(P, col, ye, 0, sx, sy);
+      if constexpr (!Frames)
+        if (geo_write) reinterpret_cast<vf2 *>(P.geo_xy)[(uint32_t)ye * (uint32_t)P.out_w + (uint32_t)xe] = vf2{sx, sy};
     };
     auto finish = [&](int k, const Px<CH> &sample) {
       const int yk = y_first + k;
@@ -2400,6 +2429,17 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
 
 using TileKernelFn = void (*)(const KParams);
 
+// The GeoRead tile kernels: one per source mode.
+template <int Interp, int CH> struct TileGeoKernelTable {
+  static TileKernelFn get(int in_mode) {
+    static_assert(Interp != 2, "nearest / bilinear");
+    static const TileKernelFn table[4] = {
+        reproject_tile_kernel<kRect, kInRect, Interp, CH, false, true>, reproject_tile_kernel<kRect, kInEquidistant, Interp, CH, false, true>,
+        reproject_tile_kernel<kRect, kInEquirect, Interp, CH, false, true>, reproject_tile_kernel<kRect, kInEquirectLoop, Interp, CH, false, true>};
+    return table[in_mode];
+  }
+};
+
 template <int Interp, int CH, bool Frames> struct TileKernelTable {
   static TileKernelFn get(int out_idx, int in_mode) {
     static const TileKernelFn table[3][4] = {
@@ -2443,7 +2483,14 @@ template <int Interp> hipError_t launch_tile_interp(KParams P, int out_idx, int 
     groups = (P.batch_n + F - 1) / F;
   }
   TileKernelFn fn;
-  if (P.frames_per_wave > 1) {
+  if (P.geo_mode == 2) { // coordinates from the geometry cache (the host asks for it for single whole-image launches only)
+    if constexpr (Interp != 2) {
+      if (P.quad != 0 || P.batch_n > 0 || P.num_samples != 1 || P.y_offset != 0 || P.y_end != P.out_h) return hipErrorInvalidValue;
+      fn = P.channels == 4 ? TileGeoKernelTable<Interp, 4>::get(in_mode) : P.channels == 3 ? TileGeoKernelTable<Interp, 3>::get(in_mode) : TileGeoKernelTable<Interp, 5>::get(in_mode);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  } else if (P.frames_per_wave > 1) {
     if constexpr (Interp != 2)
       fn = P.channels == 4   ? TileKernelTable<Interp, 4, true>::get(out_idx, in_mode)
            : P.channels == 3 ? TileKernelTable<Interp, 3, true>::get(out_idx, in_mode)
