@@ -259,7 +259,17 @@ template <int CH> __device__ __forceinline__ void px_add(Px<CH> &a, const Px<CH>
 // cubicInterpolate (src/reproject.cpp:92-98), same association order as catmull_rom().
 __device__ __forceinline__ f2 catmull_rom2(const f2 a, const f2 b, const f2 c, const f2 d, float t, float half_t) {
   const f2 inner = ((3.0f * (b - c)) + d) - a;
+#if defined(LRP_FUSED_EXACT_PRODUCTS) && !LRP_NO_PACKED
+  // Timing experiment (tools/ablate_units.sh; NOT the reference's bits for texels of 2^126 and more): 2 a and 4 c are exact
+  // products unless they overflow, so fma(2, a, -(5 b)) and fma(4, c, x) round like the separate multiply + add — 15 instead of
+  // 17 operations.  Guarding it needs a magnitude test of every texel, which costs what it saves.
+  const f2 m5b = 5.0f * b;
+  const f2 x0 = __builtin_elementwise_fma(f2{2.0f, 2.0f}, a, -m5b);
+  const f2 x1 = __builtin_elementwise_fma(f2{4.0f, 4.0f}, c, x0);
+  const f2 mid = (x1 - d) + t * inner;
+#else
   const f2 mid = ((((2.0f * a) - (5.0f * b)) + (4.0f * c)) - d) + t * inner;
+#endif
   const f2 outer = (c - a) + t * mid;
   return b + half_t * outer;
 }
