@@ -2425,7 +2425,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
             const Px<5> s5 = sample_direct<2, Loop, 5, LRP_WIN_MINWAVES5 >= 4>(P, src, psx, psy); // (LowReg at 128 VGPRs)
             s = Rgba{s5.lo, s5.hi, s5.e};
           } else {
-            s = sample_direct<2, Loop, 4, false, 4 * CH>(P, src, psx, psy);
+            s = sample_direct<2, Loop, 4, (LRP_WIN_MINWAVES >= 5), 4 * CH>(P, src, psx, psy); // (LowReg when five waves per SIMD are asked for: 96 VGPRs)
           }
         }
         emit(g, k, s, std::integral_constant<bool, kRunsEverywhere>{}, !GeoRead || P.rgbaz_runs != 0);

@@ -70,7 +70,10 @@ def pytest_runtest_logreport(report):
 
 
 def pytest_sessionfinish(session, exitstatus):
-    if _state["oracle_skipped"] and (_state["fixture_passed"] == 0 or _state["fixture_failed"]):
+    # (only a session that selected gpu-marked tests owes this evidence: a CPU-only run, or a single CPU file, on a host with
+    # another libm reports its skips and passes as they are)
+    gpu_selected = any(item.get_closest_marker("gpu") is not None for item in getattr(session, "items", []))
+    if gpu_selected and _state["oracle_skipped"] and (_state["fixture_passed"] == 0 or _state["fixture_failed"]):
         print(f"\nERROR: oracle tests were skipped (host libm differs at {_state['oracle_skipped']}) and the committed-fixture "
               f"tests ({FIXTURE_MODULE}) did not run green ({_state['fixture_passed']} passed, {_state['fixture_failed']} failed): "
               "no parity evidence in this session")
