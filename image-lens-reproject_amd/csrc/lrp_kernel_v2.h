@@ -961,7 +961,7 @@ __global__ __launch_bounds__(kT2Threads, (Frames || GeoRead) ? LRP_TILE_MINWAVES
     const vf2 *const map = reinterpret_cast<const vf2 *>(P.geo_xy);
     auto coords = [&](int k, float &sx, float &sy) {
       const int yk = y_first + k;
-      const vf2 v = __builtin_nontemporal_load(map + ((uint32_t)(yk < P.y_end ? yk : P.y_end - 1) * (uint32_t)P.out_w + (uint32_t)xg));
+      const vf2 v = __builtin_nontemporal_load(map + geo_map_index(xg, yk < P.y_end ? yk : P.y_end - 1, P.out_w));
       sx = v.x;
       sy = v.y;
     };
@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(kT2Threads, (Frames || GeoRead) ? LRP_TILE_MINWAVES
       const int ye = yk < P.y_end ? yk : P.y_end - 1; // (row: wave-uniform)
       pixel_source<OutLens, InMode>(P, col, ye, 0, sx, sy);
       if constexpr (!Frames)
-        if (geo_write) reinterpret_cast<vf2 *>(P.geo_xy)[(uint32_t)ye * (uint32_t)P.out_w + (uint32_t)xe] = vf2{sx, sy};
+        if (geo_write) reinterpret_cast<vf2 *>(P.geo_xy)[geo_map_index(xe, ye, P.out_w)] = vf2{sx, sy};
     };
     auto finish = [&](int k, const Px<CH> &sample) {
       const int yk = y_first + k;
@@ -1811,7 +1811,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
             const int yk = y_lane + kBlkH * block_row(g) + kPassRows * k;
             const int ye = yk < qh ? yk : qh - 1;
             // (lanes / rows beyond the image hold the pixel they were clamped to and write its values to its place again)
-            map[(uint32_t)ye * (uint32_t)P.out_w + (uint32_t)xe] = vf2{b.sx[k], b.sy[k]};
+            map[geo_map_index(xe, ye, P.out_w)] = vf2{b.sx[k], b.sy[k]};
           }
         }
         const int words[7] = {planned ? e.lo_x : 0, planned ? e.hi_x : 0, planned ? e.lo_y[0] : 0, planned ? e.hi_y[0] : 0,
@@ -1835,7 +1835,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
     for (int k = 0; k < 4; ++k) {
       const int yk = y_lane + kBlkH * block_row(g) + kPassRows * k;
       const int ye = yk < qh ? yk : qh - 1;
-      const vf2 v = __builtin_nontemporal_load(map + ((uint32_t)ye * (uint32_t)P.out_w + (uint32_t)xe));
+      const vf2 v = __builtin_nontemporal_load(map + geo_map_index(xe, ye, P.out_w));
       b.sx[k] = v.x;
       b.sy[k] = v.y;
     }

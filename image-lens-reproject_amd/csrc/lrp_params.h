@@ -93,7 +93,7 @@ struct KParams {
   // HBM between calls.  geo_mode 0: not used; 1: this launch computes as usual and writes the entry as a side output;
   // 2: it loads instead of computing (the GeoRead instantiations; same values, hence the same bits).
   int32_t geo_mode;
-  float *geo_xy;       // [out_h][out_w] (sx, sy): the top-left-origin source texel coordinates of src/reproject.cpp:323-324
+  float *geo_xy;       // (sx, sy) of every output pixel, element geo_map_index(x, y): the top-left-origin source texel coordinates of src/reproject.cpp:323-324
   int32_t *geo_box;    // window kernel: [block rows][blocks_x][8] (geo_layout below)
   int32_t rgbaz_runs;  // GeoRead window kernel: a rectilinear view rendered into a panorama — the big-window variant; RGBAZ: every block leaves as 16-byte chunks (what the compute instantiations of that mapping do at compile time)
 };
@@ -107,6 +107,10 @@ struct GeoLayout {
   size_t xy_bytes, box_bytes;
   size_t bytes() const { return xy_bytes + box_bytes; }
 };
+// Element (float2) of output pixel (x, y) in the coordinate map: row-major.  (A map stored in 16 x 16 tiles — 2 KiB contiguous
+// bytes per block of the window kernel instead of 16 row segments of 128 bytes — measured the same for the window kernels
+// and 2-3 % slower for the tile kernels: profiles/r04_experiments_ab.txt.)
+inline __host__ __device__ uint32_t geo_map_index(int x, int y, int out_w) { return (uint32_t)y * (uint32_t)out_w + (uint32_t)x; }
 inline GeoLayout geo_layout(int out_w, int out_h, bool with_boxes) {
   GeoLayout L{};
   L.xy_bytes = (size_t)out_w * (size_t)out_h * 8;
