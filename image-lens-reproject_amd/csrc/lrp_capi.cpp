@@ -329,10 +329,9 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     // Geometry cache (lrp_geocache.h): a single whole-image launch of the window kernel loads the coordinates of its
     // pixels and the window extremes of its blocks when an earlier launch of the same geometry has left them in HBM,
     // and leaves them there when it is the first.  Both run plain blocks: the entry is a plain per-pixel map.
-    // (... and the batched launches of a rectilinear view rendered into a panorama, whose wavefronts render one frame each:
-    // the in-view strips of that mapping wait for gathers and gain nothing from walking several frames.)
+    // Batched bicubic launches read the entry as well (their wavefronts load a block's coordinates once and walk its frames);
+    // the first frame of a batch whose geometry has no entry yet is rendered by a launch of its own, which writes it.
     // Nearest / bilinear single launches (tile kernel, one sample per pixel) use the coordinate map of the same entries.
-    const bool batch_by_frame = n_batch > 0 && oi == 2 && im == lrp::kInRect;
     // (nearest without a rotation: the mirrored pixels of the compute kernel are as fast as a load per pixel — 75.8 against 78.2 us
     // per 4K frame — and need no entry)
     // (... and a rectilinear source under a rectilinear / equirectangular target: four divides a pixel cost less than the 8 bytes
@@ -340,7 +339,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     const bool cheap_coordinates = im == lrp::kInRect && out->lens.type != LRP_FISHEYE_EQUIDISTANT;
     const bool tile_single = !window && interpolation != LRP_BICUBIC && num_samples == 1 && n_batch <= 0 &&
                              !(interpolation == LRP_NEAREST && P.quad != 0) && !cheap_coordinates;
-    if (((window && (n_batch <= 0 || batch_by_frame)) || tile_single) && !band && kernel_choice() == 2 && knob(kKnobGeoCache) != 0) {
+    if ((window || tile_single) && !band && kernel_choice() == 2 && knob(kKnobGeoCache) != 0) {
       lrp::GeoKey key;
       std::memset(&key, 0, sizeof(key));
       key.device = device;
@@ -371,14 +370,23 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
       e = launch();
     } else {
       e = hipSuccess;
-      for (int first = 0; first < n_batch && e == hipSuccess; first += lrp::kMaxBatch) {
+      int first = 0;
+      if (P.geo_mode == 1 || P.geo_mode == 3) {
+        // the frame that writes the entry goes alone (the instantiations without the frame loop have the side output); the
+        // rest of the batch follows on the same stream and reads it
+        P.src = in[0].data;
+        P.dst = out[0].data;
+        e = launch();
+        P.geo_mode = 2;
+        first = 1;
+      }
+      for (; first < n_batch && e == hipSuccess; first += lrp::kMaxBatch) {
         P.batch_n = std::min(lrp::kMaxBatch, n_batch - first);
         for (int i = 0; i < P.batch_n; ++i) {
           P.batch_src[i] = in[first + i].data;
           P.batch_dst[i] = out[first + i].data;
         }
         e = launch();
-        if (P.geo_mode == 1 || P.geo_mode == 3) P.geo_mode = 2; // the first launch wrote the entry; the rest of this call follows it on the same stream
       }
     }
     lrp::geo_launched(&geo, stream, e == hipSuccess);

@@ -1340,8 +1340,8 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
   static_assert(CH == 3 || CH == 4 || CH == 5, "window kernel: RGB, RGBA or RGBAZ");
   static_assert(QMode != 2 || (OutLens != kEquidistant && InMode != kInEquidistant), "rows-only mirroring goes through the column-separable source x");
   static_assert(QMode != 3 || OutLens == kRect, "columns-only mirroring needs vz == -1");
-  static_assert(!GeoRead || (QMode == 0 && !Frames && (OutLens == kRect || (OutLens == kEquirect && InMode == kInRect))),
-                "GeoRead: plain blocks, no frame loop, one instantiation per source mode (+ the big-window variant of the rectilinear source)");
+  static_assert(!GeoRead || (QMode == 0 && (OutLens == kRect || (OutLens == kEquirect && InMode == kInRect && !Frames))),
+                "GeoRead: plain blocks, one instantiation per source mode (+ the big-window variant of the rectilinear source)");
   // The big-window variant (GeoRead, "OutLens" kEquirect by convention; chosen by the host for a rectilinear view rendered
   // into a panorama, BASELINE configs[3]): the in-view blocks of that mapping are minified 3-5 x 1.5-3 — the window of a 16 x 4
   // PASS is ~67 x 11 texels, too wide for one DMA instruction per row and too large for 10 KiB next to three other
@@ -2208,7 +2208,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
       asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); // window g has landed; block g-1's last store may be in flight
 #endif
     if constexpr (GeoRead)
-      if (g + 1 < G) geo_fetch(g + 1, nxt);
+      if (g + 1 < G && f == 0) geo_fetch(g + 1, nxt);
     const float4 *const win = win0;
     // The tier of this block in a scalar register for the branches below: carried through the block loop inside `cur` it
     // ends up in a VGPR (the kernel is at the SGPR limit), and every test of it then costs a v_and + v_cmp and the
@@ -2230,7 +2230,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
       const Rgba cs = corner_value(cur);
       if (Quad && !kSharedRays && last_frame && g + 1 < G) coords(g + 1, nxt);
       if constexpr (GeoRead)
-        if (g + 1 < G) geo_plan(nxt);
+        if (g + 1 < G && last_frame) geo_plan(nxt);
       emit(g, 0, cs, std::true_type{});
       emit(g, 1, cs, std::true_type{});
       emit(g, 2, cs, std::true_type{});
@@ -2251,7 +2251,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
         const int k = 2 * h + kk;
         if (Quad && !kSharedRays && k == 3 && last_frame && g + 1 < G) coords(g + 1, nxt); // only its box is kept
         if constexpr (GeoRead)
-          if (k == 3 && g + 1 < G) geo_plan(nxt);
+          if (k == 3 && g + 1 < G && last_frame) geo_plan(nxt);
         const bool last_pass = k == 3;
         float psx = cur.sx[k], psy = cur.sy[k];
         if constexpr (Quad && !kSharedRays) quad_xy(image_of(g), k, psx, psy); // re-derived (2-4 instructions) instead of held in registers
@@ -2542,6 +2542,18 @@ template <int QMode, int CH, bool Frames> struct WinKernelTable {
 };
 
 // The GeoRead instantiations (plain blocks, coordinates from the geometry cache): one per source mode.
+// ... and with the frame loop: batched launches of a geometry whose entry exists.  A wavefront loads the coordinates and the
+// extremes of its block once and renders it for up to 16 frames (same box, 16-frame launches: headline 104.3 -> 100.9 us per
+// frame, general rotation 98.3 -> 95.7 against the instantiations that compute their coordinates once per 16 frames — those
+// carry the lens math in registers: 68-90 spilled SGPRs against 11-22 here).
+template <int CH> struct WinGeoFramesKernelTable {
+  static TileKernelFn get(int in_mode) {
+    static const TileKernelFn table[4] = {
+        reproject_bicubic_win_kernel<kRect, kInRect, 0, CH, true, true>, reproject_bicubic_win_kernel<kRect, kInEquidistant, 0, CH, true, true>,
+        reproject_bicubic_win_kernel<kRect, kInEquirect, 0, CH, true, true>, reproject_bicubic_win_kernel<kRect, kInEquirectLoop, 0, CH, true, true>};
+    return table[in_mode];
+  }
+};
 template <int CH> struct WinGeoKernelTable {
   static TileKernelFn get(int in_mode, bool big_windows) {
     static const TileKernelFn table[4] = {
@@ -2575,7 +2587,7 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
     if (GeoRead && P.blocks_per_wave > 0) G = std::min(P.blocks_per_wave, kGeoStripRows); // the caller's override (lrp_debug_set "geo_strip")
     // (a batch whose wavefronts walk several frames pipelines the windows of one block across its frames: one block per
     // wavefront measured 2-3 % faster there — equirect -> fisheye rotated 143 -> 139 us, rect -> rect 130.5 -> 128 —, four 5 % slower)
-    if (!GeoRead && P.batch_n > 1 && !(out_idx == 2 && in_mode == kInRect)) G = 1;
+    if (P.batch_n > 1 && !(out_idx == 2 && in_mode == kInRect)) G = 1;
     const bool strip_forced = GeoRead && P.blocks_per_wave > 0;
     while (!strip_forced && G > 1 && (long long)P.tiles_x * kWinWaves * ((row_blocks + G - 1) / G) < 8192) G >>= 1; // >= 2 rounds of wavefronts
     P.blocks_per_wave = G;
@@ -2588,19 +2600,20 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
   int groups = P.batch_n > 0 ? P.batch_n : 1;
   const int frames_override = P.frames_per_wave; // on entry: 0 = automatic
   P.frames_per_wave = 1;
-  if (P.batch_n > 1 && !GeoRead) { // (GeoRead: a frame per wavefront; its coordinates come from HBM either way)
+  if (P.batch_n > 1) {
     const long long units = (long long)n_tiles * kWinWaves * P.batch_n;
     int F = (int)std::min<long long>(P.batch_n, std::max<long long>(1, units / 8192));
     // a rectilinear view inside a panorama: a quarter of the strips (the ones in view) carry most of the frame's time and
     // gain nothing from shared coordinates (they wait for gathers) — 16 frames long they unbalance the launch (223 -> 256 us)
     if (out_idx == 2 && in_mode == kInRect) F = 1;
     if (frames_override > 0) F = std::max(1, std::min(P.batch_n, frames_override)); // the caller's override (lrp_debug_set "batch_frames": A/B runs, tests)
+    if (P.geo_mode == 1 || P.geo_mode == 3) F = 1; // the launch that writes a geometry-cache entry: the instantiations without the frame loop have the side output
     P.frames_per_wave = F;
     groups = (P.batch_n + F - 1) / F;
   }
   TileKernelFn fn;
   if constexpr (GeoRead)
-    fn = WinGeoKernelTable<CH>::get(in_mode, P.rgbaz_runs != 0);
+    fn = P.frames_per_wave > 1 ? WinGeoFramesKernelTable<CH>::get(in_mode) : WinGeoKernelTable<CH>::get(in_mode, P.rgbaz_runs != 0);
   else
     fn = P.frames_per_wave > 1 ? WinKernelTable<QMode, CH, true>::get(out_idx, in_mode) : WinKernelTable<QMode, CH, false>::get(out_idx, in_mode);
   if (!fn) return hipErrorInvalidValue; // (the host never asks for a mode outside its cells)

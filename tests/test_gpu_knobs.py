@@ -44,6 +44,8 @@ SETTINGS = {
     "batch_frames1": {"geo_cache": 0, "batch_frames": 1},
     "batch_frames5": {"geo_cache": 0, "batch_frames": 5},
     "batch_frames16_geo": {"geo_cache": 1, "batch_frames": 16},
+    "batch_frames3_geo": {"geo_cache": 1, "batch_frames": 3},
+    "batch_frames0_geo": {"geo_cache": 1},  # (batched launches read the geometry cache; the first frame of the first batch writes it)
     "multi_fork0": {"geo_cache": 0, "multi_fork": 0},
     "multi_fork3": {"geo_cache": 0, "multi_fork": 3},
     "multi_fork3_geo": {"geo_cache": 1, "multi_fork": 3},
