@@ -1,0 +1,1035 @@
+// lrp_win_kernel.h — the bicubic LDS-window kernel and its launcher.
+#pragma once
+
+#include "lrp_kernel_common.h"
+#include "lrp_tile_kernel.h" // TileKernelFn
+#include "lrp_win_plan.h"
+#include "lrp_win_tiers.h"
+
+namespace lrp {
+
+// ---- the bicubic window kernel (RGBA / RGB float) ------------------------------------
+//
+// 16 float4 gathers per pixel keep the texture-address path of a CU busy for ~256 cycles per
+// wavefront and thrash its L1; the taps of neighbouring pixels overlap almost completely, so
+// each wavefront stages the source window of its own 16 x 16 output block in LDS once:
+//   * block = 16 x 16 output pixels per wavefront, 4 passes of 16 columns x 4 rows
+//     (square blocks keep the window small under any rotation of the mapping);
+//   * all 256 pixels interior (no clamped / wrapped tap; the common case) ->
+//     window = [min int(sx) - 1, max int(sx) + 2] x [min int(sy) - 1, max int(sy) + 2],
+//     reduced with DPP-fused v_min_i32 / v_max_i32, no LDS, no barrier;
+//   * the window rows are fetched with global_load_lds_dwordx4 / dwordx3 (LDS-DMA: per-lane
+//     global address, wave-uniform LDS row base + lane * 16; no VGPR round trip), lanes
+//     beyond the window width masked off;
+//   * s_waitcnt vmcnt orders the wavefront's own ds_reads behind its DMA — the window is
+//     private to the wavefront, so there is no workgroup barrier at all;
+//   * tier 1 (magnified mappings): the weight-independent 11 of the 17 operations of every
+//     vertical cubic are evaluated once per window column and row into three coefficient
+//     planes behind the window; a pixel reads 12 coefficient vectors + 4 taps;
+//   * tier 2 (window fits, planes do not): a pixel's 16 taps are ONE LDS address + 3 row
+//     increments and the immediates 0/16/32/48.
+// A block with a border / seam / NaN pixel, or a window larger than the per-wave LDS budget
+// (strong minification), takes sample_direct() per pass instead.
+#if defined(LRP_TIER_STATS) // diagnostic builds (tools/ablate.sh): blocks per tier (coefficients, raw taps, direct)
+__device__ unsigned g_tier_stats[8]; // coefficient, raw, direct, corner, beyond a row, beyond a column, split
+#endif
+
+
+// One wavefront walks its strip of `blocks_per_wave` blocks (plain: top to bottom; mirrored: a
+// quadrant block and its three mirror images):
+//     A(0); DMA(0)
+//     for g:  A(g+1)                        | plain blocks: coordinates + box of the next block
+//             s_waitcnt vmcnt(0 or 1)       | window g has landed
+//             half 0: planes, passes 0, 1   | coefficient planes of the half, then its two passes
+//             half 1: planes, passes 2, 3   | mirrored blocks derive A(g+1) at the start of pass 3
+//                     DMA(g+1) inside pass 3, behind its last reads of the raw window and ahead
+//                     of its arithmetic and its store (vmcnt retires in order)
+// One 10 KiB buffer per wavefront: 4 wavefronts per SIMD (a double-buffered variant at 3 per
+// SIMD measured 5-25 % slower).
+//
+// CH == 3 (RGB, what the PNG / JPEG path delivers): global_load_lds_dwordx3 reads 12 bytes per
+// lane and writes them at a 16-byte lane stride (measured: the fourth dword of each slot is left
+// untouched), i.e. the hardware expands RGB texels into RGBA-sized slots.  Everything after the
+// DMA is therefore the RGBA code; the fourth component carries stale LDS contents through the
+// arithmetic (no traps are enabled) and is never stored.
+//
+// QMode — which mirror images of a block one wavefront renders with a single evaluation of stage 1 of the
+// coordinate math (everything between the output pixel and the last quantity that only changes sign under the mirror):
+//   0  plain blocks: none (any rotation)
+//   1  both axes (no rotation): the block and its three mirror images, g = 0..3, bit 0 mirrors x, bit 1 mirrors y
+//   2  rows only: a rotation about the vertical axis (pan) leaves the mapping symmetric top / bottom — the rotated ray of
+//      pixel (x, H-1-y) is the ray of (x, y) with its y negated, exactly (rows 0 and 2 of the matrix do not see vy: that
+//      is the column-separable case, which the host requires; row 1 is (+-0, c, +-0)).  Images g = 0, 2.  The four
+//      side faces of a cubemap, any --rotation pan,0,0.
+//   3  columns only: a rotation about the horizontal axis (pitch) with a rectilinear target (vz = -1 exactly) leaves it
+//      symmetric left / right: rows 1 and 2 of the matrix are (+-0, c, -s) / (+-0, s, c), so ny, nz do not see vx (the
+//      zero products vanish in sums that end in the non-zero R5 vz, R8 vz) and nx = vx.  Images g = 0, 1.  The top and
+//      bottom faces of a cubemap, any --rotation 0,pitch,0.
+//   4  shared rays: an equidistant TARGET under any rotation.  Its ray costs a square root, a double-precision sincosf
+//      and three divides per pixel, no table can hold it (the lens is not separable), and it is odd in cx and in cy by
+//      construction (src/reproject.cpp:171-186: r_px is even, vx = s cx, vy = s cy, vz = cos theta) — so the ray is
+//      evaluated once per quadrant pixel and its sign-flipped copies go through the rotation and the source lens per
+//      mirror image, like the pixels of plain blocks.  Images g = 0..3.
+// The host (lrp_capi.cpp win_mirror_mode) checks the matrix entries and the symmetry flags of the output-lens tables.
+// Frames: the instantiation for batched launches whose wavefronts walk several frames (the frame loop costs the
+// one-frame case registers, so single launches keep an instantiation without it).
+// GeoRead: the instantiation that LOADS the source coordinates of its pixels and the window extremes of its blocks from
+// a geometry-cache entry (lrp_params.h, lrp_geocache.h) instead of deriving them from the lenses: what the frames of a
+// batch share in registers, single launches of one geometry share through HBM.  The entry is written as a side output by
+// the plain-block instantiation (P.geo_mode == 1) the first time a geometry is rendered; the loaded values are the
+// stored ones, so the rendered bits are the same.  No lens math is compiled in: the output lens is irrelevant (kRect by
+// convention), plain blocks only.
+template <int OutLens, int InMode, int QMode, int CH, bool Frames = false, bool GeoRead = false>
+#ifndef LRP_WIN_MINWAVES5
+#define LRP_WIN_MINWAVES5 3 // RGBAZ: 168 VGPRs (the 80 registers of a direct-path tap set do not fit 128 without spilling)
+#endif
+#ifndef LRP_WIN_MINWAVES_AXIS
+#define LRP_WIN_MINWAVES_AXIS 4 // one-axis mirror modes (QMode 2, 3)
+#endif
+#ifndef LRP_WIN_MINWAVES_RAYS
+#define LRP_WIN_MINWAVES_RAYS 3 // shared-ray mode (QMode 4): the rays of four pixels (12 VGPRs) next to the coordinates of two blocks do not fit 128; measured 251 us at four waves per SIMD (66 spilled registers), 227 at three, 236 plain
+#endif
+#ifndef LRP_WIN_MINWAVES_FRAMES
+#define LRP_WIN_MINWAVES_FRAMES 4 // the instantiations with the frame loop
+#endif
+#ifndef LRP_WIN_CAP_BIG
+#define LRP_WIN_CAP_BIG 1280 // window slots of the big-window GeoRead variant: 20 KiB per wavefront, two wavefronts per SIMD
+#endif
+__global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 : CH == 5 ? LRP_WIN_MINWAVES5 : (QMode == 4 ? LRP_WIN_MINWAVES_RAYS : (Frames ? LRP_WIN_MINWAVES_FRAMES : (QMode >= 2 ? LRP_WIN_MINWAVES_AXIS : LRP_WIN_MINWAVES)))) void reproject_bicubic_win_kernel(const KParams Pk) {
+  constexpr bool Quad = QMode != 0;
+  constexpr bool MirX = QMode == 1 || QMode == 3 || QMode == 4, MirY = QMode == 1 || QMode == 2 || QMode == 4;
+  constexpr bool kSharedRays = QMode == 4; // only the ray through the output lens is shared: per-image coordinates are stored like a plain block's
+  static_assert(QMode != 4 || OutLens == kEquidistant, "shared rays: the equidistant target");
+  constexpr int kAllMirrors = (MirX ? 1 : 0) | (MirY ? 2 : 0); // the image mirrored in every mirrored axis
+  using WinBlock = WinBlockT<Quad>;
+  static_assert(CH == 3 || CH == 4 || CH == 5, "window kernel: RGB, RGBA or RGBAZ");
+  static_assert(QMode != 2 || (OutLens != kEquidistant && InMode != kInEquidistant), "rows-only mirroring goes through the column-separable source x");
+  static_assert(QMode != 3 || OutLens == kRect, "columns-only mirroring needs vz == -1");
+  static_assert(!GeoRead || (QMode == 0 && (OutLens == kRect || (OutLens == kEquirect && InMode == kInRect && !Frames))),
+                "GeoRead: plain blocks, one instantiation per source mode (+ the big-window variant of the rectilinear source)");
+  // The big-window variant (GeoRead, "OutLens" kEquirect by convention; chosen by the host for a rectilinear view rendered
+  // into a panorama, BASELINE configs[3]): the in-view blocks of that mapping are minified 3-5 x 1.5-3 — the window of a 16 x 4
+  // PASS is ~67 x 11 texels, too wide for one DMA instruction per row and too large for 10 KiB next to three other
+  // wavefronts' — so this variant holds 20 KiB per wavefront (two wavefronts per SIMD, no register limit to speak of) and
+  // stages pass windows up to 128 texels wide.  tools/microbench/row_gather.hip: rows of that shape arrive at 7.7 TB/s by
+  // LDS-DMA with 8 wavefronts per CU, a window each in flight; per-pixel gathers of the same bytes at 4.5 TB/s in this kernel.
+  constexpr bool kBigWin = GeoRead && OutLens == kEquirect;
+  constexpr int kCap = kBigWin ? LRP_WIN_CAP_BIG : kWinCap; // 16-byte slots of this instantiation's window buffer
+  constexpr int kMaxPassCols = kBigWin ? 128 : 64;          // widest pass window (texels): DMA instructions per window row = ceil(bw / 64)
+  constexpr bool kGeoWrite = !GeoRead && !Frames && QMode == 0 && kWinWaves == 1; // (P.geo_mode == 1: the side output)
+  const bool geo_write = kGeoWrite && (Pk.geo_mode == 1 || Pk.geo_mode == 3) && blockIdx.y == 0; // wave-uniform (3: the extremes only — the map is there; a batched launch: its first frame writes)
+  // Frames of a batched launch share one geometry: the source coordinates of a pixel, the window of a block and its tier
+  // are the same in every frame.  A wavefront therefore renders its strip for `frames_per_wave` consecutive frames
+  // (blockIdx.y = group of frames) and runs everything that does not depend on the pixel DATA — stage 1 of the coordinate
+  // math, the wave-wide box reductions, the window plan — once per block instead of once per block and frame.
+  const int frames_per_wave = Frames ? (Pk.frames_per_wave > 0 ? Pk.frames_per_wave : 1) : 1;
+  const int frame0 = Pk.batch_n > 0 ? (int)blockIdx.y * frames_per_wave : 0;
+  const int n_frames = (Frames && Pk.batch_n > 0) ? min(frames_per_wave, Pk.batch_n - frame0) : 1;
+  auto frame_src = [&](int f) { return Pk.batch_n > 0 ? Pk.batch_src[frame0 + f] : Pk.src; };
+  auto frame_dst = [&](int f) { return Pk.batch_n > 0 ? Pk.batch_dst[frame0 + f] : Pk.dst; };
+  KParams P = Pk; // src / dst: the frame being rendered (set_frame below)
+  P.src = frame_src(0);
+  P.dst = frame_dst(0);
+  constexpr bool Loop = (InMode == kInEquirectLoop);
+  // Edge blocks (WinBlockT::edge) are compiled for the rectilinear source only: a narrow view inside a wider target is
+  // where whole blocks lie beyond one side of the source; in the other instantiations the extra code costs 2-3 % (measured:
+  // fisheye -> rectilinear 100 -> 102.5 us, fisheye -> fisheye 141.5 -> 146) and such blocks take the per-pixel gathers.
+  constexpr bool kEdge = LRP_WIN_EDGE != 0 && InMode == kInRect;
+  // Split blocks (WinBlockT::split) are compiled into the single-launch instantiations only: in the kernels with the frame
+  // loop the extra code costs 2-7 % on mappings that have no such block (measured: equirect -> rect 91 -> 98 us, rect ->
+  // equirect 212 -> 227), and what needs them — the 2048^2 faces of an 8192^2 panorama — arrives as single launches.
+  // ... and for panorama sources only (a large panorama rendered into smaller views is where blocks are a little too large;
+  // the rectilinear-source kernels lost 6 % to the extra code: rect -> equirect 210 -> 223 us).
+  // (... and for the RGBAZ kernels of a rectilinear source: their per-pixel path is 20 gathers a pixel, and the pass windows
+  // below pay there — rect -> equirect RGBAZ 300 -> 288 us, BASELINE configs[3] — while RGBA / RGB lose 4-6 %.)
+  constexpr bool kSplit = LRP_WIN_SPLIT != 0 && !Frames && (InMode == kInEquirect || InMode == kInEquirectLoop || (InMode == kInRect && CH == 5));
+  // Pass windows (below) for rectilinear targets only — perspective views and cubemap faces out of a panorama; in the
+  // fisheye-target kernels the extra code cost 2.5 % (equirect -> fisheye single launches 247 -> 253 us).
+  constexpr bool kPassWin = (kSplit || (GeoRead && OutLens == kEquirect)) && LRP_WIN_PASSWIN != 0 && (OutLens == kRect || GeoRead || (InMode == kInRect && CH == 5));
+  constexpr int kPlanes = 3;
+  __shared__ float4 s_win[kWinWaves][kCap];
+
+  int tx, ty;
+  if (!xcd_tile<kWinXcdBand>(P.tiles_x, P.tiles_y, tx, ty)) return; // whole workgroup
+  // Alias pairs (LRP_WIN_ALIAS_PAIRS; mirrored strips of rectilinear -> equirectangular).  The reference has no
+  // hemisphere test: the ray of panorama pixel (x + W/2, H-1-y) is the ray of (x, y) with x and z negated, and a
+  // rectilinear projection divides by z — both pixels land on (nearly: different roundings) the same source
+  // texel, the view is rendered a second time behind the camera.  In quadrant terms the strip of tile column
+  // t and the strip of column tiles_x-1-t read the same four source windows, mirror image g of the one being
+  // image 3-g of the other.  Dealt in raster order the two are a quarter of a frame apart and the source is
+  // fetched from HBM twice; here consecutive workgroups of an XCD take the columns from
+  // both ends inwards (0, n-1, 1, n-2, ...) and the odd ones walk their mirror images in reverse, so the two
+  // strips run side by side on one L2 and ask for the same lines at the same time.
+  // Plain strips (the tables of a panorama are not mirror images bit for bit, so this is the kernel that runs):
+  // the strip of tile (t, r) and the strip of tile (t + tiles_x/2, tiles_y-1-r) are the pair, the second one
+  // walks its blocks bottom-up.
+  constexpr bool kAliasPairs = LRP_WIN_ALIAS_PAIRS != 0 && (OutLens == kEquirect || GeoRead) && InMode == kInRect && kWinWaves == 1;
+  int g_flip = 0;        // mirrored strips: the mirror image rendered by loop iteration g is g ^ g_flip
+  bool g_reverse = false; // plain strips: iteration g renders block G-1-g
+  if (kAliasPairs && P.alias_pairs != 0) {
+    if constexpr (QMode == 1) {
+      g_flip = (tx & 1) ? 3 : 0;
+      tx = (tx & 1) ? P.tiles_x - 1 - (tx >> 1) : (tx >> 1);
+    } else if constexpr (QMode == 2) {
+      // rows-only strips span all columns: the partner of strip t is strip t + tiles_x/2, whose image 2 (bottom) reads what
+      // image 0 (top) of this one reads
+      if ((P.tiles_x & 1) == 0) {
+        g_flip = (tx & 1) ? 2 : 0;
+        tx = (tx >> 1) + ((tx & 1) ? P.tiles_x >> 1 : 0);
+      }
+    } else if ((P.tiles_x & 1) == 0) {
+      g_reverse = (tx & 1) != 0;
+      tx = (tx >> 1) + (g_reverse ? P.tiles_x >> 1 : 0);
+      ty = g_reverse ? P.tiles_y - 1 - ty : ty;
+    }
+  }
+  const int lane = (int)(threadIdx.x & 63u);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int Gs = P.blocks_per_wave; // blocks per strip of this launch
+  // blocks this strip renders.  (A block wholly below the image re-renders the image's last row — every lane stores — which is
+  // how the compute kernels keep their store count.  GeoRead skips such blocks: the entry holds extremes only for the block
+  // rows the WRITING launch walked, and that launch may have cut its strips differently.)
+  const int G = GeoRead ? min(Gs, (P.y_end - P.y_offset + kBlkH - 1) / kBlkH - ty * Gs) : Gs;
+  auto block_row = [&](int g) { return (kAliasPairs && g_reverse) ? G - 1 - g : g; }; // block of a plain strip rendered by iteration g
+  auto geo_block = [&](int g) { return (uint32_t)(ty * Gs + block_row(g)) * (uint32_t)P.tiles_x + (uint32_t)tx; }; // geometry cache: box record of a plain block
+  // Mirrored blocks (Quad instantiations, launched when P.quad).  Without a rotation the mapping is symmetric
+  // about both image axes: the pixels (x, y), (W-1-x, y), (x, H-1-y), (W-1-x, H-1-y) have
+  // rays that differ in the signs of vx / vy only, every operation between the ray and the
+  // lens-plane coordinates is an IEEE multiply, divide, square root of a sum of squares or
+  // an odd libm function, so their plane coordinates differ in sign only — exactly.  The
+  // launch then enumerates the top-left quadrant, a wavefront's "strip" is the block and
+  // its three mirror images (g = 0..3: bit 0 mirrors x, bit 1 mirrors y), and stage 1 of
+  // the coordinate math (pixel_plane) runs once for the four of them.
+  constexpr bool quad = Quad;
+  const int qw = MirX ? (P.out_w + 1) >> 1 : P.out_w; // columns / rows enumerated by the launch
+  const int qh = MirY ? (P.out_h + 1) >> 1 : P.y_end; // (a row band: rows beyond it re-render its last row)
+  // mirror image rendered by loop iteration g of a mirrored strip (bit 0: mirrored in x, bit 1: in y)
+  // (masked: the compiler then knows that an axis which is not mirrored never selects the mirrored column / sign)
+  auto image_of = [&](int g) { return ((QMode == 2 ? 2 * g : g) ^ g_flip) & (QMode == 2 ? kAllMirrors : -1); };
+  // workgroup tile = 16 kWinWaves x 16G (x 16 of the quadrant when mirrored): one strip per wavefront
+  int prow, pcol; // this lane's pixel of a pass
+  win_lane_pixel(lane, prow, pcol);
+  const int x = tx * (kBlkW * kWinWaves) + wave * kBlkW + pcol;
+  const int y_lane = P.y_offset + ty * (quad ? kBlkH : kBlkH * Gs) + prow; // + kBlkH * g + kPassRows * pass
+  const int xe = x < qw ? x : qw - 1;
+  const int in_w = P.in_w;
+  SrcView src = source_view<2, CH>(P);
+  auto set_frame = [&](int f) {
+    P.src = frame_src(f);
+    P.dst = frame_dst(f);
+    src = source_view<2, CH>(P);
+  };
+  float4 *const win0 = s_win[wave];
+  constexpr bool kRunsEverywhere = CH == 5 && (OutLens == kEquirect || GeoRead) && InMode == kInRect; // (GeoRead: and P.rgbaz_runs)
+  float *out_lds = nullptr; // RGBAZ: the wavefront's exchange buffer of store_rgbaz_run (three waves per SIMD: the LDS is there)
+  if constexpr (CH == 5) {
+    __shared__ __attribute__((aligned(16))) float s_out[kWinWaves][320];
+    out_lds = s_out[wave];
+  }
+  ColTerms col{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  if constexpr (!GeoRead) col = column_terms<OutLens>(P, xe, 0);
+  ColTerms col_m = col; // the mirrored column
+  if constexpr (MirX && !kSharedRays) col_m = column_terms<OutLens>(P, P.out_w - 1 - xe, 0);
+  // Stage-1 results of the four quadrant pixels of this lane, kept for the whole strip:
+  //   rectilinear / equidistant source: (qa, qb) = plane coordinates (u, v); a mirror image negates them;
+  //   equirectangular source (through the xsep table): qa, qb = source texel y for +phi and for -phi
+  //   (the division of :269 once per sign, not once per mirror image); x comes from the column tables.
+  //   columns-only mirroring of an equirectangular source (no column table: the rotation pitches): the longitude
+  //   theta = -atan2f(-nx, -nz) is odd in nx (lrp_math.h atan2f_: the sign of y only selects +-z, tests/test_math_vs_libm.py),
+  //   the latitude does not see its sign: qa, qc = source texel x for +theta and for -theta, qb = source texel y.
+  float qa[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  constexpr bool kInEqr = InMode == kInEquirect || InMode == kInEquirectLoop;
+  constexpr bool kEqrByTheta = QMode == 3 && kInEqr;
+  //   shared rays: (qa, qb, qc) = the ray (vx, vy, vz) of the quadrant pixel.
+  float qc[(kEqrByTheta || kSharedRays) ? 4 : 1] = {};
+  auto quad_xy = [&](int g, int k, float &sx, float &sy) { // source texel coordinates of pixel k of mirror image g
+    const bool mx = (g & 1) != 0, my = (g >> 1) != 0;
+    if constexpr (kSharedRays) {
+      // the mirrored pixel's ray: vx / vy negated — except in the centre column / row of an odd-sized image, which is
+      // its own mirror image: its component is the +0 of s * 0 and stays +0 (a -0 is another input to atan2f)
+      const int yk = y_lane + kPassRows * k;
+      const uint32_t sgn_x = (mx && 2 * xe != P.out_w - 1) ? 0x80000000u : 0u;
+      const uint32_t sgn_y = (my && 2 * yk != P.out_h - 1) ? 0x80000000u : 0u;
+      float u, v;
+      ray_to_plane<InMode>(P, u2f(f2u(qa[k]) ^ sgn_x), u2f(f2u(qb[k]) ^ sgn_y), qc[k], u, v);
+      plane_to_texel<OutLens, InMode>(P, col, u, v, sx, sy);
+    } else if constexpr (kEqrByTheta) {
+      sx = mx ? qc[k] : qa[k];
+      sy = qb[k];
+    } else if constexpr (kInEqr) {
+      sx = mx ? col_m.sx : col.sx;
+      sy = my ? qb[k] : qa[k];
+    } else {
+      // exact negation = the sign bit flipped by a wave-uniform mask: one v_xor with an SGPR operand, no
+      // second register holding -q next to q (a select between the two costs 8 VGPRs, which spilled)
+      const uint32_t sgn_x = mx ? 0x80000000u : 0u, sgn_y = my ? 0x80000000u : 0u;
+      plane_to_texel<OutLens, InMode>(P, mx ? col_m : col, u2f(f2u(qa[k]) ^ sgn_x), u2f(f2u(qb[k]) ^ sgn_y), sx, sy);
+    }
+  };
+
+  // 16-byte LDS slots of the raw window
+  // RGBAZ (CH == 5): the window is two planes of the same pitch x bh geometry — colour (one 16-byte slot
+  // per texel, fetched with global_load_lds_dwordx4 from the texel's first four floats, 20-byte texel
+  // stride) and, right behind it, depth (one float per texel, global_load_lds_dword from its fifth).
+  // Everything written for RGBA then serves the colour channels unchanged; depth reads its 16 taps from
+  // the float plane and runs the five cubics as scalar instructions.
+  // the thresholds of plan_window as float bits in scalar registers (an int -> float conversion is a vector instruction:
+  // left to the compiler its result stays in a vector register for the whole kernel, and spills)
+  const WinPlanLimits plan_limits = win_plan_limits(P);
+  auto slots_of_rows = [](int pitch, int rows) { return win_slots_of_rows<CH>(pitch, rows); };
+  auto raw_slots = [&](const WinBlock &b) { return win_raw_slots<CH, kSplit>(b); };
+  // (lrp_win_plan.h)
+  auto plan_window = [&](WinBlock &b, int w_lo_x, int w_hi_x, int w_lo_ya, int w_hi_ya, int w_lo_yb, int w_hi_yb, bool exact_x, bool exact_y) {
+    win_plan_block<CH, Loop, kSplit, kEdge, kCap>(b, P, plan_limits, w_lo_x, w_hi_x, w_lo_ya, w_hi_ya, w_lo_yb, w_hi_yb, exact_x, exact_y);
+  };
+  auto clear_block = [](WinBlock &b) { win_clear_block(b); };
+  // One pixel's contribution to the extremes.  Per pixel only the exactness half of interior()
+  // (it also fails for NaN / inf); the range half is voted on the wave-wide extremes.  For finite
+  // floats the raw bits order like signed integers as long as the minimum is >= 0, and a negative
+  // coordinate makes the signed minimum negative, so v_min_i32 / v_max_i32 on the bits give the
+  // extremes (no canonicalising float min / max); a NaN is a huge or a negative integer and fails
+  // the range vote as well.
+  struct Extremes {
+    int lo_x = 0x7fffffff, hi_x = (int)0x80000000;
+    int lo_y[2] = {0x7fffffff, 0x7fffffff}, hi_y[2] = {(int)0x80000000, (int)0x80000000};
+    int exact_x = 1, exact_y = 1;
+  };
+  auto note_pixel = [](Extremes &e, int k, float sx, float sy) {
+    const f2 sxy{sx, sy};
+    const f2 back = (sxy + 2.0f) - sxy; // both coordinates in one packed add / subtract
+    e.exact_x &= (int)(back.x == 2.0f);
+    e.exact_y &= (int)(back.y == 2.0f);
+    const int bx = (int)f2u(sx), by = (int)f2u(sy);
+    e.lo_x = min(e.lo_x, bx);
+    e.hi_x = max(e.hi_x, bx);
+    e.lo_y[k >> 1] = min(e.lo_y[k >> 1], by);
+    e.hi_y[k >> 1] = max(e.hi_y[k >> 1], by);
+  };
+
+  // Mirrored strips: the windows of all four mirror blocks from ONE pair of wave-wide reductions.
+  // The source x of a pixel only depends on whether the block is mirrored in x, its source y on
+  // whether it is mirrored in y, so the strip has two x ranges and (two halves x) two y ranges —
+  // 12 extremes, two wave_box calls — instead of 4 blocks x 6.  They are parked in the lanes of one
+  // VGPR (`plan`, lane i = extreme i as float bits) and fetched with v_readlane when a block starts:
+  //   0-3:  x lo / hi unmirrored, x lo / hi mirrored
+  //   4-11: y lo / hi of half a, of half b — unmirrored, then mirrored
+  // plan_exact: bit 0 / 1 = every pixel's x + 2 exact (unmirrored / mirrored), bit 2 / 3 likewise for y.
+  // A block whose cheap exactness vote failed (next to a power-of-two coordinate) is planned the
+  // long way, precise test included.
+  int plan = 0;
+  uint32_t plan_exact = 0;
+  constexpr bool kStripPlan = Quad && !kSharedRays && LRP_WIN_STRIP_PLAN != 0;
+  auto plan_strip = [&]() {
+    Extremes e0, e1; // unmirrored (image 0) and mirrored in every mirrored axis (an axis that is not mirrored has one range: e1's equals e0's)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float sx, sy;
+      quad_xy(0, k, sx, sy);
+      note_pixel(e0, k, sx, sy);
+      quad_xy(kAllMirrors, k, sx, sy);
+      note_pixel(e1, k, sx, sy);
+    }
+    plan_exact = (wave_all(e0.exact_x != 0) ? 1u : 0u) | (wave_all(e1.exact_x != 0) ? 2u : 0u) |
+                 (wave_all(e0.exact_y != 0) ? 4u : 0u) | (wave_all(e1.exact_y != 0) ? 8u : 0u);
+    wave_box(e0.lo_x, e0.hi_x, e1.lo_x, e1.hi_x, e0.lo_y[0], e0.hi_y[0]);
+    wave_box(e0.lo_y[1], e0.hi_y[1], e1.lo_y[0], e1.hi_y[0], e1.lo_y[1], e1.hi_y[1]);
+    const int v[12] = {e0.lo_x, e0.hi_x, e1.lo_x, e1.hi_x, e0.lo_y[0], e0.hi_y[0],
+                       e0.lo_y[1], e0.hi_y[1], e1.lo_y[0], e1.hi_y[0], e1.lo_y[1], e1.hi_y[1]};
+#pragma unroll
+    for (int i = 0; i < 12; ++i) // (this clang has no writelane builtin)
+      asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(plan) : "s"(v[i]), "n"(i));
+  };
+
+  // phase A of block g: coordinates, interior vote, window box
+  auto coords = [&](int g, WinBlock &b) {
+    // the four row terms first, all loads in flight together (one exposed latency per
+    // block instead of one in front of every pixel's coordinate chain)
+    const int gm = image_of(g); // (plain blocks: g)
+    const int mx = quad ? (gm & 1) : 0, my = quad ? (gm >> 1) : 0;
+    (void)mx;
+    (void)my;
+    float row_v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (!quad || g == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int yk = y_lane + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
+        row_v[k] = row_term<OutLens>(P, yk < qh ? yk : qh - 1, 0);
+      }
+    }
+    if (quad && g == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int yk = y_lane + kPassRows * k;
+        const int ye = yk < qh ? yk : qh - 1;
+        float u, v;
+        if constexpr (kSharedRays) {
+          pixel_ray<OutLens>(P, col, row_v[k], ye, 0, qa[k], qb[k], qc[k]);
+          (void)u;
+          (void)v;
+        } else if constexpr (kEqrByTheta) {
+          // vec_to_equirectangular (src/reproject.cpp:259-271) split at the longitude: everything up to theta once, the
+          // rest of :268 once per sign of theta; the latitude half is the same for both mirror images
+          float vx, vy, vz;
+          pixel_ray<OutLens>(P, col, row_v[k], ye, 0, vx, vy, vz);
+          if (P.has_rot) { // :303-311
+            const float nx = P.rot[0] * vx + P.rot[1] * vy + P.rot[2] * vz;
+            const float ny = P.rot[3] * vx + P.rot[4] * vy + P.rot[5] * vz;
+            const float nz = P.rot[6] * vx + P.rot[7] * vy + P.rot[8] * vz;
+            vx = nx;
+            vy = ny;
+            vz = nz;
+          }
+          const float lon_min = P.in_lens.p[2], img_w = (float)P.in_w;
+          const float theta = -atan2f_(-vx, -vz); // :262
+          qa[k] = texel_coord(((theta - lon_min) / P.in_lon_span - 0.5f) * img_w, img_w);  // :268, :323
+          qc[k] = texel_coord(((-theta - lon_min) / P.in_lon_span - 0.5f) * img_w, img_w); // the mirrored pixel's
+          // the centre column of an odd-sized image is its own mirror image: nx is a zero, theta is 0 or +-pi, and -pi is
+          // not the same longitude bit for bit — the pixel is rendered twice, both times with its own theta
+          if (2 * xe == P.out_w - 1) qc[k] = qa[k];
+          qb[k] = texel_coord(equirect_cy(vx, vy, vz, P.in_lens.p[0], P.in_lat_span, (float)P.in_h), (float)P.in_h); // :263, :269, :324
+          (void)u;
+          (void)v;
+          // one pixel after the other: interleaved, the four atan2f / asinf evaluations need more registers than there are
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          pixel_plane<OutLens, InMode>(P, col, row_v[k], ye, 0, u, v);
+          if constexpr (kInEqr) { // host guarantees the xsep table: v = phi
+            float unused;
+            plane_to_texel<OutLens, InMode>(P, col, u, v, unused, qa[k]);
+            plane_to_texel<OutLens, InMode>(P, col, u, -v, unused, qb[k]);
+          } else {
+            qa[k] = u;
+            qb[k] = v;
+          }
+        }
+      }
+      if constexpr (kStripPlan) plan_strip();
+    }
+    clear_block(b);
+    if constexpr (kStripPlan) {
+      if (((plan_exact >> mx) & (plan_exact >> (2 + my)) & 1u) != 0) {
+        plan_window(b, __builtin_amdgcn_readlane(plan, 2 * mx), __builtin_amdgcn_readlane(plan, 2 * mx + 1),
+                    __builtin_amdgcn_readlane(plan, 4 + 4 * my), __builtin_amdgcn_readlane(plan, 5 + 4 * my),
+                    __builtin_amdgcn_readlane(plan, 6 + 4 * my), __builtin_amdgcn_readlane(plan, 7 + 4 * my), true, true);
+        return;
+      }
+    }
+    Extremes e;
+    // (plain blocks: everything derived from the column terms alone — their products with the rotation matrix, the
+    // column's share of the source lens — is loop-invariant, gets hoisted out of the block loop and then spilled to scratch
+    // for the whole kernel: 80-100 MB of scratch traffic per 4K frame.  Opaque here, those few multiplies run per block.)
+    ColTerms col_g = col;
+    if constexpr (!Quad && LRP_OPAQUE_COL != 0) asm volatile("" : "+v"(col_g.a), "+v"(col_g.b), "+v"(col_g.nx), "+v"(col_g.nz), "+v"(col_g.sx));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yk = y_lane + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
+      const int ye = yk < qh ? yk : qh - 1;
+      if (!quad)
+        pixel_source_rt<OutLens, InMode>(P, col_g, row_v[k], ye, 0, b.sx[k], b.sy[k]);
+      else
+        quad_xy(gm, k, b.sx[k], b.sy[k]);
+      note_pixel(e, k, b.sx[k], b.sy[k]);
+      // (shared rays: one pixel's rotation + source lens after the other — interleaved they do not fit the registers)
+      if constexpr (kSharedRays) __builtin_amdgcn_sched_barrier(0);
+    }
+    bool all_exact_x, all_exact_y;
+    if constexpr (kEdge) { // per axis: a block beyond one side of the source has no exact taps along that axis and needs none
+      all_exact_x = wave_all(e.exact_x != 0);
+      all_exact_y = wave_all(e.exact_y != 0);
+      if (!(all_exact_x && all_exact_y)) { // the precise test, for the stripe of blocks next to a power-of-two coordinate
+        int ok_x = 1, ok_y = 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          ok_x &= taps_consecutive(b.sx[k], 2.0f);
+          ok_y &= taps_consecutive(b.sy[k], 2.0f);
+        }
+        all_exact_x = wave_all(ok_x != 0);
+        all_exact_y = wave_all(ok_y != 0);
+      }
+    } else {
+      bool all_exact = wave_all((e.exact_x & e.exact_y) != 0);
+      if (!all_exact) { // the precise test, for the stripe of blocks next to a power-of-two coordinate
+        int ok = 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ok &= taps_consecutive(b.sx[k], 2.0f) & taps_consecutive(b.sy[k], 2.0f);
+        all_exact = wave_all(ok != 0);
+      }
+      all_exact_x = all_exact_y = all_exact;
+    }
+    const bool planned = kEdge ? true : (all_exact_x && all_exact_y);
+    if (planned) {
+      wave_box(e.lo_x, e.hi_x, e.lo_y[0], e.hi_y[0], e.lo_y[1], e.hi_y[1]);
+      plan_window(b, e.lo_x, e.hi_x, e.lo_y[0], e.hi_y[0], e.lo_y[1], e.hi_y[1], all_exact_x, all_exact_y);
+    }
+    if constexpr (kGeoWrite) {
+      if (geo_write) { // side output: this block's coordinates and the extremes its window was planned from
+        vf2 *const map = reinterpret_cast<vf2 *>(P.geo_xy);
+        if (Pk.geo_mode == 1) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int yk = y_lane + kBlkH * block_row(g) + kPassRows * k;
+            const int ye = yk < qh ? yk : qh - 1;
+            // (lanes / rows beyond the image hold the pixel they were clamped to and write its values to its place again)
+            map[geo_map_index(xe, ye, P.out_w)] = vf2{b.sx[k], b.sy[k]};
+          }
+        }
+        const int words[7] = {planned ? e.lo_x : 0, planned ? e.hi_x : 0, planned ? e.lo_y[0] : 0, planned ? e.hi_y[0] : 0,
+                              planned ? e.lo_y[1] : 0, planned ? e.hi_y[1] : 0,
+                              (all_exact_x ? 1 : 0) | (all_exact_y ? 2 : 0) | (planned ? 4 : 0)};
+        int bv = 0; // lane i = word i (written once per geometry: plain selects will do)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) bv = lane == i ? words[i] : bv;
+        if (lane < 8) P.geo_box[geo_block(g) * 8u + (uint32_t)lane] = bv;
+      }
+    }
+  };
+  // GeoRead: the coordinates of block g and (geo_boxv, lane i = word i) its window extremes are requested by geo_fetch and
+  // turned into a window plan by geo_plan, a few hundred instructions later
+  int geo_boxv = 0;
+  auto geo_fetch = [&](int g, WinBlock &b) {
+    // (the extremes first: loads return in order, and the first block of a strip plans its window before anything else)
+    geo_boxv = __builtin_nontemporal_load(P.geo_box + (geo_block(g) * 8u + (uint32_t)(lane & 7)));
+    const vf2 *const map = reinterpret_cast<const vf2 *>(P.geo_xy);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yk = y_lane + kBlkH * block_row(g) + kPassRows * k;
+      const int ye = yk < qh ? yk : qh - 1;
+      const vf2 v = __builtin_nontemporal_load(map + geo_map_index(xe, ye, P.out_w));
+      b.sx[k] = v.x;
+      b.sy[k] = v.y;
+    }
+  };
+  auto geo_plan = [&](WinBlock &b) {
+    clear_block(b);
+    const int flags = __builtin_amdgcn_readlane(geo_boxv, 6);
+    if ((flags & 4) != 0)
+      plan_window(b, __builtin_amdgcn_readlane(geo_boxv, 0), __builtin_amdgcn_readlane(geo_boxv, 1),
+                  __builtin_amdgcn_readlane(geo_boxv, 2), __builtin_amdgcn_readlane(geo_boxv, 3),
+                  __builtin_amdgcn_readlane(geo_boxv, 4), __builtin_amdgcn_readlane(geo_boxv, 5), (flags & 1) != 0, (flags & 2) != 0);
+  };
+  // the one value of a corner block: sample_bicubic with all 16 taps on the corner texel (sample_direct's
+  // one-column-and-one-row case, same operations)
+  auto corner_value = [&](const WinBlock &b) {
+    const int xh = (b.corner() - 1) & 1, yh = (b.corner() - 1) >> 1;
+    const float fx = xh ? 1.0f : 0.0f, fy = yh ? 1.0f : 0.0f; // the clamped weights (src/reproject.cpp:130-131)
+    const float hfx = 0.5f * fx, hfy = 0.5f * fy;
+    const uint32_t off = (uint32_t)(yh ? P.in_h - 1 : 0) * src.row_bytes + (uint32_t)(xh ? in_w - 1 : 0) * (4u * CH);
+    if constexpr (CH == 5) {
+      const Px<5> t = texel_at<5>(src.rsrc, off, 0u);
+      const Px<5> k = cubic_px<5>(t, t, t, t, fy, hfy);
+      const Px<5> r = cubic_px<5>(k, k, k, k, fx, hfx);
+      return Rgba{r.lo, r.hi, r.e};
+    } else {
+      const Px<4> t = texel_at<4>(src.rsrc, off, 0u); // (RGB: a 16-byte read of a 12-byte texel, fourth component unused)
+      const Px<4> k = cubic_px<4>(t, t, t, t, fy, hfy);
+      return cubic_px<4>(k, k, k, k, fx, hfx);
+    }
+  };
+  auto issue = [&](const float *frame, const WinBlock &b, int half = 0) { // the window `b` of the source frame `frame` (split blocks: of its half)
+    if (kEdge && b.edge() != 0) {
+      // One source row (texels x_lo .. x_lo + bw - 1 of row y_lo) or one source column (rows y_lo .. y_lo + bh - 1 of
+      // column x_lo) into consecutive slots: 64 texels per instruction, the lane's byte offset along the row / column
+      // in a VGPR, the first texel's address in an SGPR pair.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const bool along_y = b.edge() >= 3;
+      const int n = along_y ? b.bh : b.bw;
+      const uint32_t step = along_y ? src.row_bytes : 4u * CH;
+      const uint32_t first_row = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)b.y_lo * src.row_bytes));
+      const uint32_t first_col = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)b.x_lo * (4u * CH)));
+      const char *first = reinterpret_cast<const char *>(frame) + ((size_t)first_row + (size_t)first_col);
+      const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win0;
+      for (int c0 = 0; c0 < n; c0 += 64) {
+        if (c0 + lane < n) {
+          const uint32_t lane_bytes = (uint32_t)(c0 + lane) * step;
+          const uint32_t lds = lds0 + (uint32_t)c0 * 16u;
+          if constexpr (CH == 3)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %2"
+                         :
+                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(first)
+                         : "memory", "m0");
+          else
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :
+                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(first)
+                         : "memory", "m0");
+          if constexpr (CH == 5) { // depth: the float plane behind the n colour slots
+            const uint32_t lds_d = lds0 + (uint32_t)n * 16u + (uint32_t)c0 * 4u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
+                         :
+                         : "s"(__builtin_amdgcn_readfirstlane(lds_d)), "v"(lane_bytes), "s"(first + 16)
+                         : "memory", "m0");
+          }
+        }
+      }
+    } else if (b.staged()) {
+      // LDS-DMA, one window row per instruction, lanes beyond the width masked off.  The address is a wave-uniform row
+      // base in an SGPR pair (advanced by scalar adds) plus one per-lane byte offset that is the same for every row and
+      // every frame: no vector arithmetic per row.
+      float4 *const win = win0;
+      // Issued as inline assembly: the compiler's wait-count insertion then does not know
+      // that LDS is being written and puts no vmcnt(0) in front of later LDS reads (of the
+      // coefficient planes, which the DMA does not touch); the one wait that IS needed sits
+      // at the top of the block loop.  M0 = LDS byte address of the row (+ 16 B per lane).
+      // the reads of the window issued so far have returned before anything overwrites it
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // (windows wider than 64 texels — pass windows of the big-window variant — take one instruction per 64 columns and row)
+      const int n_chunks = kMaxPassCols > 64 ? (b.bw + 63) >> 6 : 1;
+      for (int chunk = 0; chunk < n_chunks; ++chunk)
+      if (chunk * 64 + lane < b.bw) {
+        uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win + (uint32_t)(b.org() + chunk * 64) * 16u;
+        const uint32_t lds_step = (uint32_t)(b.spitch() * 16); // dwordx3 too writes one 16-byte slot per lane
+        const uint32_t lane_bytes = (uint32_t)(b.x_lo + chunk * 64 + lane) * (4u * CH);
+        const int n_rows = kSplit ? b.rows_of(half) : b.bh;
+        const char *row = reinterpret_cast<const char *>(frame) + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(kSplit ? b.first_row_of(half) : b.y_lo) * src.row_bytes)); // wave-uniform
+        for (int r = 0; r < n_rows; ++r) {
+          if constexpr (CH == 4)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :
+                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(row)
+                         : "memory", "m0");
+          else if constexpr (CH == 5) {
+            // colour into the 16-byte slots of the row, depth into the row of the float plane behind the colour plane
+            // (an instruction offset would move the LDS address as well as the global one: the fifth float's 16 bytes
+            // go into the scalar base)
+            const uint32_t lds_d = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win +
+                                   (uint32_t)(b.pitch * n_rows) * 16u + (uint32_t)(r * b.pitch + chunk * 64) * 4u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :
+                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(row)
+                         : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
+                         :
+                         : "s"(__builtin_amdgcn_readfirstlane(lds_d)), "v"(lane_bytes), "s"(row + 16)
+                         : "memory", "m0");
+          } else
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %2"
+                         :
+                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(row)
+                         : "memory", "m0");
+          lds += lds_step;
+          row += src.row_bytes;
+        }
+      }
+    }
+  };
+
+  // Coefficient tier.  Of the 17 operations of a vertical Catmull-Rom evaluation, 11
+  // depend on the four taps only, not on the weight:
+  //     inner = ((3 (b - c)) + d) - a,  m0 = (((2 a - 5 b) + 4 c) - d),  cma = c - a
+  //     k = b + hfy * (cma + fy * (m0 + fy * inner))          (src/reproject.cpp:92-98)
+  // Under magnification the pixels of a block share their tap columns, so those three
+  // terms are evaluated ONCE per tap-column origin of the window (a lane per origin,
+  // straight from the staged window) and stored behind it in three planes; a pixel
+  // then spends 6 instead of 17 operations per channel and column.  Same operations
+  // on the same operands in the same order: the result is the reference's, bit for bit.
+  auto precompute = [&](const WinBlock &b, int h) {
+    const int n = b.pitch * b.iyn[h]; // origins: every window column x every first tap row of this half
+    // Origins are enumerated over their contiguous slot range from its lowest slot (bottom-up storage
+    // puts the LAST origin row there); an origin's four taps are spitch slots apart either way.
+    const float4 *const raw = win0 + (b.org() + (b.iy0[h] - 1 - b.y_lo) * b.spitch() + (b.spitch() < 0 ? (b.iyn[h] - 1) * b.spitch() : 0));
+    float4 *const planes = win0 + b.c_base;
+    auto load4 = [&](int idx, Rgba t[4]) { // origin idx = row * pitch + column reads the window texels idx + {0, 1, 2, 3} * pitch
+      const float4 *q = raw + (idx < n ? idx : n - 1); // (origins in the pad column of an odd pitch compute unused values from stale slots)
+      t[0] = as_rgba(q[0]);
+      t[1] = as_rgba(q[b.spitch()]);
+      t[2] = as_rgba(q[2 * b.spitch()]);
+      t[3] = as_rgba(q[3 * b.spitch()]);
+    };
+    auto emit = [&](int idx, const Rgba t[4]) {
+      Rgba inner, m0, cma;
+      inner.lo = ((3.0f * (t[1].lo - t[2].lo)) + t[3].lo) - t[0].lo;
+      inner.hi = ((3.0f * (t[1].hi - t[2].hi)) + t[3].hi) - t[0].hi;
+      m0.lo = (((2.0f * t[0].lo) - (5.0f * t[1].lo)) + (4.0f * t[2].lo)) - t[3].lo;
+      m0.hi = (((2.0f * t[0].hi) - (5.0f * t[1].hi)) + (4.0f * t[2].hi)) - t[3].hi;
+      cma.lo = t[2].lo - t[0].lo;
+      cma.hi = t[2].hi - t[0].hi;
+      if (idx < n) {
+        planes[idx] = float4{inner.lo.x, inner.lo.y, inner.hi.x, inner.hi.y};
+        planes[b.c_plane + idx] = float4{m0.lo.x, m0.lo.y, m0.hi.x, m0.hi.y};
+        planes[2 * b.c_plane + idx] = float4{cma.lo.x, cma.lo.y, cma.hi.x, cma.hi.y};
+      }
+    };
+    // two chunks of 64 origins per trip, the second chunk's reads in flight under the first chunk's arithmetic
+#pragma unroll 1
+    for (int i0 = 0; i0 < n; i0 += 128) {
+      const bool two = i0 + 64 < n; // wave-uniform
+      Rgba t0[4], t1[4];
+      load4(i0 + lane, t0);
+      if (two) load4(i0 + 64 + lane, t1);
+      emit(i0 + lane, t0);
+      if (two) emit(i0 + 64 + lane, t1);
+    }
+  };
+
+  // Blocks beyond the first / last source row: k = cubic(t, t, t, t, fy) of every window texel t, fy = 0 / 1 the clamped
+  // weight (src/reproject.cpp:131), a lane per texel, into the plane behind the row.  Evaluated, not assumed to be t:
+  // with a non-finite texel it is not.
+  auto edge_plane = [&](const WinBlock &b) {
+    const float fyc = b.edge() == 2 ? 1.0f : 0.0f, hfyc = 0.5f * fyc;
+    float4 *const plane = win0 + b.c_base;
+    const float *const raw_d = reinterpret_cast<const float *>(win0 + b.bw);
+    float *const plane_d = reinterpret_cast<float *>(plane + b.bw);
+#pragma unroll 1
+    for (int i0 = 0; i0 < b.bw; i0 += 64) {
+      const int i = min(i0 + lane, b.bw - 1);
+      const Rgba t = as_rgba(win0[i]);
+      const Rgba k = cubic4(t, t, t, t, fyc, hfyc);
+      plane[i] = float4{k.lo.x, k.lo.y, k.hi.x, k.hi.y};
+      if constexpr (CH == 5) {
+        const float dz = raw_d[i];
+        plane_d[i] = catmull_rom(dz, dz, dz, dz, fyc, hfyc);
+      }
+    }
+  };
+
+  // vmcnt retires in order, stores included: a store issued BEFORE the DMA of the next window
+  // would have to be acknowledged by memory before that window counts as landed.  So the
+  // DMA of window g+1 is issued inside the last pass of block g, right behind that pass's
+  // reads of the window and ahead of its arithmetic and its store; the stores of passes
+  // 0-2 are a pass or more old by then, the store of pass 3 is the one vm operation that
+  // may still be outstanding when the next block waits: vmcnt(1).  (Every lane stores,
+  // see below, so that store is always issued.)
+  WinBlock cur, nxt;
+  if constexpr (GeoRead) {
+    geo_fetch(0, cur);
+    geo_plan(cur);
+  } else {
+    coords(0, cur);
+  }
+  issue(P.src, cur);
+  int g_loop = 0, f_loop = 0;
+  bool dma_early = false; // the pending window was requested before its block's last store
+  // The step after (block g_loop, frame f_loop): the same block in the next frame, or the next block in the first frame.
+  auto issue_next = [&]() {
+    if (f_loop + 1 < n_frames)
+      issue(frame_src(f_loop + 1), cur);
+    else
+      issue(frame_src(0), nxt);
+  };
+  auto has_next = [&]() { return f_loop + 1 < n_frames || g_loop + 1 < G; };
+  auto next_window = [&]() {
+    // while this block's coefficient planes are still being read the next raw window must stay in front of them
+    // (the same block's window in the next frame always does: planes sit behind the raw window)
+    // (likewise the plane of vertical cubics of a block beyond the first / last source row: edge() 1, 2)
+    const bool planes_live = (kWinCoef && cur.coef()) || (kEdge && cur.edge() != 0 && cur.edge() < 3);
+    dma_early = has_next() && (!planes_live || f_loop + 1 < n_frames || raw_slots(nxt) <= cur.c_base);
+    if (dma_early) issue_next();
+  };
+  // The result of pass k of block g: num_samples == 1, (0.0f + s) * normalize (src/reproject.cpp:334-341), store.
+  auto emit = [&](int g, int k, const Rgba &s, auto as_runs, bool runs_rt = true) {
+    Rgba a4 = px_zero<4>();
+    px_add<4>(a4, s);
+    if constexpr (CH == 5) a4.e = 0.0f + s.e;
+    const Px<CH> a{a4.lo, CH >= 4 ? a4.hi : f2{0.0f, 0.0f}, CH == 3 ? a4.hi.x : a4.e};
+    // Every lane stores: lanes / rows beyond the image have recomputed the pixel they were
+    // clamped to (xe, ye) and write that same value to that same address again, so the
+    // store is issued by every wavefront (the vmcnt(1) below counts on it).
+    // (the four clamped rows of a mirrored strip are loop-invariant; hoisted they occupy four VGPRs for the whole
+    // strip — which spilled — so the row is re-derived from an opaque copy here: an add and a min per pass)
+    int y_base = y_lane;
+    asm volatile("" : "+v"(y_base)); // (likewise not hoisted out of the frame loop)
+    const int yk = y_base + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
+    const int yc = yk < qh ? yk : qh - 1;
+    const int gm = image_of(g);
+    const int xo = (quad && (gm & 1)) ? P.out_w - 1 - xe : xe; // mirrored blocks write the mirrored pixel
+    const int yo = (quad && (gm >> 1)) ? P.out_h - 1 - yc : yc;
+#if defined(LRP_NO_STORE) // timing experiment: almost no output traffic
+    if (a.lo.x == 12345.678f) store_px<CH, true>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
+#else
+    if constexpr (CH == 5) {
+     if constexpr (decltype(as_runs)::value) {
+      // a pass that lies in the image whole (wave-uniform) leaves as four runs of 16 pixels (store_rgbaz_run).
+      // Used where the stores are what a block costs: corner blocks (four stores and nothing else) in every kernel,
+      // all blocks of a rectilinear view rendered into a panorama (kRunsEverywhere: most of that frame is out of
+      // view or gathers minified taps; 383 -> 334 us).  In the VALU-bound kernels that interpolate from the LDS
+      // window the exchange costs more than the stores gain (measured: 4-7 % slower).
+      const int x_blk = tx * (kBlkW * kWinWaves) + wave * kBlkW;
+      const int y_top = P.y_offset + ty * (quad ? kBlkH : kBlkH * Gs) + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
+      if (runs_rt && x_blk + kBlkW <= qw && y_top + kPassRows <= qh) {
+        const bool mxo = quad && (gm & 1), myo = quad && (gm >> 1);
+        float c[5];
+        finish_px<5, true>(P, a, c);
+        const uint32_t first = (uint32_t)(myo ? P.out_h - 1 - y_top : y_top) * (uint32_t)P.out_w +
+                               (uint32_t)(mxo ? P.out_w - x_blk - kBlkW : x_blk);
+        store_rgbaz_run<4>(P, out_lds, prow * kBlkW + (mxo ? kBlkW - 1 - pcol : pcol), first, myo ? -P.out_w : P.out_w, c);
+        return;
+      }
+     }
+    }
+    store_px<CH, true>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
+#endif
+  };
+  // Pass windows (kernels with split blocks): a block whose two half windows do not fit either (a pole face of a
+  // cubemap: the panorama's rows converge) still has passes — 16 x 4 pixels — whose own window fits.  Planned per pass
+  // from the wave-wide extremes of that pass's coordinates, fetched, waited for and read on the spot; the other
+  // wavefronts of the SIMD cover the round trip (requesting the window of pass k + 1 behind the taps of pass k, like the
+  // second half of a split block, measured slower: 120 against 112 us per pole face, 14 spilled registers).
+  // False: this pass gathers per pixel.
+  // one pixel from a staged pass window `w`: the raw-tap tier (lrp_win_tiers.h)
+  auto window_sample = [&](const WinBlock &w, float psx, float psy, bool last_pass) -> Rgba {
+    const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
+    const int slot0 = __mul24((int)ty_ - 1 - w.y_lo, w.pitch) + ((int)tx_ - 1 - w.x_lo);
+    return win_tier_raw<CH>(win0 + slot0, w.pitch, reinterpret_cast<const float *>(win0 + w.pitch * w.bh) + slot0, psx - tx_, psy - ty_, [&]() {
+      if (last_pass) next_window(); // behind the last reads of this pass's window
+    });
+  };
+  // window of one pass (or of two passes that read the same source rows) from the wave-wide extremes of its coordinates;
+  // false: too wide or too large for the buffer
+  auto plan_pass_window = [&](WinBlock &w, int lo_x, int hi_x, int lo_y, int hi_y) -> bool {
+    int d0 = 0, d1 = 0;
+    wave_box(lo_x, hi_x, lo_y, hi_y, d0, d1); // (interior: the coordinates are >= 1, their bits order like integers)
+    clear_block(w);
+    w.x_lo = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)lo_x)) - 1;
+    w.y_lo = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)lo_y)) - 1;
+    w.bw = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)hi_x)) + 2 - w.x_lo + 1;
+    w.bh = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)hi_y)) + 2 - w.y_lo + 1;
+    w.pitch = w.bw | 1;
+    if (w.bw > kMaxPassCols || slots_of_rows(w.pitch, w.bh) > kCap) return false;
+    w.tier = 1;
+    return true;
+  };
+  auto pass_window = [&](float psx, float psy, Rgba &s, bool last_pass) -> bool {
+    if (!all_interior(psx, psy, 1.0f, src.x_hi, src.y_hi, 2.0f)) return false;
+    WinBlock w;
+    if (!plan_pass_window(w, (int)f2u(psx), (int)f2u(psx), (int)f2u(psy), (int)f2u(psy))) return false;
+    issue(P.src, w);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the window (and every older store)
+    s = window_sample(w, psx, psy, last_pass);
+    return true;
+  };
+#pragma unroll 1
+  for (int g = 0; g < G; ++g) {
+   g_loop = g;
+   // plain blocks: the next block's coordinates here, long before its window is requested in the
+   // last pass; mirrored blocks derive theirs in a few instructions right there (fewer live registers)
+   // (GeoRead: the next block's record is requested behind this block's wait and planned in front of its last pass — the
+   // loads are then older than the next window's DMA and the hand-counted vmcnt(1) below still holds)
+   if constexpr (!GeoRead)
+     if ((!Quad || kSharedRays) && g + 1 < G) coords(g + 1, nxt); // (shared rays: the rotation and the source lens run per image, as for a plain block)
+#pragma unroll 1
+   for (int f = 0; f < n_frames; ++f) {
+    f_loop = f;
+    if (n_frames > 1 || g == 0) set_frame(f);
+    const bool last_frame = f + 1 == n_frames; // the next step is the next block
+#if !defined(LRP_NO_DMA_WAIT) // timing experiment (wrong results): how much of the frame is exposed DMA / store latency
+    // (a launch that writes the geometry cache has the stores of coords(g + 1) in flight as well: it waits for everything)
+    if ((g == 0 && f == 0) || !dma_early || geo_write)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the window was the last thing requested
+    else
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); // window g has landed; block g-1's last store may be in flight
+#endif
+    if constexpr (GeoRead)
+      if (g + 1 < G && f == 0) geo_fetch(g + 1, nxt);
+    const float4 *const win = win0;
+    // The tier of this block in a scalar register for the branches below: carried through the block loop inside `cur` it
+    // ends up in a VGPR (the kernel is at the SGPR limit), and every test of it then costs a v_and + v_cmp and the
+    // branch condition is re-materialised through v_cndmask / v_cmp at each use — seven VALU instructions per pass.
+#if LRP_OPT_TIER
+    const int tier = __builtin_amdgcn_readfirstlane(cur.tier);
+#else
+    const int tier = cur.tier;
+#endif
+    const bool t_coef = kWinCoef && (tier & 2) != 0, t_staged = (tier & 1) != 0, t_whole = (tier & 4) != 0;
+    const int t_edge = kEdge ? ((tier >> 6) & 7) : 0;
+    const bool t_split = kSplit && (tier & 512) != 0; // the window holds passes 0-1; that of passes 2-3 is fetched behind pass 1's taps // 1, 2: beyond the first / last source row; 3, 4: column
+#if defined(LRP_TIER_STATS)
+    if (lane == 0) atomicAdd(&g_tier_stats[((tier >> 3) & 7) != 0 ? 3 : (tier & 512) != 0 ? 6 : ((tier >> 6) & 7) != 0 ? (((tier >> 6) & 7) < 3 ? 4 : 5) : (kWinCoef && (tier & 2)) ? 0 : (tier & 1) ? 1 : 2], 1u);
+#endif
+    if (((tier >> 3) & 7) != 0) {
+      // every pixel of this block is one value: no taps, no per-pixel arithmetic — four stores.  The next block's
+      // window is requested in front of the last store, as in the last pass of an ordinary block.
+      const Rgba cs = corner_value(cur);
+      if (Quad && !kSharedRays && last_frame && g + 1 < G) coords(g + 1, nxt);
+      if constexpr (GeoRead)
+        if (g + 1 < G && last_frame) geo_plan(nxt);
+      emit(g, 0, cs, std::true_type{});
+      emit(g, 1, cs, std::true_type{});
+      emit(g, 2, cs, std::true_type{});
+      next_window();
+      emit(g, 3, cs, std::true_type{});
+      if (!dma_early && has_next()) issue_next();
+      if (last_frame) cur = nxt;
+      continue;
+    }
+    if (t_edge == 1 || t_edge == 2) edge_plane(cur);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#if !defined(LRP_SKIP_PLANES) // timing experiment (wrong results): the coefficient phase removed
+      if (t_coef && (h == 0 || !t_whole)) precompute(cur, h);
+#endif
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int k = 2 * h + kk;
+        if (Quad && !kSharedRays && k == 3 && last_frame && g + 1 < G) coords(g + 1, nxt); // only its box is kept
+        if constexpr (GeoRead)
+          if (k == 3 && g + 1 < G && last_frame) geo_plan(nxt);
+        const bool last_pass = k == 3;
+        float psx = cur.sx[k], psy = cur.sy[k];
+        if constexpr (Quad && !kSharedRays) quad_xy(image_of(g), k, psx, psy); // re-derived (2-4 instructions) instead of held in registers
+        // (where the coordinates of a mirror image are a plain selection of stored values the compiler would otherwise
+        // hoist everything derived from them — truncations, weights, window addresses of all four passes and both
+        // images — out of the block loop and spill it: the selected values are opaque here)
+        // (the same goes for the frame loop: everything derived from the coordinates of a pass is the same in every frame,
+        // and kept for all four passes it does not fit the registers — what IS shared between frames is stage 1 and the
+        // window plan, by construction)
+        asm volatile("" : "+v"(psx), "+v"(psy));
+        Rgba s;
+        // behind the pixel's last read of the window: the next window's DMA (last pass), the second half of a split block (pass 1)
+        auto after_reads = [&]() {
+          if (last_pass) next_window();
+          if (t_split && k == 1) issue(P.src, cur, 1);
+        };
+        if (t_edge != 0) {
+          if (t_edge < 3) { // beyond the first / last source row
+            const float tx_ = __builtin_truncf(psx);
+            const int slot = (int)tx_ - 1 - cur.x_lo;
+            s = win_tier_edge_row<CH>(win + cur.c_base + slot, reinterpret_cast<const float *>(win + cur.c_base + cur.bw) + slot, psx - tx_, after_reads);
+          } else { // beyond the first / last source column
+            const float ty_ = __builtin_truncf(psy);
+            const int slot = (int)ty_ - 1 - cur.y_lo;
+            s = win_tier_edge_col<CH>(win + slot, reinterpret_cast<const float *>(win + cur.bh) + slot, psy - ty_, t_edge == 4 ? 1.0f : 0.0f, after_reads);
+          }
+        } else if (t_coef) {
+          const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
+          // one 24-bit multiply per pixel (a 32-bit v_mul_lo_u32 issues at quarter rate); every other term
+          // of the two addresses is wave-uniform and folded into tap_base / c_delta when the block is planned
+          const int tap = __mul24((int)ty_, cur.spitch()) + (int)tx_ + cur.tap_base; // window slot of (int(sx) - 1, int(sy)): the second tap row
+          s = win_tier_coef<CH>(win + tap, win + (tap + cur.c_delta(h)), cur.c_plane, cur.pitch,
+                                reinterpret_cast<const float *>(win + cur.pitch * cur.bh) + (tap - cur.spitch()), psx - tx_, psy - ty_, after_reads);
+        } else if (t_staged) {
+          // (split blocks: h = 1 reads the window of passes 2-3, requested behind pass 1's taps — its arithmetic and store and
+          // the other wavefronts cover part of the round trip — and waited for in front of pass 2)
+          const int half = (t_split && h == 1) ? 1 : 0;
+          if (t_split && k == 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); // the DMA is older than every store behind it
+          const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
+          const int slot0 = cur.org() + __mul24((int)ty_ - 1 - (kSplit ? cur.first_row_of(half) : cur.y_lo), cur.spitch()) + ((int)tx_ - 1 - cur.x_lo);
+          s = win_tier_raw<CH>(win + slot0, cur.spitch(),
+                               reinterpret_cast<const float *>(win + cur.pitch * (kSplit ? cur.rows_of(half) : cur.bh)) + slot0, psx - tx_, psy - ty_, after_reads);
+        } else if (kPassWin && P.win_split != 0 && pass_window(psx, psy, s, last_pass)) {
+          // (rendered from the window of this pass)
+        } else {
+          if (last_pass) next_window(); // nothing staged: no tap of this block reads the window
+          if constexpr (CH == 5) {
+            // (colour and depth taps fetched one set after the other — 16 dwordx4 + 16 dword loads instead of 20 dwordx4, at
+            // three or at four waves per SIMD — is 18-26 % slower: this path is bound by the number of gather instructions)
+            const Px<5> s5 = sample_direct<2, Loop, 5, LRP_WIN_MINWAVES5 >= 4>(P, src, psx, psy); // (LowReg at 128 VGPRs)
+            s = Rgba{s5.lo, s5.hi, s5.e};
+          } else {
+            s = sample_direct<2, Loop, 4, (LRP_WIN_MINWAVES >= 5), 4 * CH>(P, src, psx, psy); // (LowReg when five waves per SIMD are asked for: 96 VGPRs)
+          }
+        }
+        emit(g, k, s, std::integral_constant<bool, kRunsEverywhere>{}, !GeoRead || P.rgbaz_runs != 0);
+      }
+    }
+    if (!dma_early && has_next()) issue_next(); // after the last read of the planes
+    if (last_frame) cur = nxt;
+   }
+  }
+}
+
+// The window kernel of one (output lens, source mode) cell for a mirror mode, or null where the mode does not exist
+// (rows-only needs the column-separable source x: no equidistant lens on either side; columns-only a rectilinear target).
+template <int OutLens, int InMode, int QMode, int CH, bool Frames> constexpr TileKernelFn win_kernel_fn() {
+  if constexpr (QMode == 2 && (OutLens == kEquidistant || InMode == kInEquidistant))
+    return nullptr;
+  else if constexpr (QMode == 3 && OutLens != kRect)
+    return nullptr;
+  else if constexpr (QMode == 4 && OutLens != kEquidistant)
+    return nullptr;
+  else
+    return reproject_bicubic_win_kernel<OutLens, InMode, QMode, CH, Frames>;
+}
+template <int QMode, int CH, bool Frames> struct WinKernelTable {
+  static TileKernelFn get(int out_idx, int in_mode) {
+    static const TileKernelFn table[3][4] = {
+        {win_kernel_fn<kRect, kInRect, QMode, CH, Frames>(), win_kernel_fn<kRect, kInEquidistant, QMode, CH, Frames>(),
+         win_kernel_fn<kRect, kInEquirect, QMode, CH, Frames>(), win_kernel_fn<kRect, kInEquirectLoop, QMode, CH, Frames>()},
+        {win_kernel_fn<kEquidistant, kInRect, QMode, CH, Frames>(), win_kernel_fn<kEquidistant, kInEquidistant, QMode, CH, Frames>(),
+         win_kernel_fn<kEquidistant, kInEquirect, QMode, CH, Frames>(), win_kernel_fn<kEquidistant, kInEquirectLoop, QMode, CH, Frames>()},
+        {win_kernel_fn<kEquirect, kInRect, QMode, CH, Frames>(), win_kernel_fn<kEquirect, kInEquidistant, QMode, CH, Frames>(),
+         win_kernel_fn<kEquirect, kInEquirect, QMode, CH, Frames>(), win_kernel_fn<kEquirect, kInEquirectLoop, QMode, CH, Frames>()}};
+    return table[out_idx][in_mode];
+  }
+};
+
+// The GeoRead instantiations (plain blocks, coordinates from the geometry cache): one per source mode.
+// ... and with the frame loop: batched launches of a geometry whose entry exists.  A wavefront loads the coordinates and the
+// extremes of its block once and renders it for up to 16 frames (same box, 16-frame launches: headline 104.3 -> 100.9 us per
+// frame, general rotation 98.3 -> 95.7 against the instantiations that compute their coordinates once per 16 frames — those
+// carry the lens math in registers: 68-90 spilled SGPRs against 11-22 here).
+template <int CH> struct WinGeoFramesKernelTable {
+  static TileKernelFn get(int in_mode) {
+    static const TileKernelFn table[4] = {
+        reproject_bicubic_win_kernel<kRect, kInRect, 0, CH, true, true>, reproject_bicubic_win_kernel<kRect, kInEquidistant, 0, CH, true, true>,
+        reproject_bicubic_win_kernel<kRect, kInEquirect, 0, CH, true, true>, reproject_bicubic_win_kernel<kRect, kInEquirectLoop, 0, CH, true, true>};
+    return table[in_mode];
+  }
+};
+template <int CH> struct WinGeoKernelTable {
+  static TileKernelFn get(int in_mode, bool big_windows) {
+    static const TileKernelFn table[4] = {
+        reproject_bicubic_win_kernel<kRect, kInRect, 0, CH, false, true>, reproject_bicubic_win_kernel<kRect, kInEquidistant, 0, CH, false, true>,
+        reproject_bicubic_win_kernel<kRect, kInEquirect, 0, CH, false, true>, reproject_bicubic_win_kernel<kRect, kInEquirectLoop, 0, CH, false, true>};
+    if (big_windows && in_mode == kInRect) return reproject_bicubic_win_kernel<kEquirect, kInRect, 0, CH, false, true>;
+    return table[in_mode];
+  }
+};
+
+// num_samples must be 1 (the pipeline keeps no accumulator across sub-samples).  QMode != 0: P.win_mode == QMode,
+// set by the host only for cells where the mode exists.  GeoRead: P.geo_mode == 2, a single whole-image launch.
+template <int QMode, int CH, bool GeoRead = false>
+inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, hipStream_t stream) {
+  static_assert(!GeoRead || QMode == 0, "the geometry cache feeds plain blocks");
+  if (GeoRead && (P.geo_mode != 2 || P.y_offset != 0 || P.y_end != P.out_h)) return hipErrorInvalidValue;
+  const int rows = P.y_end - P.y_offset;
+  if (QMode != 0) {
+    // the launch enumerates the top-left quadrant (the top / the left half when one axis is mirrored); a wavefront
+    // renders a block and its mirror images
+    const int qw = (QMode == 1 || QMode == 3 || QMode == 4) ? (P.out_w + 1) / 2 : P.out_w;
+    const int qh = (QMode == 1 || QMode == 2 || QMode == 4) ? (P.out_h + 1) / 2 : P.out_h;
+    P.tiles_x = (qw + kBlkW * kWinWaves - 1) / (kBlkW * kWinWaves);
+    P.tiles_y = (qh + kBlkH - 1) / kBlkH;
+    P.blocks_per_wave = (QMode == 1 || QMode == 4) ? 4 : 2;
+  } else {
+    P.tiles_x = (P.out_w + kBlkW * kWinWaves - 1) / (kBlkW * kWinWaves);
+    // strips of LRP_WIN_STRIP blocks when that still leaves >= 8 workgroups per CU, else shorter
+    const int row_blocks = (rows + kBlkH - 1) / kBlkH;
+    int G = LRP_WIN_STRIP;
+    if (GeoRead && P.blocks_per_wave > 0) G = std::min(P.blocks_per_wave, kGeoStripRows); // the caller's override (lrp_debug_set "geo_strip")
+    // (a batch whose wavefronts walk several frames pipelines the windows of one block across its frames: one block per
+    // wavefront measured 2-3 % faster there — equirect -> fisheye rotated 143 -> 139 us, rect -> rect 130.5 -> 128 —, four 5 % slower)
+    if (P.batch_n > 1 && !(out_idx == 2 && in_mode == kInRect)) G = 1;
+    const bool strip_forced = GeoRead && P.blocks_per_wave > 0;
+    while (!strip_forced && G > 1 && (long long)P.tiles_x * kWinWaves * ((row_blocks + G - 1) / G) < 8192) G >>= 1; // >= 2 rounds of wavefronts
+    P.blocks_per_wave = G;
+    P.tiles_y = (row_blocks + G - 1) / G;
+  }
+  const int n_tiles = P.tiles_x * P.tiles_y;
+  if (n_tiles <= 0) return hipSuccess;
+  // Frames per wavefront of a batched launch: as many as leave at least two rounds of wavefronts on the chip
+  // (4096 wave slots), so that a 4K batch of 16 runs every strip through all 16 frames and small images keep the chip full.
+  int groups = P.batch_n > 0 ? P.batch_n : 1;
+  const int frames_override = P.frames_per_wave; // on entry: 0 = automatic
+  P.frames_per_wave = 1;
+  if (P.batch_n > 1) {
+    const long long units = (long long)n_tiles * kWinWaves * P.batch_n;
+    int F = (int)std::min<long long>(P.batch_n, std::max<long long>(1, units / 8192));
+    // a rectilinear view inside a panorama: a quarter of the strips (the ones in view) carry most of the frame's time and
+    // gain nothing from shared coordinates (they wait for gathers) — 16 frames long they unbalance the launch (223 -> 256 us)
+    if (out_idx == 2 && in_mode == kInRect) F = 1;
+    if (frames_override > 0) F = std::max(1, std::min(P.batch_n, frames_override)); // the caller's override (lrp_debug_set "batch_frames": A/B runs, tests)
+    if (P.geo_mode == 1 || P.geo_mode == 3) F = 1; // the launch that writes a geometry-cache entry: the instantiations without the frame loop have the side output
+    P.frames_per_wave = F;
+    groups = (P.batch_n + F - 1) / F;
+  }
+  TileKernelFn fn;
+  if constexpr (GeoRead)
+    fn = P.frames_per_wave > 1 ? WinGeoFramesKernelTable<CH>::get(in_mode) : WinGeoKernelTable<CH>::get(in_mode, P.rgbaz_runs != 0);
+  else
+    fn = P.frames_per_wave > 1 ? WinKernelTable<QMode, CH, true>::get(out_idx, in_mode) : WinKernelTable<QMode, CH, false>::get(out_idx, in_mode);
+  if (!fn) return hipErrorInvalidValue; // (the host never asks for a mode outside its cells)
+  hipLaunchKernelGGL(fn, dim3((unsigned)(kXcds * xcd_rows(P.tiles_y, kWinXcdBand) * P.tiles_x), (unsigned)groups), dim3(kWinThreads), 0, stream, P);
+  return hipGetLastError();
+}
+
+} // namespace lrp
