@@ -337,7 +337,10 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     // (... and a rectilinear source under a rectilinear / equirectangular target: four divides a pixel cost less than the 8 bytes
     // a pixel the map adds to these memory-bound kernels — rect -> equirect nearest 105 -> 117 us, bilinear 144 -> 159 with it)
     const bool cheap_coordinates = im == lrp::kInRect && out->lens.type != LRP_FISHEYE_EQUIDISTANT;
-    const bool tile_single = !window && interpolation != LRP_BICUBIC && num_samples == 1 && n_batch <= 0 &&
+    // Batched bilinear launches read the map too, a frame per workgroup (8 wavefronts per SIMD against the 4 of the instantiations
+    // that hold coordinates across frames: equirect -> fisheye rotated 129.4 -> 107.1 us per frame, equirect -> rect 89.3 -> 84.3);
+    // batched nearest keeps the frame loop (69.4 against 72.9 us).
+    const bool tile_single = !window && interpolation != LRP_BICUBIC && num_samples == 1 && (n_batch <= 0 || interpolation == LRP_BILINEAR) &&
                              !(interpolation == LRP_NEAREST && P.quad != 0) && !cheap_coordinates;
     if ((window || tile_single) && !band && kernel_choice() == 2 && knob(kKnobGeoCache) != 0) {
       lrp::GeoKey key;

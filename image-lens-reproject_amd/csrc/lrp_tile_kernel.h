@@ -303,7 +303,7 @@ template <int Interp> hipError_t launch_tile_interp(KParams P, int out_idx, int 
   int groups = P.batch_n > 0 ? P.batch_n : 1;
   const int frames_override = P.frames_per_wave; // on entry: 0 = automatic
   P.frames_per_wave = 1;
-  if (Interp != 2 && P.num_samples == 1 && P.batch_n > 1 && P.quad == 0) { // (the plain path: any rotation; the mirrored paths are bound by memory)
+  if (Interp != 2 && P.num_samples == 1 && P.batch_n > 1 && P.quad == 0 && P.geo_mode != 2) { // (the plain path: any rotation; the mirrored paths are bound by memory; GeoRead: a frame per workgroup)
     const long long units = (long long)n_tiles * P.batch_n;
     int F = (int)std::min<long long>(P.batch_n, std::max<long long>(1, units / 4096));
     if (out_idx == 2 && in_mode == kInRect) F = 1; // (see the window kernel: uneven tiles)
@@ -314,7 +314,7 @@ template <int Interp> hipError_t launch_tile_interp(KParams P, int out_idx, int 
   TileKernelFn fn;
   if (P.geo_mode == 2) { // coordinates from the geometry cache (the host asks for it for single whole-image launches only)
     if constexpr (Interp != 2) {
-      if (P.quad != 0 || P.batch_n > 0 || P.num_samples != 1 || P.y_offset != 0 || P.y_end != P.out_h) return hipErrorInvalidValue;
+      if (P.quad != 0 || P.num_samples != 1 || P.y_offset != 0 || P.y_end != P.out_h) return hipErrorInvalidValue;
       fn = P.channels == 4 ? TileGeoKernelTable<Interp, 4>::get(in_mode) : P.channels == 3 ? TileGeoKernelTable<Interp, 3>::get(in_mode) : TileGeoKernelTable<Interp, 5>::get(in_mode);
     } else {
       return hipErrorInvalidValue;
