@@ -1,34 +1,39 @@
 #!/usr/bin/env bash
 # One pass over everything DESIGN.md quotes; run on an MI355X box from the repo root.
-# Writes gpurun_out/final/* (copy what is to be judged into profiles/).
+# Writes gpurun_out/final/* (copy what is to be judged into profiles/ with tools/final_collect.sh).
 set -uo pipefail
 R="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd "$R"
 out=gpurun_out/final; rm -rf $out gpurun_out/traffic; mkdir -p $out
 (timeout 1500 python -m pytest tests -m gpu -q > $out/gpu_tests.log 2>&1; echo "exit $?" >> $out/gpu_tests.log); tail -3 $out/gpu_tests.log
 # the PMC traffic first: bench.py reports roofline.traffic only from a file stamped with the sources it runs
-bash tools/collect_traffic.sh > $out/traffic.log 2>&1; tail -2 $out/traffic.log; cp gpurun_out/traffic_r03.json profiles/traffic_r03.json
+bash tools/collect_traffic.sh > $out/traffic.log 2>&1; tail -2 $out/traffic.log; cp gpurun_out/traffic_r04.json profiles/traffic_r04.json
 (timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?")
-ALL="eqd_rect_bc eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch eqr_rect_bc_gen rect_rect_bc eqd_eqd_bc eqr_eqr_bc_rot eqr_eqd_bc_rot rect_eqd_bc rect_eqr_bc eqr_eqd_bl_rot eqr_rect_bl eqr_rect_nn"
+ALL="eqd_rect_bc eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch eqr_rect_bc_gen rect_rect_bc eqd_eqd_bc eqr_eqr_bc_rot eqr_eqd_bc_rot rect_eqd_bc rect_eqr_bc eqr_eqd_bl_rot eqr_rect_bl eqr_rect_nn eqr_rect_bl_rot eqr_rect_nn_rot"
 BC="eqd_rect_bc eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch eqr_rect_bc_gen rect_rect_bc eqr_eqd_bc_rot rect_eqr_bc"
-timeout 300 ./tools/kbench --sum --reps 30 $ALL > $out/kbench_rgba.log 2>&1
+timeout 300 ./tools/kbench --sum --reps 32 --distinct 16 $ALL > $out/kbench_rgba_single.log 2>&1
+timeout 300 ./tools/kbench --sum --reps 32 --distinct 16 --geo 0 $ALL > $out/kbench_rgba_single_geo0.log 2>&1
 timeout 400 ./tools/kbench --sum --reps 8 --batch 16 --distinct 16 $ALL > $out/kbench_rgba_batched.log 2>&1
+timeout 400 ./tools/kbench --sum --reps 8 --batch 16 --distinct 16 --geo 0 $ALL > $out/kbench_rgba_batched_geo0.log 2>&1
 timeout 300 ./tools/kbench --sum --reps 8 --batch 16 --distinct 16 --channels 3 $BC eqr_rect_bl eqr_rect_nn > $out/kbench_rgb_batched.log 2>&1
 timeout 300 ./tools/kbench --sum --reps 8 --batch 16 --distinct 16 --channels 5 $BC eqr_rect_bl eqr_rect_nn > $out/kbench_rgbaz_batched.log 2>&1
+timeout 300 ./tools/kbench --sum --reps 24 --distinct 16 --channels 5 $BC > $out/kbench_rgbaz_single.log 2>&1
 timeout 200 ./tools/kbench --sum --reps 8 --batch 16 --distinct 16 --channels 5 --post rect_eqr_bc > $out/kbench_rgbaz_post_batched.log 2>&1
+timeout 200 ./tools/kbench --sum --reps 24 --distinct 16 --channels 5 --post rect_eqr_bc > $out/kbench_rgbaz_post_single.log 2>&1
 timeout 200 ./tools/kbench --sum --reps 20 --size 8192 --out-size 2048 --channels 3 --distinct 4 eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch > $out/kbench_cubemap_faces.log 2>&1
-for m in 1 0; do echo "# LRP_MIRROR_MODES=$m"; LRP_MIRROR_MODES=$m timeout 300 ./tools/kbench --reps 8 --batch 16 --distinct 16 eqr_rect_bc_rot eqr_rect_bc_pitch eqr_eqd_bc_rot eqd_eqd_bc; done > $out/kbench_mirror_modes_on_off.log 2>&1
+timeout 200 ./tools/kbench --sum --reps 20 --size 8192 --out-size 2048 --channels 3 --distinct 4 --geo 0 eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch > $out/kbench_cubemap_faces_geo0.log 2>&1
 timeout 300 ./tools/staged_bench > $out/staged.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof_bench -- python3 $R/bench.py --no-cpu-baseline > $R/$out/prof_bench.log 2>&1; echo "rocprof rc=$?"
-cat $R/$out/prof_bench/*/*kernel_stats.csv
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof_bench -- python3 $R/bench.py --no-cpu-baseline --no-staged > $R/$out/prof_bench.log 2>&1; echo "rocprof rc=$?"
+cat $R/$out/prof_bench/*/*kernel_stats.csv | cut -c1-200
 python3 $R/tools/kernel_trace_summary.py $(ls -t $R/$out/prof_bench/*/*kernel_trace.csv | head -1) | tee $R/$out/kernel_trace_by_launch_shape.txt
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
-           "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" \
-           "SQ_LDS_IDX_ACTIVE SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE"; do
+           "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/$out/sq/p$i -- $R/tools/kbench --batch 16 --reps 4 --warmup 20 --distinct 16 eqd_rect_bc eqr_rect_bc_pitch eqr_rect_bc_gen > $R/$out/sq_p$i.log 2>&1
-  echo "sq pass $i rc=$?"
+  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/$out/sq/b$i -- $R/tools/kbench --batch 16 --reps 4 --warmup 20 --distinct 16 eqd_rect_bc eqr_rect_bc_gen > $R/$out/sq_b$i.log 2>&1
+  echo "sq batched pass $i rc=$?"
+  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/$out/sq/s$i -- $R/tools/kbench --reps 8 --warmup 20 --distinct 16 eqd_rect_bc eqr_rect_bc_gen > $R/$out/sq_s$i.log 2>&1
+  echo "sq single pass $i rc=$?"
 done
 python3 $R/tools/pmc_summary.py $R/$out/sq > $R/$out/sq_counters.txt
 cat $R/$out/bench.json
