@@ -111,14 +111,25 @@ struct GeoLayout {
 // bytes per block of the window kernel instead of 16 row segments of 128 bytes — measured the same for the window kernels
 // and 2-3 % slower for the tile kernels: profiles/r04_experiments_ab.txt.)
 inline __host__ __device__ uint32_t geo_map_index(int x, int y, int out_w) { return (uint32_t)y * (uint32_t)out_w + (uint32_t)x; }
+// Block rows an entry allocates, and — behind the box records — one CLASS byte per block, stored column by column
+// (block column * geo_block_rows + block row: the blocks of a wavefront's strip are consecutive bytes of one aligned word):
+// 0, or 1-4 = every pixel of the block lies beyond that corner of the source (WinBlockT::corner()).  A GeoRead wavefront reads
+// the classes of its strip with one scalar load when it starts; a corner block then needs neither its box record nor its
+// coordinates — no vector load at all in front of its four stores.
+inline __host__ __device__ uint32_t geo_block_rows(int out_h) {
+  const uint32_t by = (uint32_t)(out_h + 15) / 16;
+  return (by + kGeoStripRows - 1) / kGeoStripRows * kGeoStripRows;
+}
+inline __host__ __device__ uint32_t geo_block_cols(int out_w) { return (uint32_t)(out_w + 15) / 16; }
+inline __host__ __device__ size_t geo_class_offset(int out_w, int out_h) { // bytes from the first box record to the first class byte
+  return (size_t)geo_block_cols(out_w) * geo_block_rows(out_h) * 32;
+}
 inline GeoLayout geo_layout(int out_w, int out_h, bool with_boxes) {
   GeoLayout L{};
   L.xy_bytes = (size_t)out_w * (size_t)out_h * 8;
   if (with_boxes) {
-    const size_t bx = (size_t)(out_w + 15) / 16;
-    size_t by = (size_t)(out_h + 15) / 16;
-    by = (by + kGeoStripRows - 1) / kGeoStripRows * kGeoStripRows;
-    L.box_bytes = bx * by * 32;
+    const size_t blocks = (size_t)geo_block_cols(out_w) * geo_block_rows(out_h);
+    L.box_bytes = blocks * 32 + ((blocks + 15) & ~(size_t)15);
   }
   return L;
 }

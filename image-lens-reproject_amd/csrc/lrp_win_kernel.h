@@ -95,7 +95,10 @@ template <int OutLens, int InMode, int QMode, int CH, bool Frames = false, bool 
 #ifndef LRP_WIN_CAP_BIG
 #define LRP_WIN_CAP_BIG 1280 // window slots of the big-window GeoRead variant: 20 KiB per wavefront, two wavefronts per SIMD
 #endif
-__global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 : CH == 5 ? LRP_WIN_MINWAVES5 : (QMode == 4 ? LRP_WIN_MINWAVES_RAYS : (Frames ? LRP_WIN_MINWAVES_FRAMES : (QMode >= 2 ? LRP_WIN_MINWAVES_AXIS : LRP_WIN_MINWAVES)))) void reproject_bicubic_win_kernel(const KParams Pk) {
+#ifndef LRP_WIN_MINWAVES_BIG
+#define LRP_WIN_MINWAVES_BIG 2
+#endif
+__global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LRP_WIN_MINWAVES_BIG : CH == 5 ? LRP_WIN_MINWAVES5 : (QMode == 4 ? LRP_WIN_MINWAVES_RAYS : (Frames ? LRP_WIN_MINWAVES_FRAMES : (QMode >= 2 ? LRP_WIN_MINWAVES_AXIS : LRP_WIN_MINWAVES)))) void reproject_bicubic_win_kernel(const KParams Pk) {
   constexpr bool Quad = QMode != 0;
   constexpr bool MirX = QMode == 1 || QMode == 3 || QMode == 4, MirY = QMode == 1 || QMode == 2 || QMode == 4;
   constexpr bool kSharedRays = QMode == 4; // only the ray through the output lens is shared: per-image coordinates are stored like a plain block's
@@ -191,6 +194,9 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
   // rows the WRITING launch walked, and that launch may have cut its strips differently.)
   const int G = GeoRead ? min(Gs, (P.y_end - P.y_offset + kBlkH - 1) / kBlkH - ty * Gs) : Gs;
   auto block_row = [&](int g) { return (kAliasPairs && g_reverse) ? G - 1 - g : g; }; // block of a plain strip rendered by iteration g
+  // ... and its class byte (lrp_params.h)
+  auto geo_classes = [&]() { return reinterpret_cast<uint8_t *>(P.geo_box) + geo_class_offset(P.out_w, P.out_h); };
+  auto geo_class_index = [&](int g) { return (uint32_t)tx * geo_block_rows(P.out_h) + (uint32_t)(ty * Gs + block_row(g)); };
   auto geo_block = [&](int g) { return (uint32_t)(ty * Gs + block_row(g)) * (uint32_t)P.tiles_x + (uint32_t)tx; }; // geometry cache: box record of a plain block
   // Mirrored blocks (Quad instantiations, launched when P.quad).  Without a rotation the mapping is symmetric
   // about both image axes: the pixels (x, y), (W-1-x, y), (x, H-1-y), (W-1-x, H-1-y) have
@@ -480,6 +486,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
 #pragma unroll
         for (int i = 0; i < 7; ++i) bv = lane == i ? words[i] : bv;
         if (lane < 8) P.geo_box[geo_block(g) * 8u + (uint32_t)lane] = bv;
+        if (lane == 0) geo_classes()[geo_class_index(g)] = (uint8_t)(planned ? b.corner() : 0);
       }
     }
   };
@@ -499,8 +506,36 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
       b.sy[k] = v.y;
     }
   };
-  auto geo_plan = [&](WinBlock &b) {
+  // The classes of this strip's blocks (lrp_params.h geo_class_offset): one aligned word through the scalar cache when the
+  // wavefront starts (strips of 1, 2 or 4 blocks: their class bytes lie in one word).  A corner block is then known before
+  // anything is requested for it and skips geo_fetch: in a strip of corner blocks nothing stands between the stores
+  // (a 4096^2 frame of corner blocks, every block waiting for its successor's record and coordinates: RGBA 100 -> 79 us,
+  // RGBAZ + tonemap 167 -> 144 us).
+#ifndef LRP_GEO_CLASSES
+#define LRP_GEO_CLASSES 2 // 0: never; 1: every GeoRead instantiation of a source with corners (10 more spilled SGPRs at four wavefronts per SIMD: rect -> fisheye single launches 164 -> 171 us); 2: the big-window variant only
+#endif
+  constexpr bool kGeoClasses = GeoRead && !Loop && LRP_WIN_CORNER != 0 && (LRP_GEO_CLASSES == 1 || (LRP_GEO_CLASSES == 2 && kBigWin));
+  uint32_t strip_classes = 0;
+  if constexpr (kGeoClasses) {
+    if (Gs <= 4 && (Gs & (Gs - 1)) == 0) {
+      typedef const uint32_t __attribute__((address_space(4))) *ScalarU;
+      const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)tx * geo_block_rows(P.out_h) + (uint32_t)(ty * Gs)));
+      const uintptr_t base = reinterpret_cast<uintptr_t>(geo_classes());
+      const uint64_t addr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32 |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base)) + (first & ~3u);
+      strip_classes = *reinterpret_cast<ScalarU>(addr) >> (8u * (first & 3u));
+    }
+  }
+  auto geo_class = [&](int g) -> int { // 0: plan from the box record; 1-4: corner block
+    if constexpr (kGeoClasses) return (int)((strip_classes >> (8u * (uint32_t)block_row(g))) & 7u);
+    return 0;
+  };
+  auto geo_plan = [&](WinBlock &b, int cls) {
     clear_block(b);
+    if (cls != 0) {
+      b.tier = cls << 3;
+      return;
+    }
     const int flags = __builtin_amdgcn_readlane(geo_boxv, 6);
     if ((flags & 4) != 0)
       plan_window(b, __builtin_amdgcn_readlane(geo_boxv, 0), __builtin_amdgcn_readlane(geo_boxv, 1),
@@ -509,18 +544,26 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
   };
   // the one value of a corner block: sample_bicubic with all 16 taps on the corner texel (sample_direct's
   // one-column-and-one-row case, same operations)
+  // (the texel through the scalar cache: its address is wave-uniform, a scalar load returns in ~200 cycles, occupies no vector
+  // register until the arithmetic and stays out of the vmcnt order the window pipeline counts on — as a vector load it was a
+  // second exposed round trip in front of every corner block's stores: a 4096^2 RGBA frame of corner blocks 109 -> 100 us)
   auto corner_value = [&](const WinBlock &b) {
     const int xh = (b.corner() - 1) & 1, yh = (b.corner() - 1) >> 1;
     const float fx = xh ? 1.0f : 0.0f, fy = yh ? 1.0f : 0.0f; // the clamped weights (src/reproject.cpp:130-131)
     const float hfx = 0.5f * fx, hfy = 0.5f * fy;
     const uint32_t off = (uint32_t)(yh ? P.in_h - 1 : 0) * src.row_bytes + (uint32_t)(xh ? in_w - 1 : 0) * (4u * CH);
+    typedef const float __attribute__((address_space(4))) *ScalarF;
+    const uintptr_t base = reinterpret_cast<uintptr_t>(P.src);
+    const uint64_t addr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32 |
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base)) + (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+    const ScalarF tp = reinterpret_cast<ScalarF>(addr);
     if constexpr (CH == 5) {
-      const Px<5> t = texel_at<5>(src.rsrc, off, 0u);
+      const Px<5> t{f2{tp[0], tp[1]}, f2{tp[2], tp[3]}, tp[4]};
       const Px<5> k = cubic_px<5>(t, t, t, t, fy, hfy);
       const Px<5> r = cubic_px<5>(k, k, k, k, fx, hfx);
       return Rgba{r.lo, r.hi, r.e};
     } else {
-      const Px<4> t = texel_at<4>(src.rsrc, off, 0u); // (RGB: a 16-byte read of a 12-byte texel, fourth component unused)
+      const Px<4> t{f2{tp[0], tp[1]}, f2{tp[2], CH == 3 ? 0.0f : tp[3]}, 0.0f}; // (RGB: the fourth component is unused)
       const Px<4> k = cubic_px<4>(t, t, t, t, fy, hfy);
       return cubic_px<4>(k, k, k, k, fx, hfx);
     }
@@ -691,8 +734,9 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
   // see below, so that store is always issued.)
   WinBlock cur, nxt;
   if constexpr (GeoRead) {
-    geo_fetch(0, cur);
-    geo_plan(cur);
+    const int cls0 = geo_class(0);
+    if (cls0 == 0) geo_fetch(0, cur);
+    geo_plan(cur, cls0);
   } else {
     coords(0, cur);
   }
@@ -716,11 +760,20 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
     if (dma_early) issue_next();
   };
   // The result of pass k of block g: num_samples == 1, (0.0f + s) * normalize (src/reproject.cpp:334-341), store.
-  auto emit = [&](int g, int k, const Rgba &s, auto as_runs, bool runs_rt = true) {
+  auto accumulate = [&](const Rgba &s) {
     Rgba a4 = px_zero<4>();
     px_add<4>(a4, s);
     if constexpr (CH == 5) a4.e = 0.0f + s.e;
-    const Px<CH> a{a4.lo, CH >= 4 ? a4.hi : f2{0.0f, 0.0f}, CH == 3 ? a4.hi.x : a4.e};
+    return Px<CH>{a4.lo, CH >= 4 ? a4.hi : f2{0.0f, 0.0f}, CH == 3 ? a4.hi.x : a4.e};
+  };
+  // where pass k of block g goes: (xo, yo) this lane's pixel; runs: the pass lies in the image whole (wave-uniform), `first` = its
+  // first pixel, `row_step` = pixels from one of its four rows to the next, `mxo`: written right to left
+  struct PassOut {
+    int xo, yo, row_step;
+    uint32_t first;
+    bool whole, mxo;
+  };
+  auto pass_out = [&](int g, int k) {
     // Every lane stores: lanes / rows beyond the image have recomputed the pixel they were
     // clamped to (xe, ye) and write that same value to that same address again, so the
     // store is issued by every wavefront (the vmcnt(1) below counts on it).
@@ -731,10 +784,23 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
     const int yk = y_base + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
     const int yc = yk < qh ? yk : qh - 1;
     const int gm = image_of(g);
-    const int xo = (quad && (gm & 1)) ? P.out_w - 1 - xe : xe; // mirrored blocks write the mirrored pixel
-    const int yo = (quad && (gm >> 1)) ? P.out_h - 1 - yc : yc;
+    PassOut o;
+    o.xo = (quad && (gm & 1)) ? P.out_w - 1 - xe : xe; // mirrored blocks write the mirrored pixel
+    o.yo = (quad && (gm >> 1)) ? P.out_h - 1 - yc : yc;
+    const int x_blk = tx * (kBlkW * kWinWaves) + wave * kBlkW;
+    const int y_top = P.y_offset + ty * (quad ? kBlkH : kBlkH * Gs) + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
+    o.whole = x_blk + kBlkW <= qw && y_top + kPassRows <= qh;
+    o.mxo = quad && (gm & 1);
+    const bool myo = quad && (gm >> 1);
+    o.first = (uint32_t)(myo ? P.out_h - 1 - y_top : y_top) * (uint32_t)P.out_w + (uint32_t)(o.mxo ? P.out_w - x_blk - kBlkW : x_blk);
+    o.row_step = myo ? -P.out_w : P.out_w;
+    return o;
+  };
+  auto emit = [&](int g, int k, const Rgba &s, auto as_runs, bool runs_rt = true) {
+    const Px<CH> a = accumulate(s);
+    const PassOut o = pass_out(g, k);
 #if defined(LRP_NO_STORE) // timing experiment: almost no output traffic
-    if (a.lo.x == 12345.678f) store_px<CH, true>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
+    if (a.lo.x == 12345.678f) store_px<CH, true>(P, (uint32_t)o.yo * (uint32_t)P.out_w + (uint32_t)o.xo, a);
 #else
     if constexpr (CH == 5) {
      if constexpr (decltype(as_runs)::value) {
@@ -743,21 +809,58 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
       // all blocks of a rectilinear view rendered into a panorama (kRunsEverywhere: most of that frame is out of
       // view or gathers minified taps; 383 -> 334 us).  In the VALU-bound kernels that interpolate from the LDS
       // window the exchange costs more than the stores gain (measured: 4-7 % slower).
-      const int x_blk = tx * (kBlkW * kWinWaves) + wave * kBlkW;
-      const int y_top = P.y_offset + ty * (quad ? kBlkH : kBlkH * Gs) + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
-      if (runs_rt && x_blk + kBlkW <= qw && y_top + kPassRows <= qh) {
-        const bool mxo = quad && (gm & 1), myo = quad && (gm >> 1);
+      if (runs_rt && o.whole) {
         float c[5];
         finish_px<5, true>(P, a, c);
-        const uint32_t first = (uint32_t)(myo ? P.out_h - 1 - y_top : y_top) * (uint32_t)P.out_w +
-                               (uint32_t)(mxo ? P.out_w - x_blk - kBlkW : x_blk);
-        store_rgbaz_run<4>(P, out_lds, prow * kBlkW + (mxo ? kBlkW - 1 - pcol : pcol), first, myo ? -P.out_w : P.out_w, c);
+        store_rgbaz_run<4>(P, out_lds, prow * kBlkW + (o.mxo ? kBlkW - 1 - pcol : pcol), o.first, o.row_step, c);
         return;
       }
      }
     }
-    store_px<CH, true>(P, (uint32_t)yo * (uint32_t)P.out_w + (uint32_t)xo, a);
+    store_px<CH, true>(P, (uint32_t)o.yo * (uint32_t)P.out_w + (uint32_t)o.xo, a);
 #endif
+  };
+  // A corner block: every pixel is the one value `s`.  Finished (normalize, tonemap) once, stored four times; an RGBAZ pass that
+  // lies in the image whole leaves as 80 sixteen-byte chunks of the repeating five-float pattern straight from registers (no
+  // exchange through the LDS).  `before_last` runs in front of the last store (the next window's request).
+  auto emit_corner = [&](int g, const Rgba &s, auto before_last) {
+    const Px<CH> a = accumulate(s);
+    float c[5];
+    finish_px<CH, true>(P, a, c);
+    typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    v4f_a4 q0{0.0f, 0.0f, 0.0f, 0.0f}, q1{0.0f, 0.0f, 0.0f, 0.0f};
+    int chunk_row = 0, chunk_col = 0;
+    if constexpr (CH == 5) {
+      // chunk `lane` = chunk cc of run row r (20 chunks per row of 16 pixels); chunks 64-79 (lanes 0-15) = row 3, chunks 4-19
+      chunk_row = (lane * 3277) >> 16;
+      chunk_col = lane - 20 * chunk_row;
+      auto pattern = [&](int chunk) { // floats 4 chunk .. 4 chunk + 3 of c[0] c[1] c[2] c[3] c[4] c[0] ...
+        const int m = (4 * chunk) % 5;
+        auto at = [&](int i) { const int j = (m + i) % 5; return j == 0 ? c[0] : j == 1 ? c[1] : j == 2 ? c[2] : j == 3 ? c[3] : c[4]; };
+        return v4f_a4{at(0), at(1), at(2), at(3)};
+      };
+      q0 = pattern(chunk_col);
+      q1 = pattern(4 + lane);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k == 3) before_last();
+      const PassOut o = pass_out(g, k);
+#if defined(LRP_NO_STORE)
+      if (c[0] == 12345.678f) store_texel_nt<CH>(P.dst + (size_t)((uint32_t)o.yo * (uint32_t)P.out_w + (uint32_t)o.xo) * CH, c);
+#else
+      if constexpr (CH == 5) {
+        if (o.whole) { // (a constant run reads the same mirrored or not)
+          float *const row0 = P.dst + (size_t)o.first * 5;
+          const ptrdiff_t step = (ptrdiff_t)o.row_step * 5;
+          __builtin_nontemporal_store(q0, reinterpret_cast<v4f_a4 *>(row0 + chunk_row * step + 4 * chunk_col));
+          if (lane < 16) __builtin_nontemporal_store(q1, reinterpret_cast<v4f_a4 *>(row0 + 3 * step + 16 + 4 * lane));
+          continue;
+        }
+      }
+      store_texel_nt<CH>(P.dst + (size_t)((uint32_t)o.yo * (uint32_t)P.out_w + (uint32_t)o.xo) * CH, c);
+#endif
+    }
   };
   // Pass windows (kernels with split blocks): a block whose two half windows do not fit either (a pole face of a
   // cubemap: the panorama's rows converge) still has passes — 16 x 4 pixels — whose own window fits.  Planned per pass
@@ -819,7 +922,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
       asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); // window g has landed; block g-1's last store may be in flight
 #endif
     if constexpr (GeoRead)
-      if (g + 1 < G && f == 0) geo_fetch(g + 1, nxt);
+      if (g + 1 < G && f == 0 && geo_class(g + 1) == 0) geo_fetch(g + 1, nxt);
     const float4 *const win = win0;
     // The tier of this block in a scalar register for the branches below: carried through the block loop inside `cur` it
     // ends up in a VGPR (the kernel is at the SGPR limit), and every test of it then costs a v_and + v_cmp and the
@@ -841,12 +944,8 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
       const Rgba cs = corner_value(cur);
       if (Quad && !kSharedRays && last_frame && g + 1 < G) coords(g + 1, nxt);
       if constexpr (GeoRead)
-        if (g + 1 < G && last_frame) geo_plan(nxt);
-      emit(g, 0, cs, std::true_type{});
-      emit(g, 1, cs, std::true_type{});
-      emit(g, 2, cs, std::true_type{});
-      next_window();
-      emit(g, 3, cs, std::true_type{});
+        if (g + 1 < G && last_frame) geo_plan(nxt, geo_class(g + 1));
+      emit_corner(g, cs, [&]() { next_window(); });
       if (!dma_early && has_next()) issue_next();
       if (last_frame) cur = nxt;
       continue;
@@ -862,7 +961,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? 2 
         const int k = 2 * h + kk;
         if (Quad && !kSharedRays && k == 3 && last_frame && g + 1 < G) coords(g + 1, nxt); // only its box is kept
         if constexpr (GeoRead)
-          if (k == 3 && g + 1 < G && last_frame) geo_plan(nxt);
+          if (k == 3 && g + 1 < G && last_frame) geo_plan(nxt, geo_class(g + 1));
         const bool last_pass = k == 3;
         float psx = cur.sx[k], psy = cur.sy[k];
         if constexpr (Quad && !kSharedRays) quad_xy(image_of(g), k, psx, psy); // re-derived (2-4 instructions) instead of held in registers
