@@ -181,7 +181,7 @@ lrp::KParams make_params(const lrp_image *in, const lrp_image *out, int num_samp
 // initial values, once, when the library is loaded — nothing on a launch path calls getenv.
 //   kernel: 0 = pixel kernel, 1 = tile kernel everywhere, 2 (default) = tile kernel with the LDS-window kernel for
 //   bicubic, 3 = the same without its shared-coefficient tier and without any work sharing.  All HIP; there is no CPU path.
-enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobCount };
+enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobGeoBig, kKnobCount };
 struct KnobSpec {
   const char *name, *env;
   int lo, hi, initial;
@@ -198,6 +198,7 @@ const KnobSpec kKnobs[kKnobCount] = {
     {"multi_fork", "LRP_MULTI_FORK", 0, kMaxSideStreams, 1},    // side streams of lrp_reproject_multi_device
     {"geo_cache", "LRP_GEO_CACHE", 0, 1, 1},        // geometry cache used by single launches (0: every launch computes)
     {"geo_strip", "LRP_GEO_STRIP", 0, lrp::kGeoStripRows, 0}, // blocks per wavefront of a launch that reads the geometry cache (0: automatic)
+    {"geo_big", "LRP_GEO_BIG", 0, 1, 1},            // big-window variant of the kernels that read the geometry cache (a rectilinear view rendered into a panorama); 0: the four-wavefront instantiation
 };
 std::atomic<int> g_knobs[kKnobCount];
 const bool g_knobs_initialised = [] { // the one place that reads the environment
@@ -361,6 +362,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
         P.quad = 0; // (tile kernels: the plain path writes / the GeoRead kernels read the map)
         P.blocks_per_wave = knob(kKnobGeoStrip); // 0: the launcher decides
         P.rgbaz_runs = (out->lens.type == LRP_EQUIRECTANGULAR && in->lens.type == LRP_RECTILINEAR) ? 1 : 0;
+        P.big_windows = knob(kKnobGeoBig) != 0 ? P.rgbaz_runs : 0;
       }
     }
     auto launch = [&]() {

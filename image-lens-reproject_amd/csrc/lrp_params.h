@@ -95,6 +95,7 @@ struct KParams {
   int32_t geo_mode;
   float *geo_xy;       // (sx, sy) of every output pixel, element geo_map_index(x, y): the top-left-origin source texel coordinates of src/reproject.cpp:323-324
   int32_t *geo_box;    // window kernel: [block rows][blocks_x][8] (geo_layout below)
+  int32_t big_windows; // GeoRead window kernel: the big-window variant (20 KiB of LDS per wavefront, two wavefronts per SIMD) where it is instantiated
   int32_t rgbaz_runs;  // GeoRead window kernel: a rectilinear view rendered into a panorama — the big-window variant; RGBAZ: every block leaves as 16-byte chunks (what the compute instantiations of that mapping do at compile time)
 };
 

@@ -1070,6 +1070,8 @@ template <int CH> struct WinGeoKernelTable {
         reproject_bicubic_win_kernel<kRect, kInRect, 0, CH, false, true>, reproject_bicubic_win_kernel<kRect, kInEquidistant, 0, CH, false, true>,
         reproject_bicubic_win_kernel<kRect, kInEquirect, 0, CH, false, true>, reproject_bicubic_win_kernel<kRect, kInEquirectLoop, 0, CH, false, true>};
     if (big_windows && in_mode == kInRect) return reproject_bicubic_win_kernel<kEquirect, kInRect, 0, CH, false, true>;
+    // (a big-window variant for the wrapping panorama source, measured: the pole face of the 8192^2 -> 2048^2 cubemap 108.6 ->
+    // 103.9 us, its side faces 59.8 -> 67.2, every 4096^2 mapping out of a panorama 20-25 % slower — not instantiated)
     return table[in_mode];
   }
 };
@@ -1123,7 +1125,7 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
   }
   TileKernelFn fn;
   if constexpr (GeoRead)
-    fn = P.frames_per_wave > 1 ? WinGeoFramesKernelTable<CH>::get(in_mode) : WinGeoKernelTable<CH>::get(in_mode, P.rgbaz_runs != 0);
+    fn = P.frames_per_wave > 1 ? WinGeoFramesKernelTable<CH>::get(in_mode) : WinGeoKernelTable<CH>::get(in_mode, P.big_windows != 0);
   else
     fn = P.frames_per_wave > 1 ? WinKernelTable<QMode, CH, true>::get(out_idx, in_mode) : WinKernelTable<QMode, CH, false>::get(out_idx, in_mode);
   if (!fn) return hipErrorInvalidValue; // (the host never asks for a mode outside its cells)

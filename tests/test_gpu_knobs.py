@@ -31,6 +31,7 @@ SETTINGS = {
     "geo_cache": {"geo_cache": 1},
     "geo_cache_strip1": {"geo_cache": 1, "geo_strip": 1},
     "geo_cache_strip4": {"geo_cache": 1, "geo_strip": 4},
+    "geo_cache_big0": {"geo_cache": 1, "geo_big": 0},  # (a rectilinear view into a panorama through the four-wavefront instantiation)
     "xsep0": {"geo_cache": 0, "xsep": 0},
     "quad0": {"geo_cache": 0, "quad": 0},
     "mirror_modes0": {"geo_cache": 0, "mirror_modes": 0},
@@ -81,7 +82,7 @@ class _DeviceSynth:
 
 
 def test_switch_names_and_ranges(lrp):
-    for name in ("kernel", "xsep", "quad", "mirror_modes", "win_edge", "win_split", "batch_frames", "multi_fork", "geo_cache", "geo_strip"):
+    for name in ("kernel", "xsep", "quad", "mirror_modes", "win_edge", "win_split", "batch_frames", "multi_fork", "geo_cache", "geo_strip", "geo_big"):
         now = lrp.debug_set(name, -1)
         assert lrp.debug_set(name, now) == now  # setting the current value returns it
         assert lrp.debug_set(name, 10 ** 6) == now and lrp.debug_set(name, -1) == now  # out of range: a query
