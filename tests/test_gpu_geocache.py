@@ -143,6 +143,45 @@ def test_big_window_variant_against_the_live_oracle(lrp, oracle, torch_cuda, cha
         cases.assert_same_bits(again.cpu().numpy(), want, f"read {in_name} {iw}x{ih} -> {ow}x{oh} C={channels} {rot_name}")
 
 
+@pytest.mark.parametrize("channels", [3, 4, 5])
+def test_corner_classes_under_every_strip_length(lrp, oracle, torch_cuda, channels):
+    """The class bytes of a geometry-cache entry (lrp_params.h geo_class_offset): a wavefront of the big-window variant
+    reads the classes of its strip when it starts and renders corner blocks without their record and coordinates.
+    Outputs of many block rows that are mostly out of view (tele lens: almost all corner blocks), sizes that are not
+    multiples of the block and of the strip, every strip length (8 and 16: the kernel plans every block from its
+    record), a pitch that moves the view to the top edge, the fused tonemap — the filling launch and the reading
+    launches against the live oracle."""
+    torch = torch_cuda
+    for (iw, ih, ow, oh), in_name, rot_name, post in (((96, 64, 80, 200), "rect_tele", "none", None), ((64, 64, 147, 331), "rect_tele", "r30", (1.5, 3.0)),
+                                                      ((200, 120, 64, 130), "rect", "pitch90", (0.75, 2.0)), ((90, 70, 33, 97), "rect", "pan180", None)):
+        case = dict(iw=iw, ih=ih, ow=ow, oh=oh, out="eqr_full", inp=in_name, interp=2, c=channels, ns=1, rot=rot_name, seed=0xC1A5 + ow + channels)
+        want = golden_cases.run_oracle(oracle, lrp, case)
+        if post:
+            want = oracle.post_process(want, *post)
+        src, lin, lout, rot = _small_setup(lrp, torch, case)
+        d_in = torch.from_numpy(src).cuda()
+
+        def render():
+            d_out = torch.full((oh, ow, channels), -12345.0, dtype=torch.float32, device="cuda")
+            lrp.reproject(lrp.Image(lin, iw, ih, channels, d_in), lrp.Image(lout, ow, oh, channels, d_out), 1, 2, rot, post=post)
+            torch.cuda.synchronize()
+            return d_out.cpu().numpy()
+
+        what = f"{in_name} {iw}x{ih} -> {ow}x{oh} C={channels} {rot_name} post={post}"
+        cases.assert_same_bits(render(), want, "fill " + what)
+        for strip in (0, 1, 2, 4, 8, 16):
+            prev = lrp.debug_set("geo_strip", strip)
+            got = render()
+            lrp.debug_set("geo_strip", prev)
+            cases.assert_same_bits(got, want, f"read (strip {strip}) " + what)
+        prev = lrp.debug_set("geo_big", 0)  # the four-wavefront instantiation reads the same entry (and ignores the classes)
+        got = render()
+        lrp.debug_set("geo_big", prev)
+        cases.assert_same_bits(got, want, "read (geo_big 0) " + what)
+        stats = lrp.geometry_cache_stats()
+        assert stats["fills"] >= 1 and stats["hits"] >= 7
+
+
 FRAMES = ["config0_512_eqr_rect_nn", "config2_4k_eqr_eqd_bl_rot", "4k_eqr_rect_bl", "4k_eqr_rect_nn", "config1_4k_eqd_rect_bc", "northstar_4k_eqr_rect_bc", "scaling_4k_eqr_eqd_bc_rot", "config3_4k_rgbaz_rect_eqr_bc_post",
           "config3_4k_rgbz_rect_eqr_bc_post", "config4_8k_rgb_face0", "config4_8k_rgb_face1", "config4_8k_rgb_face4",
           "4k_eqr_rect_bc_rot", "4k_eqr_rect_bc_pan90", "4k_eqr_rect_bc_pitch90", "4k_rect_rect_bc_rot", "4k_eqd_eqd_bc_rot",
