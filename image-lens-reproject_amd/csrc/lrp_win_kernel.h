@@ -1101,7 +1101,13 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
     // wavefront measured 2-3 % faster there — equirect -> fisheye rotated 143 -> 139 us, rect -> rect 130.5 -> 128 —, four 5 % slower)
     if (P.batch_n > 1 && !(out_idx == 2 && in_mode == kInRect)) G = 1;
     const bool strip_forced = GeoRead && P.blocks_per_wave > 0;
-    while (!strip_forced && G > 1 && (long long)P.tiles_x * kWinWaves * ((row_blocks + G - 1) / G) < 8192) G >>= 1; // >= 2 rounds of wavefronts
+    // (a rectilinear source under a rectilinear / fisheye target: half of the blocks are corner blocks, the rest wait for
+    // gathers or edge rows — single blocks balance the launch: rect -> fisheye single launches 164 -> 154 us)
+    if (GeoRead && !strip_forced && in_mode == kInRect && P.big_windows == 0 && P.batch_n <= 1) G = 1;
+    // >= 2 rounds of wavefronts; the launches that read the geometry cache >= 4 (their wavefronts differ more in what a block
+    // costs them — nothing is computed, everything is waited for: pole face of the 8192^2 -> 2048^2 cubemap 107.5 -> 98.4 us)
+    const long long min_waves = GeoRead ? 16384 : 8192;
+    while (!strip_forced && G > 1 && (long long)P.tiles_x * kWinWaves * ((row_blocks + G - 1) / G) < min_waves) G >>= 1;
     P.blocks_per_wave = G;
     P.tiles_y = (row_blocks + G - 1) / G;
   }
