@@ -12,5 +12,7 @@ cp $f/kernel_trace_by_launch_shape.txt profiles/${r}_bench_kernel_trace_by_launc
 (cat $f/kbench_cubemap_faces.log; echo "# geometry cache off"; cat $f/kbench_cubemap_faces_geo0.log) > profiles/${r}_kbench_cubemap_faces.txt
 cp $f/sq_counters.txt profiles/${r}_sq_counters.txt
 cp $f/staged.log profiles/${r}_staged_pcie.txt
+cp $f/fov_sweep.log profiles/${r}_rect_eqr_fov_sweep.txt
+cp $f/tap_paths.log profiles/${r}_tap_paths_microbench.txt
 tail -3 $f/gpu_tests.log > profiles/${r}_gpu_tests_tail.txt
 echo "collected into profiles/${r}_*"

@@ -22,6 +22,8 @@ timeout 200 ./tools/kbench --sum --reps 24 --distinct 16 --channels 5 --post rec
 timeout 200 ./tools/kbench --sum --reps 20 --size 8192 --out-size 2048 --channels 3 --distinct 4 eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch > $out/kbench_cubemap_faces.log 2>&1
 timeout 200 ./tools/kbench --sum --reps 20 --size 8192 --out-size 2048 --channels 3 --distinct 4 --geo 0 eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch > $out/kbench_cubemap_faces_geo0.log 2>&1
 timeout 300 ./tools/staged_bench > $out/staged.log 2>&1
+(echo "# RGBA"; python3 tools/fov_sweep.py 4 2>&1 | grep focal; echo "# RGBAZ + tonemap"; python3 tools/fov_sweep.py 5 post 2>&1 | grep focal) > $out/fov_sweep.log
+timeout 200 tools/microbench/tap_paths > $out/tap_paths.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof_bench -- python3 $R/bench.py --no-cpu-baseline --no-staged > $R/$out/prof_bench.log 2>&1; echo "rocprof rc=$?"
 cat $R/$out/prof_bench/*/*kernel_stats.csv | cut -c1-200
