@@ -117,7 +117,8 @@ int lrp_debug_kernel(int choice);
 /* The other testing / A-B switches, by name: "kernel" (as lrp_debug_kernel), "xsep", "quad", "mirror_modes",
  * "win_edge", "win_split", "geo_cache" (0 / 1: a sharing or staging path of the tile / window kernels off / on — the bits
  * do not change), "batch_frames" (frames per wavefront of a batched launch, 0 = automatic),
- * "multi_fork" (side streams of lrp_reproject_multi_device, 0-5).  Sets the value for subsequent calls of all threads
+ * "multi_fork" (side streams of lrp_reproject_multi_device, 0-5), "geo_strip" (blocks per wavefront of a launch that reads the
+ * geometry cache, 0 = automatic), "geo_big" (0: no big-window variant for a rectilinear view rendered into a panorama).  Sets the value for subsequent calls of all threads
  * and returns the previous one; a value outside the switch's range only queries; an unknown name returns -1.  The
  * environment variables LRP_XSEP, LRP_QUAD, ... supply the initial values once, when the library is loaded. */
 int lrp_debug_set(const char *name, int value);
