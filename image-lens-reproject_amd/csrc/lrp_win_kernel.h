@@ -30,6 +30,9 @@ namespace lrp {
 //     increments and the immediates 0/16/32/48.
 // A block with a border / seam / NaN pixel, or a window larger than the per-wave LDS budget
 // (strong minification), takes sample_direct() per pass instead.
+#if defined(LRP_WAVE_STAMPS) // diagnostic builds (tools/wave_timeline.py): start / end (100 MHz wall clock) and hardware slot of every wavefront of a launch
+__device__ unsigned long long g_wave_stamps[3 * 65536];
+#endif
 #if defined(LRP_TIER_STATS) // diagnostic builds (tools/ablate.sh): blocks per tier (coefficients, raw taps, direct)
 __device__ unsigned g_tier_stats[8]; // coefficient, raw, direct, corner, beyond a row, beyond a column, split
 #endif
@@ -154,6 +157,9 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
 
   int tx, ty;
   if (!xcd_tile<kWinXcdBand>(P.tiles_x, P.tiles_y, tx, ty)) return; // whole workgroup
+#if defined(LRP_WAVE_STAMPS)
+  const unsigned long long stamp_start = wall_clock64();
+#endif
   // Alias pairs (LRP_WIN_ALIAS_PAIRS; mirrored strips of rectilinear -> equirectangular).  The reference has no
   // hemisphere test: the ray of panorama pixel (x + W/2, H-1-y) is the ray of (x, y) with x and z negated, and a
   // rectilinear projection divides by z — both pixels land on (nearly: different roundings) the same source
@@ -1024,6 +1030,14 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     if (last_frame) cur = nxt;
    }
   }
+#if defined(LRP_WAVE_STAMPS)
+  if (blockIdx.y == 0 && blockIdx.x < 65536u && (threadIdx.x & 63u) == 0) {
+    const unsigned hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_ID, XCC_ID
+    g_wave_stamps[3 * blockIdx.x] = stamp_start;
+    g_wave_stamps[3 * blockIdx.x + 1] = wall_clock64();
+    g_wave_stamps[3 * blockIdx.x + 2] = (unsigned long long)hw_id | ((unsigned long long)(xcc_id & 15u) << 32) | ((unsigned long long)(unsigned)G << 40) | ((unsigned long long)(blockIdx.x % 8) << 60);
+  }
+#endif
 }
 
 // The window kernel of one (output lens, source mode) cell for a mirror mode, or null where the mode does not exist
