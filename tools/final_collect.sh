@@ -4,7 +4,7 @@ set -euo pipefail
 R="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd "$R"
 f=gpurun_out/final; r=${1:-r04}
 cp $f/bench.json profiles/${r}_bench.json
-cat $f/prof_bench/*/*kernel_stats.csv > profiles/${r}_bench_kernel_stats.csv
+cat "$(ls -t $f/prof_bench/*/*kernel_stats.csv | head -1)" > profiles/${r}_bench_kernel_stats.csv # (the newest: gpurun merges the passes of a round into one directory)
 cp $f/kernel_trace_by_launch_shape.txt profiles/${r}_bench_kernel_trace_by_launch_shape.txt
 (echo "# single-frame launches, geometry cache on (default)"; cat $f/kbench_rgba_single.log; echo; echo "# single-frame launches, geometry cache off (every launch computes its coordinates)"; cat $f/kbench_rgba_single_geo0.log) > profiles/${r}_kbench_rgba_single.txt
 (echo "# 16-frame launches, default"; cat $f/kbench_rgba_batched.log; echo; echo "# 16-frame launches, geometry cache off"; cat $f/kbench_rgba_batched_geo0.log) > profiles/${r}_kbench_rgba_batched.txt
