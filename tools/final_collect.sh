@@ -14,5 +14,6 @@ cp $f/sq_counters.txt profiles/${r}_sq_counters.txt
 cp $f/staged.log profiles/${r}_staged_pcie.txt
 cp $f/fov_sweep.log profiles/${r}_rect_eqr_fov_sweep.txt
 cp $f/tap_paths.log profiles/${r}_tap_paths_microbench.txt
+[ -f $f/hbm_stream.log ] && cp $f/hbm_stream.log profiles/${r}_hbm_stream_microbench.txt
 tail -3 $f/gpu_tests.log > profiles/${r}_gpu_tests_tail.txt
 echo "collected into profiles/${r}_*"

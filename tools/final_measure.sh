@@ -24,6 +24,7 @@ timeout 200 ./tools/kbench --sum --reps 20 --size 8192 --out-size 2048 --channel
 timeout 300 ./tools/staged_bench > $out/staged.log 2>&1
 (echo "# RGBA"; python3 tools/fov_sweep.py 4 2>&1 | grep focal; echo "# RGBAZ + tonemap"; python3 tools/fov_sweep.py 5 post 2>&1 | grep focal) > $out/fov_sweep.log
 timeout 200 tools/microbench/tap_paths > $out/tap_paths.log 2>&1
+timeout 100 tools/microbench/hbm_stream > $out/hbm_stream.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof_bench -- python3 $R/bench.py --no-cpu-baseline --no-staged > $R/$out/prof_bench.log 2>&1; echo "rocprof rc=$?"
 cat $R/$out/prof_bench/*/*kernel_stats.csv | cut -c1-200
