@@ -98,6 +98,9 @@ template <int OutLens, int InMode, int QMode, int CH, bool Frames = false, bool 
 #ifndef LRP_WIN_CAP_BIG
 #define LRP_WIN_CAP_BIG 1280 // window slots of the big-window GeoRead variant: 20 KiB per wavefront, two wavefronts per SIMD
 #endif
+#ifndef LRP_WIN_CAP_BIG5
+#define LRP_WIN_CAP_BIG5 1200 // ... RGBAZ: 18.75 KiB, so that with the 1.25 KiB exchange buffer of its stores eight wavefronts fit a CU's 160 KiB (1280 slots: seven; rect -> equirect RGBAZ + tonemap 330 -> 318 us single, 313 -> 300 batched)
+#endif
 #ifndef LRP_WIN_MINWAVES_BIG
 #define LRP_WIN_MINWAVES_BIG 2
 #endif
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   // stages pass windows up to 128 texels wide.  tools/microbench/row_gather.hip: rows of that shape arrive at 7.7 TB/s by
   // LDS-DMA with 8 wavefronts per CU, a window each in flight; per-pixel gathers of the same bytes at 4.5 TB/s in this kernel.
   constexpr bool kBigWin = GeoRead && OutLens == kEquirect;
-  constexpr int kCap = kBigWin ? LRP_WIN_CAP_BIG : kWinCap; // 16-byte slots of this instantiation's window buffer
+  constexpr int kCap = kBigWin ? (CH == 5 ? LRP_WIN_CAP_BIG5 : LRP_WIN_CAP_BIG) : kWinCap; // 16-byte slots of this instantiation's window buffer
   constexpr int kMaxPassCols = kBigWin ? 128 : 64;          // widest pass window (texels): DMA instructions per window row = ceil(bw / 64)
   constexpr bool kGeoWrite = !GeoRead && !Frames && QMode == 0 && kWinWaves == 1; // (P.geo_mode == 1: the side output)
   const bool geo_write = kGeoWrite && (Pk.geo_mode == 1 || Pk.geo_mode == 3) && blockIdx.y == 0; // wave-uniform (3: the extremes only — the map is there; a batched launch: its first frame writes)
