@@ -182,6 +182,54 @@ def test_corner_classes_under_every_strip_length(lrp, oracle, torch_cuda, channe
         assert stats["fills"] >= 1 and stats["hits"] >= 7
 
 
+@pytest.mark.parametrize("chunk", range(6))
+def test_random_configurations_through_the_cache(lrp, oracle, torch_cuda, chunk):
+    """Randomised lens pairs, rotations, sizes and channel counts (the generators of test_gpu_random_lenses.py, one sample per
+    pixel): the launch that fills the entry, a single launch that reads it, a batch of five that reads it and — for a
+    rectilinear view into a panorama — the four-wavefront instantiation, all three samplers, against the live oracle."""
+    import test_gpu_random_lenses as rl
+
+    torch = torch_cuda
+    for k in range(8):
+        seed = 7000 + 8 * chunk + k
+        rng = np.random.default_rng(seed)
+        in_w, in_h = int(rng.integers(40, 400)), int(rng.integers(30, 300))
+        out_w, out_h = int(rng.integers(17, 330)), int(rng.integers(9, 250))
+        c = int(rng.choice([3, 4, 4, 5]))
+        lin, lout = rl.random_lens(lrp, rng, in_w, in_h), rl.random_lens(lrp, rng, out_w, out_h)
+        if k % 4 == 0:  # every fourth: the mapping of the big-window variant and the class bytes
+            lin, lout = lrp.LensInfo.rectilinear(float(rng.uniform(10.0, 90.0)), 36.0, in_w, in_h), lrp.LensInfo.equirectangular()
+        rot = rl.random_rotation(lrp, rng)
+        post = (1.25, 3.0) if k % 3 == 0 else None
+        src = cases.hash_noise(in_h, in_w, c, seed=seed, planted=bool(rng.integers(0, 2)))
+        d_in = torch.from_numpy(src).cuda()
+        img_in = lrp.Image(lin, in_w, in_h, c, d_in)
+
+        def render(interp, batch=0):
+            outs = [torch.full((out_h, out_w, c), -777.0, dtype=torch.float32, device="cuda") for _ in range(max(batch, 1))]
+            if batch:
+                lrp.reproject_batch([img_in] * batch, [lrp.Image(lout, out_w, out_h, c, o) for o in outs], 1, interp, rot, post=post)
+            else:
+                lrp.reproject(img_in, lrp.Image(lout, out_w, out_h, c, outs[0]), 1, interp, rot, post=post)
+            torch.cuda.synchronize()
+            return [o.cpu().numpy() for o in outs]
+
+        for interp in (2, 1, 0):
+            want = oracle.reproject(lin, src, lout, out_w, out_h, 1, interp, rot)
+            if post:
+                want = oracle.post_process(want, *post)
+            what = f"seed {seed}: {in_w}x{in_h}x{c} -> {out_w}x{out_h}, lens {lin.type}->{lout.type}, interp={interp}, post={post}"
+            cases.assert_same_bits(render(interp)[0], want, "first launch, " + what)
+            cases.assert_same_bits(render(interp)[0], want, "second launch, " + what)
+            for got in render(interp, batch=5):
+                cases.assert_same_bits(got, want, "batch of five, " + what)
+            if interp == 2 and k % 4 == 0:
+                prev = lrp.debug_set("geo_big", 0)
+                got = render(interp)[0]
+                lrp.debug_set("geo_big", prev)
+                cases.assert_same_bits(got, want, "geo_big 0, " + what)
+
+
 FRAMES = ["config0_512_eqr_rect_nn", "config2_4k_eqr_eqd_bl_rot", "4k_eqr_rect_bl", "4k_eqr_rect_nn", "config1_4k_eqd_rect_bc", "northstar_4k_eqr_rect_bc", "scaling_4k_eqr_eqd_bc_rot", "config3_4k_rgbaz_rect_eqr_bc_post",
           "config3_4k_rgbz_rect_eqr_bc_post", "config4_8k_rgb_face0", "config4_8k_rgb_face1", "config4_8k_rgb_face4",
           "4k_eqr_rect_bc_rot", "4k_eqr_rect_bc_pan90", "4k_eqr_rect_bc_pitch90", "4k_rect_rect_bc_rot", "4k_eqd_eqd_bc_rot",
