@@ -371,11 +371,13 @@ def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_
     torch.cuda.synchronize()
     s_avg, s_min = time_launches(torch, stream, single, 64)
     prev_geo = pkg.debug_set("geo_cache", 0)
-    for i in range(8):
-        single(i)
-    torch.cuda.synchronize()
-    u_avg, _u_min = time_launches(torch, stream, single, 32)
-    pkg.debug_set("geo_cache", prev_geo)
+    try:  # (the switch is process-wide: whatever happens in here, the launches after it run the default again)
+        for i in range(8):
+            single(i)
+        torch.cuda.synchronize()
+        u_avg, _u_min = time_launches(torch, stream, single, 32)
+    finally:
+        pkg.debug_set("geo_cache", prev_geo)
     # (inW*inH + outW*outH)*C*4 per launch that reads the source; a cubemap is six such launches
     launch_bytes = (size * size + out_size * out_size) * c * 4
     frame_bytes = launch_bytes * (len(faces) if faces else 1)

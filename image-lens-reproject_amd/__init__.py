@@ -208,7 +208,8 @@ def debug_kernel(choice=-1):
 
 def debug_set(name, value=-1):
     """lrp_debug_set: the named A/B switch ("xsep", "quad", "mirror_modes", "win_edge", "win_split", "geo_cache",
-    "batch_frames", "multi_fork", "geo_strip", "geo_big", "kernel"); returns the previous value, -1 only queries."""
+    "batch_frames", "multi_fork", "geo_strip", "geo_big", "geo_lists", "geo_fill_stream", "geo_fill_fused", "kernel"; "listed_launches" is a
+    counter); returns the previous value, -1 only queries."""
     prev = _native.load().lrp_debug_set(str(name).encode(), int(value))
     if prev < 0:
         raise ValueError(f"unknown debug switch {name!r}")

@@ -32,6 +32,8 @@ hipError_t launch_tile_nearest(const KParams &P, int out_idx, int in_mode, hipSt
 hipError_t launch_tile_bilinear(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
 hipError_t launch_tile_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
 hipError_t launch_win_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // (P.geo_mode == 2: the GeoRead kernels)
+hipError_t launch_geo_build_lists(int32_t *box, int out_w, int out_h, int alias_pairs, hipStream_t stream); // lrp_geo_lists.hip
+hipError_t launch_corner_fill(const KParams &P, hipStream_t stream);
 hipError_t launch_post_process(float *data, uint32_t n_pixels, int channels, float exposure, float reinhard,
                                hipStream_t stream);
 hipError_t launch_synth_fill(float *data, uint32_t n_elems, int channels, uint32_t seed, int depth_channel,
@@ -181,12 +183,13 @@ lrp::KParams make_params(const lrp_image *in, const lrp_image *out, int num_samp
 // initial values, once, when the library is loaded — nothing on a launch path calls getenv.
 //   kernel: 0 = pixel kernel, 1 = tile kernel everywhere, 2 (default) = tile kernel with the LDS-window kernel for
 //   bicubic, 3 = the same without its shared-coefficient tier and without any work sharing.  All HIP; there is no CPU path.
-enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobGeoBig, kKnobCount };
+enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobGeoBig, kKnobGeoLists, kKnobGeoFillStream, kKnobGeoFillFused, kKnobListedLaunches, kKnobCount };
 struct KnobSpec {
   const char *name, *env;
   int lo, hi, initial;
 };
 constexpr int kMaxSideStreams = 5;
+constexpr unsigned kMinWavesForFusedFill = 2048; // wavefronts a listed window launch must have to carry the corner runs itself
 const KnobSpec kKnobs[kKnobCount] = {
     {"kernel", "LRP_KERNEL", 0, 3, 2},
     {"xsep", "LRP_XSEP", 0, 1, 1},                  // column-separable source x tables
@@ -199,6 +202,10 @@ const KnobSpec kKnobs[kKnobCount] = {
     {"geo_cache", "LRP_GEO_CACHE", 0, 1, 1},        // geometry cache used by single launches (0: every launch computes)
     {"geo_strip", "LRP_GEO_STRIP", 0, lrp::kGeoStripRows, 0}, // blocks per wavefront of a launch that reads the geometry cache (0: automatic)
     {"geo_big", "LRP_GEO_BIG", 0, 1, 1},            // big-window variant of the kernels that read the geometry cache (a rectilinear view rendered into a panorama); 0: the four-wavefront instantiation
+    {"geo_lists", "LRP_GEO_LISTS", 0, 2, 1},        // rendering by block class from the lists of a geometry-cache entry (corner runs by the fill kernel, the window kernel over the work list): 0 never, 1 where at least 1/16 of the blocks are corner blocks, 2 whenever the lists are known
+    {"geo_fill_stream", "LRP_GEO_FILL_STREAM", 0, 1, 0}, // the fill kernel of a listed launch: 0 in front of the window kernel on the caller's stream, 1 beside it on a side stream of the device
+    {"geo_fill_fused", "LRP_GEO_FILL_FUSED", 0, 1, 1}, // the corner runs of a listed launch as a share per wavefront of the window kernel (0: always the fill kernel)
+    {"listed_launches", "LRP_LISTED_LAUNCHES_UNUSED", 0, 0, 0}, // a counter, not a switch: launches rendered by block class so far (set 0 to reset; tests, bench)
 };
 std::atomic<int> g_knobs[kKnobCount];
 const bool g_knobs_initialised = [] { // the one place that reads the environment
@@ -221,6 +228,54 @@ bool mirror_modes_enabled() { return knob(kKnobMirrorModes) != 0; }
 bool win_edge_enabled() { return knob(kKnobWinEdge) != 0; }
 bool win_split_enabled() { return knob(kKnobWinSplit) != 0; }
 bool xsep_enabled() { return knob(kKnobXsep) != 0; }
+
+// The fill kernel of a listed launch (lrp_geo_lists.hip).  In front of the window kernel on the caller's stream, or — knob
+// "geo_fill_stream" — beside it on a side stream of the device: the two write disjoint pixels, the window kernel holds
+// two to four wavefronts per SIMD and all of a CU's LDS, the fill kernel needs neither.  Fork / join by events, so the
+// caller's stream order is kept; not while that stream is being captured.
+struct FillFork {
+  std::mutex busy; // one fork / join being enqueued at a time per device (the events are re-recorded by every call)
+  hipStream_t side = nullptr;
+  hipEvent_t forked = nullptr, joined = nullptr;
+};
+std::mutex g_fill_fork_mutex;
+std::map<int, std::unique_ptr<FillFork>> g_fill_forks;
+FillFork *fill_fork(int device) {
+  std::lock_guard<std::mutex> lock(g_fill_fork_mutex);
+  std::unique_ptr<FillFork> &slot = g_fill_forks[device];
+  if (!slot) {
+    std::unique_ptr<FillFork> f(new FillFork);
+    if (hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&f->forked, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&f->joined, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    slot = std::move(f);
+  }
+  return slot.get();
+}
+hipError_t fill_corner_runs(const lrp::KParams &P, int device, hipStream_t stream) {
+  if (P.geo_n_runs == 0) return hipSuccess;
+  if (knob(kKnobGeoFillStream) != 0) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
+    FillFork *const f = cap == hipStreamCaptureStatusNone ? fill_fork(device) : nullptr;
+    if (f != nullptr) {
+      std::lock_guard<std::mutex> lock(f->busy);
+      if (hipEventRecord(f->forked, stream) == hipSuccess && hipStreamWaitEvent(f->side, f->forked, 0) == hipSuccess) {
+        const hipError_t e = lrp::launch_corner_fill(P, f->side);
+        // join, whatever happened: the caller's stream continues behind the side stream
+        if (hipEventRecord(f->joined, f->side) != hipSuccess || hipStreamWaitEvent(stream, f->joined, 0) != hipSuccess) {
+          (void)hipGetLastError();
+          (void)hipStreamSynchronize(f->side);
+        }
+        return e;
+      }
+      (void)hipGetLastError();
+    }
+  }
+  return lrp::launch_corner_fill(P, stream);
+}
 
 // n_batch > 0: `in` / `out` are arrays of n_batch images of one geometry (checked by the caller);
 // the tile / window kernels render them in launches of up to kMaxBatch frames, the per-pixel
@@ -254,6 +309,12 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     bool plain = false;
     e = lrp::get_output_tables(device, out_kind, P.out_lens, out->width, out->height, num_samples, stream, lease,
                                &P.col_tab, &P.row_tab, &plain, &symmetry);
+    if (e == hipErrorOutOfMemory) { // the geometry cache holds what it holds for speed only: give it back, once
+      (void)hipGetLastError();
+      lrp::geo_release_all();
+      e = lrp::get_output_tables(device, out_kind, P.out_lens, out->width, out->height, num_samples, stream, lease,
+                                 &P.col_tab, &P.row_tab, &plain, &symmetry);
+    }
     if (e == hipErrorOutOfMemory) {
       (void)hipGetLastError();
       tile = false; // no memory for the tables: per-pixel kernel
@@ -351,7 +412,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
       key.in_mode = im;
       key.out_w = out->width, key.out_h = out->height, key.in_w = in->width, key.in_h = in->height;
       key.has_rot = P.has_rot;
-      key.out_lens = P.out_lens, key.in_lens = P.in_lens;
+      key.out_lens = lrp::geo_canonical_lens(P.out_lens, out->lens.type), key.in_lens = lrp::geo_canonical_lens(P.in_lens, in->lens.type);
       if (P.has_rot) std::memcpy(key.rot, P.rot, sizeof(key.rot));
       lrp::geo_acquire(key, window, stream, &geo);
       if (geo.mode != 0) {
@@ -363,9 +424,33 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
         P.blocks_per_wave = knob(kKnobGeoStrip); // 0: the launcher decides
         P.rgbaz_runs = (out->lens.type == LRP_EQUIRECTANGULAR && in->lens.type == LRP_RECTILINEAR) ? 1 : 0;
         P.big_windows = knob(kKnobGeoBig) != 0 ? P.rgbaz_runs : 0;
+        // Rendering by block class (lrp_params.h "Block lists"): once the lists of the entry are known, the corner blocks
+        // — every pixel the one clamped corner texel — are written by the store-only fill kernel and the window kernel
+        // walks the work list, which holds no corner block.  Where corner blocks are rare the plain enumeration stays.
+        const int lists_knob = knob(kKnobGeoLists);
+        if (window && im == lrp::kInRect && geo.mode == 2 && geo.lists && lists_knob != 0 && geo.n_blocks != 0 &&
+            (lists_knob == 2 || (unsigned long long)geo.n_corner_blocks * 16u >= geo.n_blocks)) {
+          const uint8_t *const lists = reinterpret_cast<const uint8_t *>(geo.box) + lrp::geo_lists_offset(out->width, out->height);
+          P.geo_work = reinterpret_cast<const int32_t *>(lists + (size_t)lrp::kGeoListHeaderWords * 4);
+          P.geo_runs = reinterpret_cast<const uint32_t *>(P.geo_work + 2 * lrp::geo_work_capacity(out->width, out->height));
+          P.geo_n_work = geo.n_work;
+          P.geo_n_runs = geo.n_runs;
+          // the corner runs: a share per wavefront of the window launch where it has enough wavefronts to spread them over,
+          // else (few or no blocks to render: the frame is nearly all corners) the fill kernel at its own, full occupancy
+          if (knob(kKnobGeoFillFused) != 0 && geo.n_work >= kMinWavesForFusedFill && geo.n_runs != 0)
+            P.geo_fill_per_wave = (geo.n_runs * 16u + geo.n_work - 1) / geo.n_work;
+        }
       }
     }
+    const bool listed = P.geo_work != nullptr;
     auto launch = [&]() {
+      if (listed) { // the corner runs of this launch's frames, then (or meanwhile, or inside it) everything else
+        g_knobs[kKnobListedLaunches].fetch_add(1, std::memory_order_relaxed);
+        if (P.geo_fill_per_wave == 0) {
+          const hipError_t fe = fill_corner_runs(P, device, stream);
+          if (fe != hipSuccess) return fe;
+        }
+      }
       if (window) return lrp::launch_win_bicubic(P, oi, im, stream);
       if (interpolation == LRP_NEAREST) return lrp::launch_tile_nearest(P, oi, im, stream);
       if (interpolation == LRP_BILINEAR) return lrp::launch_tile_bilinear(P, oi, im, stream);
@@ -393,6 +478,16 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
         }
         e = launch();
       }
+    }
+    if (e == hipSuccess && window && im == lrp::kInRect && (geo.mode == 1 || geo.mode == 3) && geo.host_counts != nullptr && knob(kKnobGeoLists) != 0) {
+      // the launch above wrote the class bytes of the entry: its block lists are built behind it, and their header follows
+      // the records to the host (page-locked; read once the records' event has completed)
+      const uint8_t *const header = reinterpret_cast<const uint8_t *>(geo.box) + lrp::geo_lists_offset(out->width, out->height);
+      if (lrp::launch_geo_build_lists(geo.box, out->width, out->height, P.alias_pairs, stream) == hipSuccess &&
+          hipMemcpyAsync(geo.host_counts, header, (size_t)lrp::kGeoListHeaderWords * 4, hipMemcpyDeviceToHost, stream) == hipSuccess)
+        geo.lists_enqueued = true;
+      else
+        (void)hipGetLastError(); // (no lists for this entry: every launch enumerates the frame)
     }
     lrp::geo_launched(&geo, stream, e == hipSuccess);
   } else {
@@ -429,6 +524,11 @@ struct Buffer {
     if (bytes <= cap) return LRP_OK;
     release();
     hipError_t e = pinned_host ? hipHostMalloc(&ptr, bytes, hipHostMallocDefault) : hipMalloc(&ptr, bytes);
+    if (e == hipErrorOutOfMemory && !pinned_host) { // the geometry cache holds what it holds for speed only: give it back, once
+      (void)hipGetLastError();
+      lrp::geo_release_all();
+      e = hipMalloc(&ptr, bytes);
+    }
     if (e != hipSuccess) {
       ptr = nullptr;
       cap = 0;
@@ -711,6 +811,20 @@ int lrp_reproject_multi(const lrp_image *in, lrp_image *outs, int n_out, int num
     if (e != hipSuccess && result == LRP_OK) result = hip_fail(e, what);
     return e == hipSuccess && result == LRP_OK;
   };
+  // Where a participant's source lives: the first participant on a GPU holds the copy of that GPU (`holder[d] == d`), later
+  // occurrences of the same GPU read it in place.  The holders receive it in a binary tree: holder k (k-th distinct GPU)
+  // copies from holder k - 2^floor(log2 k) — after round r, 2^r GPUs hold the source and every one of them feeds another,
+  // each over its own xGMI link (seven copies out of one root share that root's links and its HBM read bandwidth: 805 MB x 7).
+  std::vector<int> holder((size_t)n_devices), holders;
+  for (int d = 0; d < n_devices; ++d) {
+    holder[(size_t)d] = d;
+    for (int e = 0; e < d; ++e)
+      if (devices[e] == devices[d]) {
+        holder[(size_t)d] = e;
+        break;
+      }
+    if (holder[(size_t)d] == d) holders.push_back(d);
+  }
   for (int d = 0; d < n_devices && result == LRP_OK; ++d) {
     MultiPeer &p = *peers[(size_t)d];
     if (!hip_ok(hipSetDevice(p.device), "hipSetDevice")) break;
@@ -722,32 +836,40 @@ int lrp_reproject_multi(const lrp_image *in, lrp_image *outs, int n_out, int num
       band(i, d, first, count);
       out_bytes += (size_t)count * (size_t)outs[i].width * (size_t)outs[i].channels * 4u;
     }
-    result = p.src.reserve(in_bytes);
+    if (holder[(size_t)d] == d) result = p.src.reserve(in_bytes);
     if (result == LRP_OK) result = p.out.reserve(out_bytes ? out_bytes : 4);
   }
-  // the source: host -> devices[0] once, then device to device
+  // the source: host -> devices[0] once, then device to device down the tree
   MultiPeer &root = *peers[0];
   if (result == LRP_OK && hip_ok(hipSetDevice(root.device), "hipSetDevice") &&
       hip_ok(hipMemcpyAsync(root.src.ptr, in->data, in_bytes, hipMemcpyHostToDevice, root.stream), "hipMemcpyAsync (source upload)"))
     hip_ok(hipEventRecord(root.source_ready, root.stream), "hipEventRecord");
-  for (int d = 1; d < n_devices && result == LRP_OK; ++d) {
-    MultiPeer &p = *peers[(size_t)d];
+  for (size_t k = 1; k < holders.size() && result == LRP_OK; ++k) {
+    size_t top = 1;
+    while (top * 2 <= k) top *= 2;
+    MultiPeer &p = *peers[(size_t)holders[k]], &from = *peers[(size_t)holders[k - top]];
     if (!hip_ok(hipSetDevice(p.device), "hipSetDevice")) break;
-    int can = p.device == root.device ? 1 : 0;
-    if (!can) {
-      (void)hipDeviceCanAccessPeer(&can, p.device, root.device);
-      if (can) {
-        const hipError_t e = hipDeviceEnablePeerAccess(root.device, 0);
-        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
-        (void)hipGetLastError();
-      }
+    int can = 0;
+    (void)hipDeviceCanAccessPeer(&can, p.device, from.device);
+    if (can) {
+      const hipError_t e = hipDeviceEnablePeerAccess(from.device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+      (void)hipGetLastError();
     }
     if (can) {
-      if (hip_ok(hipStreamWaitEvent(p.stream, root.source_ready, 0), "hipStreamWaitEvent"))
-        hip_ok(hipMemcpyPeerAsync(p.src.ptr, p.device, root.src.ptr, root.device, in_bytes, p.stream), "hipMemcpyPeerAsync");
+      if (hip_ok(hipStreamWaitEvent(p.stream, from.source_ready, 0), "hipStreamWaitEvent"))
+        hip_ok(hipMemcpyPeerAsync(p.src.ptr, p.device, from.src.ptr, from.device, in_bytes, p.stream), "hipMemcpyPeerAsync");
     } else {
       hip_ok(hipMemcpyAsync(p.src.ptr, in->data, in_bytes, hipMemcpyHostToDevice, p.stream), "hipMemcpyAsync (second upload)");
     }
+    if (result == LRP_OK) hip_ok(hipEventRecord(p.source_ready, p.stream), "hipEventRecord");
+  }
+  // later occurrences of a GPU wait for that GPU's copy
+  for (int d = 0; d < n_devices && result == LRP_OK; ++d) {
+    if (holder[(size_t)d] == d) continue;
+    MultiPeer &p = *peers[(size_t)d];
+    if (!hip_ok(hipSetDevice(p.device), "hipSetDevice")) break;
+    hip_ok(hipStreamWaitEvent(p.stream, peers[(size_t)holder[(size_t)d]]->source_ready, 0), "hipStreamWaitEvent");
   }
   // bands: render into the participant's buffer at the band's own row offset (the kernels address whole images),
   // download each band to its rows of the host output
@@ -761,7 +883,7 @@ int lrp_reproject_multi(const lrp_image *in, lrp_image *outs, int n_out, int num
       if (count == 0) continue;
       const size_t row_floats = (size_t)outs[i].width * (size_t)outs[i].channels;
       lrp_image din = *in, dout = outs[i];
-      din.data = (float *)p.src.ptr;
+      din.data = (float *)peers[(size_t)holder[(size_t)d]]->src.ptr;
       // a virtual whole image whose rows [first, first + count) are the buffer's [cursor, ...): only those are written
       dout.data = (float *)p.out.ptr + cursor - (size_t)first * row_floats;
       result = enqueue_reproject(&din, &dout, num_samples, interpolation, rotations ? rotations + 9 * i : nullptr, post, p.device,

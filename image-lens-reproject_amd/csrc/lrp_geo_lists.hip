@@ -1,0 +1,173 @@
+// lrp_geo_lists.hip — rendering a geometry by block class (lrp_params.h "Block lists"):
+//   geo_build_lists   once per geometry-cache entry, right behind the launch that wrote its class bytes: the WORK list
+//                     (every block that is not a corner block, in XCD-interleaved launch order) and the corner RUNS;
+//   corner_fill       the store-only kernel of the corner runs: no LDS window, no coordinates, no taps — every pixel of a
+//                     run is the one value sample_bicubic gives when all 16 taps clamp to the same corner texel
+//                     (src/reproject.cpp:109-148 with the clamped indices of :114-127 and weights of :130-131), finished
+//                     like any other pixel (:334-341, fused post_process :421-437), written as whole contiguous row
+//                     segments at 16 bytes per lane.
+// In a rectilinear view rendered into a panorama (BASELINE configs[3]) 37 % of the blocks are corner blocks; inside the
+// window kernel they occupy two-per-SIMD wave slots and leave as 320-byte pieces.
+#include <hip/hip_runtime.h>
+
+#include "lrp_corner_fill.h"
+
+namespace lrp {
+
+namespace {
+
+constexpr int kListThreads = 1024;
+constexpr int kListWaves = kListThreads / 64;
+
+// Exclusive prefix sum of `v` over the workgroup, in thread order; *total = the workgroup's sum.
+__device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t *s_wave, uint32_t *total) {
+  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+  uint32_t incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(incl, off);
+    if (lane >= off) incl += up;
+  }
+  __syncthreads(); // (s_wave may still be read by the previous call)
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kListWaves; ++w) {
+    const uint32_t t = s_wave[w];
+    before += w < wave ? t : 0u;
+    all += t;
+  }
+  *total = all;
+  return before + incl - v;
+}
+
+// Workgroups 0-7: the work sub-list of XCD k.  The window kernel's launch deals workgroup w to XCD w % 8 and maps it to
+// the block (j % blocks_x, (j / blocks_x) * 8 + w % 8), j = w / 8 (lrp_device.h xcd_tile, single rows of blocks); with
+// alias pairs (lrp_win_kernel.h) consecutive workgroups of an XCD take the two blocks that read the same source texels in
+// front of and behind the camera.  The sub-list is that sequence with the corner blocks removed, stored at 8 * position + k.
+// Workgroup 8: the corner runs, rows of blocks top to bottom, groups of kGeoRunBlocks columns left to right.
+__global__ __launch_bounds__(kListThreads) void geo_build_lists_kernel(const uint8_t *classes, uint32_t class_rows, int blocks_x,
+                                                                       int blocks_y, int alias_pairs, uint32_t *header,
+                                                                       int32_t *work, uint32_t *runs) {
+  __shared__ uint32_t s_wave[kListWaves];
+  const int k = (int)blockIdx.x;
+  const bool alias = alias_pairs != 0 && (blocks_x & 1) == 0;
+  if (k < kXcds) {
+    const int rows_k = blocks_y > k ? (blocks_y - k + kXcds - 1) / kXcds : 0;
+    const uint32_t n_items = (uint32_t)rows_k * (uint32_t)blocks_x;
+    uint32_t base = 0;
+    for (uint32_t i0 = 0; i0 < n_items; i0 += kListThreads) {
+      const uint32_t j = i0 + threadIdx.x;
+      int tx = 0, ty = 0;
+      bool listed = false;
+      if (j < n_items) {
+        const int row = (int)(j / (uint32_t)blocks_x);
+        tx = (int)(j - (uint32_t)row * (uint32_t)blocks_x);
+        ty = row * kXcds + k;
+        if (alias) {
+          const bool rev = (tx & 1) != 0;
+          tx = (tx >> 1) + (rev ? blocks_x >> 1 : 0);
+          ty = rev ? blocks_y - 1 - ty : ty;
+        }
+        listed = classes[(size_t)tx * class_rows + (uint32_t)ty] == 0;
+      }
+      uint32_t total;
+      const uint32_t pos = base + wg_exclusive_scan(listed ? 1u : 0u, s_wave, &total);
+      if (listed) {
+        work[2 * ((size_t)pos * kXcds + k)] = tx;
+        work[2 * ((size_t)pos * kXcds + k) + 1] = ty;
+      }
+      base += total;
+    }
+    if (threadIdx.x == 0) atomicMax(&header[0], base * kXcds); // entries of the interleaved list: 8 x the longest sub-list
+    return;
+  }
+  const int groups = (blocks_x + kGeoRunBlocks - 1) / kGeoRunBlocks;
+  const uint32_t n_items = (uint32_t)blocks_y * (uint32_t)groups;
+  uint32_t base = 0, corner_blocks = 0;
+  for (uint32_t i0 = 0; i0 < n_items; i0 += kListThreads) {
+    const uint32_t item = i0 + threadIdx.x;
+    const int row = (int)(item / (uint32_t)groups), c_first = (int)(item - (uint32_t)row * (uint32_t)groups) * kGeoRunBlocks;
+    uint8_t cls[kGeoRunBlocks];
+    uint32_t n_runs = 0;
+#pragma unroll
+    for (int c = 0; c < kGeoRunBlocks; ++c) {
+      const int tx = c_first + c;
+      cls[c] = (item < n_items && tx < blocks_x) ? classes[(size_t)tx * class_rows + (uint32_t)row] : (uint8_t)0;
+      if (cls[c] != 0 && (c == 0 || cls[c] != cls[c - 1])) ++n_runs;
+      corner_blocks += cls[c] != 0 ? 1u : 0u;
+    }
+    uint32_t total;
+    uint32_t pos = base + wg_exclusive_scan(n_runs, s_wave, &total);
+#pragma unroll
+    for (int c = 0; c < kGeoRunBlocks; ++c) {
+      if (cls[c] != 0 && (c == 0 || cls[c] != cls[c - 1])) {
+        int len = 1;
+        while (c + len < kGeoRunBlocks && cls[c + len] == cls[c]) ++len;
+        runs[4 * (size_t)pos] = (uint32_t)row;
+        runs[4 * (size_t)pos + 1] = (uint32_t)(c_first + c);
+        runs[4 * (size_t)pos + 2] = (uint32_t)len;
+        runs[4 * (size_t)pos + 3] = cls[c];
+        ++pos;
+      }
+    }
+    base += total;
+  }
+  uint32_t all_corner;
+  (void)wg_exclusive_scan(corner_blocks, s_wave, &all_corner);
+  if (threadIdx.x == 0) {
+    header[1] = base;
+    header[2] = all_corner;
+    header[3] = (uint32_t)blocks_x * (uint32_t)blocks_y;
+  }
+}
+
+// ---- the fill kernel -------------------------------------------------------------------------------------------------
+// One workgroup = one run of one frame (blockIdx.y = frame of a batched launch): 16 pixel rows of up to
+// kGeoRunBlocks * 16 pixels, four rows per wavefront (lrp_corner_fill.h).
+constexpr int kFillWaves = 4;
+
+template <int CH> __global__ __launch_bounds__(64 * kFillWaves) void corner_fill_kernel(const KParams P) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int frame = (int)blockIdx.y;
+  const float *const src = P.batch_n > 0 ? P.batch_src[frame] : P.src;
+  float *const dst = P.batch_n > 0 ? P.batch_dst[frame] : P.dst;
+  const uint32_t first = blockIdx.x * 16u + (uint32_t)wave * (16u / kFillWaves);
+  corner_fill_rows<CH>(P, src, dst, first, first + 16u / kFillWaves);
+}
+
+} // namespace
+
+// Behind the launch that wrote the class bytes of an entry, on its stream.  `box` = the entry's first box record.
+hipError_t launch_geo_build_lists(int32_t *box, int out_w, int out_h, int alias_pairs, hipStream_t stream) {
+  uint8_t *const base = reinterpret_cast<uint8_t *>(box);
+  uint32_t *const header = reinterpret_cast<uint32_t *>(base + geo_lists_offset(out_w, out_h));
+  int32_t *const work = reinterpret_cast<int32_t *>(header + kGeoListHeaderWords);
+  uint32_t *const runs = reinterpret_cast<uint32_t *>(work + 2 * geo_work_capacity(out_w, out_h));
+  hipError_t e = hipMemsetAsync(header, 0, (size_t)kGeoListHeaderWords * 4, stream);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(work, 0xFF, geo_work_capacity(out_w, out_h) * 8, stream); // (-1, -1): nothing here
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(geo_build_lists_kernel, dim3(kXcds + 1), dim3(kListThreads), 0, stream, base + geo_class_offset(out_w, out_h),
+                     geo_block_rows(out_h), (int)geo_block_cols(out_w), (int)geo_image_block_rows(out_h), alias_pairs, header, work, runs);
+  return hipGetLastError();
+}
+
+// The corner runs of P.geo_runs into P.dst (batched: into every P.batch_dst), P.channels in {3, 4, 5}, num_samples == 1.
+hipError_t launch_corner_fill(const KParams &P, hipStream_t stream) {
+  if (P.geo_n_runs == 0) return hipSuccess;
+  if (P.geo_runs == nullptr || P.num_samples != 1) return hipErrorInvalidValue;
+  const dim3 grid(P.geo_n_runs, (unsigned)(P.batch_n > 0 ? P.batch_n : 1)), block(64 * kFillWaves);
+  if (P.channels == 3)
+    hipLaunchKernelGGL(corner_fill_kernel<3>, grid, block, 0, stream, P);
+  else if (P.channels == 4)
+    hipLaunchKernelGGL(corner_fill_kernel<4>, grid, block, 0, stream, P);
+  else if (P.channels == 5)
+    hipLaunchKernelGGL(corner_fill_kernel<5>, grid, block, 0, stream, P);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+} // namespace lrp

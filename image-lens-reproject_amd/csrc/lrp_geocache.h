@@ -10,7 +10,8 @@
 // Loaded values are the stored ones, so the rendered bits do not change.
 //
 // Bounded (bytes per device, least recently used entries go first), opt-out through the C ABI
-// (lrp_geometry_cache_configure), freed by lrp_release_cached_tables.
+// (lrp_geometry_cache_configure), freed by lrp_release_cached_tables.  State is per device: a launch
+// thread of one GPU never takes a lock, waits for an event or synchronises on behalf of another GPU.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -21,7 +22,8 @@
 
 namespace lrp {
 
-// Everything the coordinates of src/reproject.cpp:323-324 depend on (compared byte for byte).
+// Everything the coordinates of src/reproject.cpp:323-324 depend on (compared byte for byte; the caller zeroes what the
+// lens type does not use, geo_canonical_lens).
 struct GeoKey {
   int32_t device;
   int32_t out_type, in_mode; // output lens (kRect / kEquidistant / kEquirect), input mode (kIn*)
@@ -30,6 +32,10 @@ struct GeoKey {
   LensP out_lens, in_lens;
   float rot[9];
 };
+// The lens parameters a geometry depends on: the members of the union that `lens_type` (include/lrp.h numbering) does not
+// have are indeterminate in a caller's struct (a C caller sets focal_length and nothing else) and are zeroed in the key.
+// Signed zeros and NaN payloads are kept apart: a miss is only slower, a false hit would change bits.
+LensP geo_canonical_lens(const LensP &lens, int lens_type);
 
 // What a launch does with the cache: P.geo_mode and the entry's pointers.
 struct GeoUse {
@@ -37,6 +43,13 @@ struct GeoUse {
   float *xy = nullptr;
   int32_t *box = nullptr;
   void *entry = nullptr; // opaque; pinned until geo_launched
+  // Block lists (lrp_params.h): a launch that writes the boxes (mode 1 with boxes, mode 3) also enqueues geo_build_lists
+  // and a copy of the list header into `host_counts` (page-locked) and says so in `lists_enqueued`; a reading launch finds
+  // `lists` set once that copy has been seen complete, with the counts of the header.
+  uint32_t *host_counts = nullptr;
+  bool lists_enqueued = false;
+  bool lists = false;
+  uint32_t n_work = 0, n_runs = 0, n_corner_blocks = 0, n_blocks = 0;
 };
 
 // Decides, for a launch that is about to be enqueued on `stream` (device already selected), whether it reads the
@@ -44,15 +57,17 @@ struct GeoUse {
 // per-block extremes too).  A reader on another stream than the entry's writer is made to wait for the writer
 // (hipStreamWaitEvent).  Never fails: any problem (no memory, a capturing stream, the cache switched off) is mode 0.
 void geo_acquire(const GeoKey &key, bool want_boxes, hipStream_t stream, GeoUse *use);
-// After the launch has been enqueued (ok) or has failed to: publishes a written entry, unpins.
+// After the launch has been enqueued (ok) or has failed to: publishes a written entry, marks the stream, unpins.
 void geo_launched(GeoUse *use, hipStream_t stream, bool ok);
 
 struct GeoStats {
   uint64_t bytes, max_bytes, entries, fills, hits, bypasses, evictions;
 };
 // max_bytes < 0 / min_sightings < 1: keep the current value.  max_bytes == 0 switches the cache off (and frees it).
+// max_bytes == -2: back to the default cap (min(4 GiB, 2 % of the device's memory), at least two entries of the largest
+// geometry seen on that device).
 void geo_configure(long long max_bytes, int min_sightings);
 void geo_stats(GeoStats *out);
-void geo_release_all(); // synchronises the devices that hold entries, frees everything unpinned
+void geo_release_all(); // waits for the launches that touched the entries (their events), frees everything unpinned
 
 } // namespace lrp

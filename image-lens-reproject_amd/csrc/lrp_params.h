@@ -97,17 +97,41 @@ struct KParams {
   int32_t *geo_box;    // window kernel: [block rows][blocks_x][8] (geo_layout below)
   int32_t big_windows; // GeoRead window kernel: the big-window variant (20 KiB of LDS per wavefront, two wavefronts per SIMD) where it is instantiated
   int32_t rgbaz_runs;  // GeoRead window kernel: a rectilinear view rendered into a panorama — the big-window variant; RGBAZ: every block leaves as 16-byte chunks (what the compute instantiations of that mapping do at compile time)
+  // Block lists of a geometry-cache entry (GeoLists below, lrp_geo_lists.hip).  geo_work != null: a GeoRead window launch
+  // walks the WORK list — workgroup i renders block geo_work[i] = (column, row) of 16 x 16 blocks, or exits on a -1 —
+  // instead of enumerating the frame; the corner blocks, which are not on it, are written by the fill kernel from geo_runs.
+  const int32_t *geo_work;   // [geo_n_work][2]
+  const uint32_t *geo_runs;  // [geo_n_runs][4]: block row, first block column, blocks (<= kGeoRunBlocks), corner class 1-4
+  uint32_t geo_n_work, geo_n_runs;
+  uint32_t geo_fill_per_wave; // listed window launch: row segments of the corner runs every wavefront writes when it is done (0: the fill kernel writes them)
 };
 
 // A geometry-cache entry (num_samples == 1, whole images): the coordinate map and, for the window kernel, per 16 x 16
 // block (block row * blocks_x + block column) 8 words — lo_x, hi_x, lo_y / hi_y of passes 0-1, lo_y / hi_y of passes 2-3
 // (float bits of the wave-wide extremes of the block's coordinates), flags (bit 0 / 1: the taps of every pixel are
 // consecutive in x / y, bit 2: a window was planned from these), 0.
+inline __host__ __device__ uint32_t geo_block_cols(int out_w) { return (uint32_t)(out_w + 15) / 16; }
 constexpr int kGeoStripRows = 16; // block rows are allocated in multiples of the longest strip a GeoRead launch may walk
 struct GeoLayout {
-  size_t xy_bytes, box_bytes;
-  size_t bytes() const { return xy_bytes + box_bytes; }
+  size_t xy_bytes, box_bytes, list_bytes;
+  size_t bytes() const { return xy_bytes + box_bytes + list_bytes; }
 };
+// Block lists, behind the class bytes (built once per entry by geo_build_lists, lrp_geo_lists.hip, from the class bytes):
+//   header  kGeoListHeaderWords words: [0] work entries, [1] runs, [2] corner blocks, [3] blocks of the image
+//   work    pairs (block column, block row) of every block that is NOT a corner block, in the order the window kernel's
+//           launch would reach them: entry i goes to workgroup i, i.e. to XCD i % 8, and the entries of one XCD are its
+//           rows of blocks (row % 8 == XCD) in raster order with the corner blocks taken out (alias pairs stay neighbours);
+//           sub-lists shorter than the longest end in (-1, -1).  Dense and cost-uniform: no wave slot is spent on stores only.
+//   runs    maximal runs of horizontally adjacent corner blocks of one class inside an aligned group of kGeoRunBlocks
+//           block columns: (block row, first block column, blocks, class).  Every pixel of a run is the same value
+//           (the clamped corner texel, src/reproject.cpp:114-131), so a run is 16 contiguous row segments of that value.
+constexpr int kGeoListHeaderWords = 16;
+constexpr int kGeoRunBlocks = 16;
+inline __host__ __device__ uint32_t geo_image_block_rows(int out_h) { return (uint32_t)(out_h + 15) / 16; }
+inline __host__ __device__ size_t geo_work_capacity(int out_w, int out_h) { // entries (pairs)
+  return (size_t)kXcds * ((geo_image_block_rows(out_h) + kXcds - 1) / kXcds) * geo_block_cols(out_w);
+}
+inline __host__ __device__ size_t geo_run_capacity(int out_w, int out_h) { return (size_t)geo_image_block_rows(out_h) * geo_block_cols(out_w); }
 // Element (float2) of output pixel (x, y) in the coordinate map: row-major.  (A map stored in 16 x 16 tiles — 2 KiB contiguous
 // bytes per block of the window kernel instead of 16 row segments of 128 bytes — measured the same for the window kernels
 // and 2-3 % slower for the tile kernels: profiles/r04_experiments_ab.txt.)
@@ -121,16 +145,19 @@ inline __host__ __device__ uint32_t geo_block_rows(int out_h) {
   const uint32_t by = (uint32_t)(out_h + 15) / 16;
   return (by + kGeoStripRows - 1) / kGeoStripRows * kGeoStripRows;
 }
-inline __host__ __device__ uint32_t geo_block_cols(int out_w) { return (uint32_t)(out_w + 15) / 16; }
 inline __host__ __device__ size_t geo_class_offset(int out_w, int out_h) { // bytes from the first box record to the first class byte
   return (size_t)geo_block_cols(out_w) * geo_block_rows(out_h) * 32;
 }
+inline __host__ __device__ size_t geo_lists_offset(int out_w, int out_h) { // bytes from the first box record to the list header
+  const size_t blocks = (size_t)geo_block_cols(out_w) * geo_block_rows(out_h);
+  return (blocks * 32 + blocks + 255) & ~(size_t)255;
+}
 inline GeoLayout geo_layout(int out_w, int out_h, bool with_boxes) {
   GeoLayout L{};
-  L.xy_bytes = (size_t)out_w * (size_t)out_h * 8;
+  L.xy_bytes = ((size_t)out_w * (size_t)out_h * 8 + 255) & ~(size_t)255; // (the records and lists behind the map start on a 256-byte boundary)
   if (with_boxes) {
-    const size_t blocks = (size_t)geo_block_cols(out_w) * geo_block_rows(out_h);
-    L.box_bytes = blocks * 32 + ((blocks + 15) & ~(size_t)15);
+    L.box_bytes = geo_lists_offset(out_w, out_h);
+    L.list_bytes = (size_t)kGeoListHeaderWords * 4 + geo_work_capacity(out_w, out_h) * 8 + geo_run_capacity(out_w, out_h) * 16;
   }
   return L;
 }

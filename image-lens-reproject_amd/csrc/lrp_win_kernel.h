@@ -2,6 +2,7 @@
 #pragma once
 
 #include "lrp_kernel_common.h"
+#include "lrp_corner_fill.h"
 #include "lrp_tile_kernel.h" // TileKernelFn
 #include "lrp_win_plan.h"
 #include "lrp_win_tiers.h"
@@ -158,8 +159,43 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   constexpr int kPlanes = 3;
   __shared__ float4 s_win[kWinWaves][kCap];
 
+  // A listed launch may also hand every wavefront a share of the corner runs (Pk.geo_fill_per_wave row segments each,
+  // lrp_corner_fill.h): a few store instructions at the very end of its life, when nothing else of it is live and nothing
+  // waits for them — the stores of the out-of-view part of the frame then overlap the window round trips of the in-view
+  // part inside ONE launch (as a kernel of its own in front of this one the fill costs its whole duration, beside it on a
+  // second stream the fork / join costs more than it hides).
+  // (compiled into the instantiations of the rectilinear source only — the source whose views leave most of a wider target
+  // out of view; in the others, the headline's among them, the extra scalar state costs 7-10 spilled SGPRs for nothing)
+  constexpr bool kListable = GeoRead && InMode == kInRect;
+  auto fill_share = [&]() {
+    if constexpr (kListable) {
+      const uint32_t per_wave = Pk.geo_fill_per_wave;
+      if (per_wave != 0) {
+        const uint32_t total = Pk.geo_n_runs * 16u, s0 = blockIdx.x * per_wave;
+        if (s0 < total)
+          for (int f = 0; f < n_frames; ++f) corner_fill_rows<CH>(Pk, frame_src(f), frame_dst(f), s0, min(s0 + per_wave, total));
+      }
+    }
+  };
   int tx, ty;
-  if (!xcd_tile<kWinXcdBand>(P.tiles_x, P.tiles_y, tx, ty)) return; // whole workgroup
+  // Listed launches (GeoRead, P.geo_work: lrp_params.h "Block lists"): workgroup i renders block geo_work[i] — the blocks of
+  // the frame that are not corner blocks, already in XCD-interleaved order with alias pairs next to each other; the corner
+  // blocks are written by the fill kernel (lrp_geo_lists.hip).  One block per wavefront.
+  bool listed = false;
+  if constexpr (kListable) listed = Pk.geo_work != nullptr;
+  if (listed) {
+    typedef const int32_t __attribute__((address_space(4))) *ScalarI;
+    const uintptr_t base = reinterpret_cast<uintptr_t>(Pk.geo_work);
+    const uint64_t addr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32 |
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base)) + (uint64_t)blockIdx.x * 8u;
+    const ScalarI e = reinterpret_cast<ScalarI>(addr);
+    tx = e[0];
+    ty = e[1];
+    if (tx < 0) { // the end of a shorter sub-list
+      fill_share();
+      return;
+    }
+  } else if (!xcd_tile<kWinXcdBand>(P.tiles_x, P.tiles_y, tx, ty)) return; // whole workgroup
 #if defined(LRP_WAVE_STAMPS)
   const unsigned long long stamp_start = wall_clock64();
 #endif
@@ -178,7 +214,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   constexpr bool kAliasPairs = LRP_WIN_ALIAS_PAIRS != 0 && (OutLens == kEquirect || GeoRead) && InMode == kInRect && kWinWaves == 1;
   int g_flip = 0;        // mirrored strips: the mirror image rendered by loop iteration g is g ^ g_flip
   bool g_reverse = false; // plain strips: iteration g renders block G-1-g
-  if (kAliasPairs && P.alias_pairs != 0) {
+  if (kAliasPairs && P.alias_pairs != 0 && !listed) {
     if constexpr (QMode == 1) {
       g_flip = (tx & 1) ? 3 : 0;
       tx = (tx & 1) ? P.tiles_x - 1 - (tx >> 1) : (tx >> 1);
@@ -526,7 +562,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   constexpr bool kGeoClasses = GeoRead && !Loop && LRP_WIN_CORNER != 0 && (LRP_GEO_CLASSES == 1 || (LRP_GEO_CLASSES == 2 && kBigWin));
   uint32_t strip_classes = 0;
   if constexpr (kGeoClasses) {
-    if (Gs <= 4 && (Gs & (Gs - 1)) == 0) {
+    if (Gs <= 4 && (Gs & (Gs - 1)) == 0 && !listed) { // (a listed block is not a corner block)
       typedef const uint32_t __attribute__((address_space(4))) *ScalarU;
       const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)tx * geo_block_rows(P.out_h) + (uint32_t)(ty * Gs)));
       const uintptr_t base = reinterpret_cast<uintptr_t>(geo_classes());
@@ -1033,6 +1069,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     if (last_frame) cur = nxt;
    }
   }
+  fill_share();
 #if defined(LRP_WAVE_STAMPS)
   if (blockIdx.y == 0 && blockIdx.x < 65536u && (threadIdx.x & 63u) == 0) {
     const unsigned hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_ID, XCC_ID
@@ -1125,6 +1162,8 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
     // costs them — nothing is computed, everything is waited for: pole face of the 8192^2 -> 2048^2 cubemap 107.5 -> 98.4 us)
     const long long min_waves = GeoRead ? 16384 : 8192;
     while (!strip_forced && G > 1 && (long long)P.tiles_x * kWinWaves * ((row_blocks + G - 1) / G) < min_waves) G >>= 1;
+    if (GeoRead && P.geo_work != nullptr && in_mode != kInRect) return hipErrorInvalidValue; // (lists: the rectilinear source's instantiations)
+    if (GeoRead && P.geo_work != nullptr) G = 1; // a listed launch: one block per wavefront, the blocks of the work list only
     P.blocks_per_wave = G;
     P.tiles_y = (row_blocks + G - 1) / G;
   }
@@ -1152,7 +1191,13 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
   else
     fn = P.frames_per_wave > 1 ? WinKernelTable<QMode, CH, true>::get(out_idx, in_mode) : WinKernelTable<QMode, CH, false>::get(out_idx, in_mode);
   if (!fn) return hipErrorInvalidValue; // (the host never asks for a mode outside its cells)
-  hipLaunchKernelGGL(fn, dim3((unsigned)(kXcds * xcd_rows(P.tiles_y, kWinXcdBand) * P.tiles_x), (unsigned)groups), dim3(kWinThreads), 0, stream, P);
+  unsigned grid_x = (unsigned)(kXcds * xcd_rows(P.tiles_y, kWinXcdBand) * P.tiles_x);
+  if (GeoRead && P.geo_work != nullptr) {
+    if (kWinWaves != 1) return hipErrorInvalidValue; // (the work list names blocks, one per workgroup)
+    if (P.geo_n_work == 0) return hipSuccess;       // every block is a corner block
+    grid_x = P.geo_n_work;
+  }
+  hipLaunchKernelGGL(fn, dim3(grid_x, (unsigned)groups), dim3(kWinThreads), 0, stream, P);
   return hipGetLastError();
 }
 

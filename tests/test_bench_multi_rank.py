@@ -78,6 +78,21 @@ def test_weak_scaling_mode_and_uneven_shards(lrp, torch_cuda, tmp_path):
     assert len(sums_odd["checksums"]) == 25 and sums_odd["checksums"][:BATCH] == sums["checksums"][:BATCH]
 
 
+@pytest.mark.gpu
+def test_four_ranks_share_one_gpu_with_uneven_shards(lrp, torch_cuda, tmp_path):
+    """More ranks than the two of the tests above, uneven blocks (42 images over 4 ranks: 11 + 11 + 11 + 9): the same per-image
+    checksums as one rank, one entry per rank in every per-rank list.  Four, not eight: a GPU box admits at most six
+    processes on its card (this test's parent is one of them); the world-size-8 sharding runs over gloo on the CPU
+    (tests/test_sharding_gloo.py)."""
+    one, sums1 = run_bench(1, tmp_path, extra=("--batch", "42"))
+    four, sums4 = run_bench(4, tmp_path, extra=("--batch", "42"))
+    assert four["n_gpus"] == 4 and four["config"]["images_per_gpu_per_step"] == 11
+    assert len(sums4["checksums"]) == 42 and sums4["checksums"] == sums1["checksums"]
+    assert one["outputs_digest"] == four["outputs_digest"]
+    assert len(four["per_rank_elapsed_s"]) == 4 and len(four["per_rank_device_busy_s"]) == 4
+    assert abs(max(four["per_rank_elapsed_s"]) - four["timed_region_s"]) < 1e-9
+
+
 def test_gpus_flag_must_match_the_launcher():
     """`--gpus 2` inside a 1-rank launch is an error with the torchrun command line, not a silent 1-GPU run."""
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")

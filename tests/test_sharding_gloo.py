@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the N > 1 path of bench.py — static image
+"""CPU, world_size 2 and 8 over gloo: the N > 1 path of bench.py — static image
 sharding with no data-path collective, and the max-over-ranks timing reduce."""
 import importlib
 import os
@@ -55,3 +55,26 @@ def test_two_ranks_gloo():
         flat = [i for part in gathered for i in part]
         assert flat == list(range(n_items))
         assert t == 2.0  # max over ranks of (1.0, 2.0)
+
+
+def test_eight_ranks_gloo_uneven_shards():
+    """The world size the driver's scaling run ends at (8 GPUs): 8 gloo ranks, a batch that does not divide (40 images:
+    blocks of 5) and one that leaves the last ranks short (43: 6 x 7 + 1 + 0): the blocks partition the batch in order,
+    and the whole-job time is the slowest rank's."""
+    world = 8
+    for n_items in (40, 43):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = 31500 + (os.getpid() + n_items) % 2000
+        procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        results = [q.get(timeout=300) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        assert sorted(r for r, _g, _t in results) == list(range(world))
+        for rank, gathered, t in results:
+            assert [i for part in gathered for i in part] == list(range(n_items))
+            assert max(len(part) for part in gathered) == -(-n_items // world)
+            assert t == 8.0  # max over ranks of 1.0 .. 8.0
