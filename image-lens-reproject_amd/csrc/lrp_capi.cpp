@@ -183,12 +183,16 @@ lrp::KParams make_params(const lrp_image *in, const lrp_image *out, int num_samp
 // initial values, once, when the library is loaded — nothing on a launch path calls getenv.
 //   kernel: 0 = pixel kernel, 1 = tile kernel everywhere, 2 (default) = tile kernel with the LDS-window kernel for
 //   bicubic, 3 = the same without its shared-coefficient tier and without any work sharing.  All HIP; there is no CPU path.
-enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobGeoBig, kKnobGeoLists, kKnobGeoFillStream, kKnobGeoFillFused, kKnobListedLaunches, kKnobCount };
+enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobGeoBig, kKnobGeoLists, kKnobGeoFillStream, kKnobGeoFillFused, kKnobMultiMerge, kKnobListedLaunches, kKnobMergedLaunches, kKnobCount };
 struct KnobSpec {
   const char *name, *env;
   int lo, hi, initial;
 };
 constexpr int kMaxSideStreams = 5;
+// Listed launches render one block per wavefront: where the blocks that remain are mostly in view (BASELINE configs[3]: 37 % corner
+// blocks) the strips of the enumerating launch win by 2-7 % (their wavefronts fetch the next block's record under the current
+// block); from about half a frame of corner blocks on the listed launch wins (rect -> fisheye 2-3 %, narrower views 10-40 %).
+constexpr unsigned kListedCornerPercent = 45;
 constexpr unsigned kMinWavesForFusedFill = 2048; // wavefronts a listed window launch must have to carry the corner runs itself
 const KnobSpec kKnobs[kKnobCount] = {
     {"kernel", "LRP_KERNEL", 0, 3, 2},
@@ -202,10 +206,12 @@ const KnobSpec kKnobs[kKnobCount] = {
     {"geo_cache", "LRP_GEO_CACHE", 0, 1, 1},        // geometry cache used by single launches (0: every launch computes)
     {"geo_strip", "LRP_GEO_STRIP", 0, lrp::kGeoStripRows, 0}, // blocks per wavefront of a launch that reads the geometry cache (0: automatic)
     {"geo_big", "LRP_GEO_BIG", 0, 1, 1},            // big-window variant of the kernels that read the geometry cache (a rectilinear view rendered into a panorama); 0: the four-wavefront instantiation
-    {"geo_lists", "LRP_GEO_LISTS", 0, 2, 1},        // rendering by block class from the lists of a geometry-cache entry (corner runs by the fill kernel, the window kernel over the work list): 0 never, 1 where at least 1/16 of the blocks are corner blocks, 2 whenever the lists are known
+    {"geo_lists", "LRP_GEO_LISTS", 0, 2, 1},        // rendering by block class from the lists of a geometry-cache entry (corner runs by the fill kernel / a share per wavefront, the window kernel over the work list): 0 never, 1 where at least 45 % of the blocks are corner blocks, 2 whenever the lists are known
     {"geo_fill_stream", "LRP_GEO_FILL_STREAM", 0, 1, 0}, // the fill kernel of a listed launch: 0 in front of the window kernel on the caller's stream, 1 beside it on a side stream of the device
     {"geo_fill_fused", "LRP_GEO_FILL_FUSED", 0, 1, 1}, // the corner runs of a listed launch as a share per wavefront of the window kernel (0: always the fill kernel)
+    {"multi_merge", "LRP_MULTI_MERGE", 0, 1, 1},     // lrp_reproject_multi_device: the outputs whose geometry-cache entries exist in ONE launch (blockIdx.z = output); 0: a launch per output
     {"listed_launches", "LRP_LISTED_LAUNCHES_UNUSED", 0, 0, 0}, // a counter, not a switch: launches rendered by block class so far (set 0 to reset; tests, bench)
+    {"merged_launches", "LRP_MERGED_LAUNCHES_UNUSED", 0, 0, 0}, // a counter: multi-output launches so far
 };
 std::atomic<int> g_knobs[kKnobCount];
 const bool g_knobs_initialised = [] { // the one place that reads the environment
@@ -283,9 +289,18 @@ hipError_t fill_corner_runs(const lrp::KParams &P, int device, hipStream_t strea
 // row_count > 0: only output rows [row_first, row_first + row_count) are rendered (the rows of the reference
 // loop are independent, src/reproject.cpp:284); the kernels that share work between mirrored rows need the
 // whole image and are not used for a band.
+// merge != null (lrp_reproject_multi_device): when this output would be rendered by a window launch that READS a
+// geometry-cache entry, nothing is launched: the launch is described in *merge and the caller renders several such outputs
+// of one source with ONE launch (lrp_params.h face_n).  Anything else is launched as usual and merge->ready stays false.
+struct MergeCandidate {
+  bool ready = false;
+  lrp::KParams P;
+  lrp::GeoKey key;
+  int out_idx = 0, in_mode = 0;
+};
 int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int interpolation,
                       const float *rotation, const lrp_post *post, int device, hipStream_t stream, int n_batch = 0,
-                      int row_first = 0, int row_count = 0) {
+                      int row_first = 0, int row_count = 0, MergeCandidate *merge = nullptr) {
   if (num_samples <= 0) return LRP_OK; // reference loop body never runs: output untouched
   lrp::KParams P = make_params(in, out, num_samples, rotation, post);
   const bool band = row_count > 0 && !(row_first == 0 && row_count == out->height);
@@ -414,6 +429,15 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
       key.has_rot = P.has_rot;
       key.out_lens = lrp::geo_canonical_lens(P.out_lens, out->lens.type), key.in_lens = lrp::geo_canonical_lens(P.in_lens, in->lens.type);
       if (P.has_rot) std::memcpy(key.rot, P.rot, sizeof(key.rot));
+      if (merge != nullptr && window && n_batch <= 0 && knob(kKnobMultiMerge) != 0 && lrp::geo_peek(key, true)) {
+        merge->ready = true;
+        merge->P = P;
+        merge->P.col_tab = merge->P.row_tab = merge->P.xsep_tab = nullptr; // (the kernels that read the cache use no table; the lease ends here)
+        merge->key = key;
+        merge->out_idx = oi;
+        merge->in_mode = im;
+        return LRP_OK;
+      }
       lrp::geo_acquire(key, window, stream, &geo);
       if (geo.mode != 0) {
         P.geo_mode = geo.mode;
@@ -429,7 +453,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
         // walks the work list, which holds no corner block.  Where corner blocks are rare the plain enumeration stays.
         const int lists_knob = knob(kKnobGeoLists);
         if (window && im == lrp::kInRect && geo.mode == 2 && geo.lists && lists_knob != 0 && geo.n_blocks != 0 &&
-            (lists_knob == 2 || (unsigned long long)geo.n_corner_blocks * 16u >= geo.n_blocks)) {
+            (lists_knob == 2 || (unsigned long long)geo.n_corner_blocks * 100u >= (unsigned long long)geo.n_blocks * kListedCornerPercent)) {
           const uint8_t *const lists = reinterpret_cast<const uint8_t *>(geo.box) + lrp::geo_lists_offset(out->width, out->height);
           P.geo_work = reinterpret_cast<const int32_t *>(lists + (size_t)lrp::kGeoListHeaderWords * 4);
           P.geo_runs = reinterpret_cast<const uint32_t *>(P.geo_work + 2 * lrp::geo_work_capacity(out->width, out->height));
@@ -437,8 +461,15 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
           P.geo_n_runs = geo.n_runs;
           // the corner runs: a share per wavefront of the window launch where it has enough wavefronts to spread them over,
           // else (few or no blocks to render: the frame is nearly all corners) the fill kernel at its own, full occupancy
-          if (knob(kKnobGeoFillFused) != 0 && geo.n_work >= kMinWavesForFusedFill && geo.n_runs != 0)
-            P.geo_fill_per_wave = (geo.n_runs * 16u + geo.n_work - 1) / geo.n_work;
+          if (knob(kKnobGeoFillFused) != 0 && geo.n_work >= kMinWavesForFusedFill && geo.n_runs != 0) {
+            // every stride-th wavefront (odd stride: all XCDs) writes at least one whole run (16 row segments)
+            const unsigned long long segs = (unsigned long long)geo.n_runs * 16u;
+            unsigned stride = (unsigned)std::max<unsigned long long>(1, 16ull * geo.n_work / segs) | 1u;
+            stride = std::min(stride, std::max(1u, geo.n_work / 1024u) | 1u); // (at least ~1024 filling wavefronts)
+            const unsigned fillers = (geo.n_work + stride - 1) / stride;
+            P.geo_fill_stride = stride;
+            P.geo_fill_per_wave = (unsigned)((segs + fillers - 1) / fillers);
+          }
         }
       }
     }
@@ -686,6 +717,53 @@ MultiFork *multi_fork(int device) { // null if the streams / events cannot be cr
 // Side streams lrp_reproject_multi_device deals its launches over besides the caller's (lrp_debug_set("multi_fork", n);
 // 0 keeps every launch on the caller's stream; default 1 — measured best, 588 -> 509 us per 8192^2 -> 6 x 2048^2 cubemap; 2-3: 522, 5: 549).
 int multi_fork_lanes() { return knob(kKnobMultiFork); }
+
+// One launch for the outputs group[0 .. n_group) of `in` (all described by enqueue_reproject as reading launches of one
+// shape).  An output whose entry has gone or changed hands in the meantime is rendered by a launch of its own.
+int enqueue_merged_outputs(const std::vector<MergeCandidate> &cand, lrp_image *outs, const int *group, int n_group, const lrp_image *in,
+                           int num_samples, int interpolation, const float *rotations, const lrp_post *post, int device, hipStream_t stream) {
+  lrp::KParams P = cand[(size_t)group[0]].P;
+  const int oi = cand[(size_t)group[0]].out_idx, im = cand[(size_t)group[0]].in_mode;
+  lrp::GeoUse uses[lrp::kMaxFaces];
+  int merged[lrp::kMaxFaces], n_merged = 0, result = LRP_OK;
+  for (int k = 0; k < n_group && result == LRP_OK; ++k) {
+    const int i = group[k];
+    lrp::GeoUse use;
+    lrp::geo_acquire(cand[(size_t)i].key, true, stream, &use);
+    if (use.mode == 2) {
+      uses[n_merged] = use;
+      merged[n_merged++] = i;
+      continue;
+    }
+    lrp::geo_launched(&use, stream, false); // (a claim this path will not honour: given up) ...
+    result = enqueue_reproject(in, &outs[i], num_samples, interpolation, rotations ? rotations + 9 * i : nullptr, post, device, stream); // ... the usual way
+  }
+  if (n_merged == 0) return result;
+  hipError_t e = hipSuccess;
+  if (result == LRP_OK) {
+    P.geo_mode = 2;
+    P.win_mode = 0;
+    P.quad = 0;
+    P.alias_pairs = 0; // (per-geometry: the faces differ in their rotations)
+    P.blocks_per_wave = knob(kKnobGeoStrip);
+    P.rgbaz_runs = (outs[merged[0]].lens.type == LRP_EQUIRECTANGULAR && in->lens.type == LRP_RECTILINEAR) ? 1 : 0;
+    P.big_windows = knob(kKnobGeoBig) != 0 ? P.rgbaz_runs : 0;
+    P.face_n = n_merged;
+    for (int k = 0; k < n_merged; ++k) {
+      P.face_dst[k] = outs[merged[k]].data;
+      P.face_xy[k] = uses[k].xy;
+      P.face_box[k] = uses[k].box;
+    }
+    P.dst = P.face_dst[0];
+    P.geo_xy = P.face_xy[0];
+    P.geo_box = P.face_box[0];
+    e = lrp::launch_win_bicubic(P, oi, im, stream);
+    if (e == hipSuccess) g_knobs[kKnobMergedLaunches].fetch_add(1, std::memory_order_relaxed);
+  }
+  for (int k = 0; k < n_merged; ++k) lrp::geo_launched(&uses[k], stream, e == hipSuccess && result == LRP_OK);
+  if (e != hipSuccess && result == LRP_OK) result = hip_fail(e, "multi-output reproject kernel launch");
+  return result;
+}
 } // namespace
 
 int lrp_reproject_multi_device(const lrp_image *in, lrp_image *outs, int n_out, int num_samples,
@@ -708,26 +786,62 @@ int lrp_reproject_multi_device(const lrp_image *in, lrp_image *outs, int n_out, 
   int n_lanes = 1;
   lanes[0] = (hipStream_t)stream;
   const int want_side = std::min(multi_fork_lanes(), n_out - 1);
+  // The fork point is recorded now; the side streams are made to wait for it only when a launch is about to go to one
+  // (ensure_fork below): a call whose outputs all merge into one launch never pays for a fork and a join.
+  bool fork_recorded = false, forked = false;
   if (want_side > 0) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) (void)hipGetLastError();
     if (cap == hipStreamCaptureStatusNone && (fork = multi_fork(device)) != nullptr) {
       fork_lock = std::unique_lock<std::mutex>(fork->busy);
-      bool ok = hipEventRecord(fork->forked, (hipStream_t)stream) == hipSuccess;
-      for (int k = 0; k < want_side && ok; ++k) ok = hipStreamWaitEvent(fork->side[k], fork->forked, 0) == hipSuccess;
-      if (ok) {
-        for (int k = 0; k < want_side; ++k) lanes[n_lanes++] = fork->side[k];
-      } else { // side streams that already wait on the event just wait for the caller's earlier work: harmless
+      fork_recorded = hipEventRecord(fork->forked, (hipStream_t)stream) == hipSuccess;
+      if (!fork_recorded) {
         (void)hipGetLastError();
         fork = nullptr;
       }
     }
   }
+  auto ensure_fork = [&]() { // true: lanes[1 ..] are usable
+    if (forked) return true;
+    if (!fork_recorded || fork == nullptr) return false;
+    bool ok = true;
+    for (int k = 0; k < want_side && ok; ++k) ok = hipStreamWaitEvent(fork->side[k], fork->forked, 0) == hipSuccess;
+    if (ok) {
+      for (int k = 0; k < want_side; ++k) lanes[n_lanes++] = fork->side[k];
+      forked = true;
+    } else { // side streams that already wait on the event just wait for the caller's earlier work: harmless
+      (void)hipGetLastError();
+      fork_recorded = false;
+    }
+    return forked;
+  };
   int result = LRP_OK;
-  for (int i = 0; i < n_out && result == LRP_OK; ++i)
+  // Outputs whose geometry-cache entries exist (every call of a run but the first: the faces of a cubemap keep their
+  // rotations) are not launched one by one: groups of up to kMaxFaces outputs of one shape go out as ONE launch on the
+  // caller's stream.  The others — first sightings, other samplers — are launched as before, dealt over the lanes.
+  std::vector<MergeCandidate> cand((size_t)n_out);
+  int lane_next = 0;
+  for (int i = 0; i < n_out && result == LRP_OK; ++i) {
+    if (lane_next > 0) (void)ensure_fork(); // (the first launch goes to the caller's stream)
     result = enqueue_reproject(in, &outs[i], num_samples, interpolation, rotations ? rotations + 9 * i : nullptr, post, device,
-                               lanes[i % n_lanes]);
-  if (fork != nullptr) // join, whatever happened: the caller's stream continues behind the side streams
+                               lanes[lane_next % n_lanes], 0, 0, 0, n_out > 1 ? &cand[(size_t)i] : nullptr);
+    if (!cand[(size_t)i].ready) ++lane_next;
+  }
+  std::vector<char> done((size_t)n_out, 0);
+  for (int i = 0; i < n_out && result == LRP_OK; ++i) {
+    if (!cand[(size_t)i].ready || done[(size_t)i]) continue;
+    int group[lrp::kMaxFaces], n_group = 0;
+    for (int j = i; j < n_out && n_group < lrp::kMaxFaces; ++j) {
+      const MergeCandidate &a = cand[(size_t)i], &b = cand[(size_t)j];
+      if (!b.ready || done[(size_t)j]) continue;
+      const bool same_shape = a.out_idx == b.out_idx && a.in_mode == b.in_mode && a.P.out_w == b.P.out_w && a.P.out_h == b.P.out_h &&
+                              a.P.channels == b.P.channels && std::memcmp(&a.P.out_lens, &b.P.out_lens, sizeof(a.P.out_lens)) == 0;
+      if (same_shape) group[n_group++] = j;
+    }
+    result = enqueue_merged_outputs(cand, outs, group, n_group, in, num_samples, interpolation, rotations, post, device, (hipStream_t)stream);
+    for (int k = 0; k < n_group; ++k) done[(size_t)group[k]] = 1;
+  }
+  if (fork != nullptr && forked) // join, whatever happened: the caller's stream continues behind the side streams
     for (int k = 0; k + 1 < n_lanes; ++k)
       if (hipEventRecord(fork->joined[k], fork->side[k]) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, fork->joined[k], 0) != hipSuccess) {
         const hipError_t e = hipGetLastError();

@@ -374,6 +374,15 @@ void geo_acquire(const GeoKey &key, bool want_boxes, hipStream_t stream, GeoUse 
   for (Retired &r : to_free) free_retired(r, false);
 }
 
+bool geo_peek(const GeoKey &key, bool want_boxes) {
+  DeviceCache *const dc = cache_of(key.device);
+  if (!dc || g_max_bytes.load(std::memory_order_relaxed) == 0) return false;
+  std::lock_guard<std::mutex> lock(dc->mutex);
+  for (const auto &e : dc->entries)
+    if (same_key(e->key, key)) return part_usable(e->map) && (!want_boxes || part_usable(e->box));
+  return false;
+}
+
 void geo_launched(GeoUse *use, hipStream_t stream, bool ok) {
   if (!use->entry) return;
   Entry *e = static_cast<Entry *>(use->entry);

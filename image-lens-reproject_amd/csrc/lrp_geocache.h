@@ -57,6 +57,9 @@ struct GeoUse {
 // per-block extremes too).  A reader on another stream than the entry's writer is made to wait for the writer
 // (hipStreamWaitEvent).  Never fails: any problem (no memory, a capturing stream, the cache switched off) is mode 0.
 void geo_acquire(const GeoKey &key, bool want_boxes, hipStream_t stream, GeoUse *use);
+// True: the entry of `key` exists and a geo_acquire now would read it (mode 2) — for callers that only want the cache when
+// it is there (lrp_reproject_multi_device merges the outputs whose entries are) and must not claim what they will not write.
+bool geo_peek(const GeoKey &key, bool want_boxes);
 // After the launch has been enqueued (ok) or has failed to: publishes a written entry, marks the stream, unpins.
 void geo_launched(GeoUse *use, hipStream_t stream, bool ok);
 

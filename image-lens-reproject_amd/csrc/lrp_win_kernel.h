@@ -136,10 +136,20 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   const int frame0 = Pk.batch_n > 0 ? (int)blockIdx.y * frames_per_wave : 0;
   const int n_frames = (Frames && Pk.batch_n > 0) ? min(frames_per_wave, Pk.batch_n - frame0) : 1;
   auto frame_src = [&](int f) { return Pk.batch_n > 0 ? Pk.batch_src[frame0 + f] : Pk.src; };
-  auto frame_dst = [&](int f) { return Pk.batch_n > 0 ? Pk.batch_dst[frame0 + f] : Pk.dst; };
+  auto frame_dst = [&](int f) {
+    if constexpr (GeoRead && !Frames)
+      if (Pk.face_n > 0) return Pk.face_dst[blockIdx.z];
+    return Pk.batch_n > 0 ? Pk.batch_dst[frame0 + f] : Pk.dst;
+  };
   KParams P = Pk; // src / dst: the frame being rendered (set_frame below)
   P.src = frame_src(0);
   P.dst = frame_dst(0);
+  if constexpr (GeoRead && !Frames) {
+    if (Pk.face_n > 0) { // a multi-output launch: this workgroup's output (frame_dst) and its geometry (lrp_params.h)
+      P.geo_xy = Pk.face_xy[blockIdx.z];
+      P.geo_box = Pk.face_box[blockIdx.z];
+    }
+  }
   constexpr bool Loop = (InMode == kInEquirectLoop);
   // Edge blocks (WinBlockT::edge) are compiled for the rectilinear source only: a narrow view inside a wider target is
   // where whole blocks lie beyond one side of the source; in the other instantiations the extra code costs 2-3 % (measured:
@@ -152,7 +162,14 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   // the rectilinear-source kernels lost 6 % to the extra code: rect -> equirect 210 -> 223 us).
   // (... and for the RGBAZ kernels of a rectilinear source: their per-pixel path is 20 gathers a pixel, and the pass windows
   // below pay there — rect -> equirect RGBAZ 300 -> 288 us, BASELINE configs[3] — while RGBA / RGB lose 4-6 %.)
-  constexpr bool kSplit = LRP_WIN_SPLIT != 0 && !Frames && (InMode == kInEquirect || InMode == kInEquirectLoop || (InMode == kInRect && CH == 5));
+#ifndef LRP_BIG_SPLIT4
+#define LRP_BIG_SPLIT4 1 // the big-window RGBA variant stages half blocks too, like the RGBAZ one (rect -> equirect 4096^2: 210 -> 203 us single, 191 -> 184 batched)
+#endif
+#ifndef LRP_BIG_MAXCOLS
+#define LRP_BIG_MAXCOLS 64 // widest block / half-block window of the big-window variant (pass windows: 128)
+#endif
+  constexpr bool kSplit = LRP_WIN_SPLIT != 0 && !Frames && (InMode == kInEquirect || InMode == kInEquirectLoop || (InMode == kInRect && CH == 5) || (kBigWin && LRP_BIG_SPLIT4 != 0));
+  constexpr int kMaxStagedCols = kBigWin ? LRP_BIG_MAXCOLS : 64;
   // Pass windows (below) for rectilinear targets only — perspective views and cubemap faces out of a panorama; in the
   // fisheye-target kernels the extra code cost 2.5 % (equirect -> fisheye single launches 247 -> 253 us).
   constexpr bool kPassWin = (kSplit || (GeoRead && OutLens == kEquirect)) && LRP_WIN_PASSWIN != 0 && (OutLens == kRect || GeoRead || (InMode == kInRect && CH == 5));
@@ -170,8 +187,8 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   auto fill_share = [&]() {
     if constexpr (kListable) {
       const uint32_t per_wave = Pk.geo_fill_per_wave;
-      if (per_wave != 0) {
-        const uint32_t total = Pk.geo_n_runs * 16u, s0 = blockIdx.x * per_wave;
+      if (per_wave != 0 && blockIdx.x % Pk.geo_fill_stride == 0) {
+        const uint32_t total = Pk.geo_n_runs * 16u, s0 = blockIdx.x / Pk.geo_fill_stride * per_wave;
         if (s0 < total)
           for (int f = 0; f < n_frames; ++f) corner_fill_rows<CH>(Pk, frame_src(f), frame_dst(f), s0, min(s0 + per_wave, total));
       }
@@ -331,7 +348,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   auto raw_slots = [&](const WinBlock &b) { return win_raw_slots<CH, kSplit>(b); };
   // (lrp_win_plan.h)
   auto plan_window = [&](WinBlock &b, int w_lo_x, int w_hi_x, int w_lo_ya, int w_hi_ya, int w_lo_yb, int w_hi_yb, bool exact_x, bool exact_y) {
-    win_plan_block<CH, Loop, kSplit, kEdge, kCap>(b, P, plan_limits, w_lo_x, w_hi_x, w_lo_ya, w_hi_ya, w_lo_yb, w_hi_yb, exact_x, exact_y);
+    win_plan_block<CH, Loop, kSplit, kEdge, kCap, kMaxStagedCols>(b, P, plan_limits, w_lo_x, w_hi_x, w_lo_ya, w_hi_ya, w_lo_yb, w_hi_yb, exact_x, exact_y);
   };
   auto clear_block = [](WinBlock &b) { win_clear_block(b); };
   // One pixel's contribution to the extremes.  Per pixel only the exactness half of interior()
@@ -1161,7 +1178,8 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
     // >= 2 rounds of wavefronts; the launches that read the geometry cache >= 4 (their wavefronts differ more in what a block
     // costs them — nothing is computed, everything is waited for: pole face of the 8192^2 -> 2048^2 cubemap 107.5 -> 98.4 us)
     const long long min_waves = GeoRead ? 16384 : 8192;
-    while (!strip_forced && G > 1 && (long long)P.tiles_x * kWinWaves * ((row_blocks + G - 1) / G) < min_waves) G >>= 1;
+    const int n_faces = (GeoRead && P.face_n > 0) ? P.face_n : 1;
+    while (!strip_forced && G > 1 && (long long)P.tiles_x * kWinWaves * ((row_blocks + G - 1) / G) * n_faces < min_waves) G >>= 1;
     if (GeoRead && P.geo_work != nullptr && in_mode != kInRect) return hipErrorInvalidValue; // (lists: the rectilinear source's instantiations)
     if (GeoRead && P.geo_work != nullptr) G = 1; // a listed launch: one block per wavefront, the blocks of the work list only
     P.blocks_per_wave = G;
@@ -1197,7 +1215,12 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
     if (P.geo_n_work == 0) return hipSuccess;       // every block is a corner block
     grid_x = P.geo_n_work;
   }
-  hipLaunchKernelGGL(fn, dim3(grid_x, (unsigned)groups), dim3(kWinThreads), 0, stream, P);
+  unsigned grid_z = 1;
+  if (GeoRead && P.face_n > 0) {
+    if (P.face_n > kMaxFaces || P.batch_n > 0 || P.geo_work != nullptr) return hipErrorInvalidValue;
+    grid_z = (unsigned)P.face_n;
+  }
+  hipLaunchKernelGGL(fn, dim3(grid_x, (unsigned)groups, grid_z), dim3(kWinThreads), 0, stream, P);
   return hipGetLastError();
 }
 

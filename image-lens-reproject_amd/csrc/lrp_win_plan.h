@@ -161,7 +161,7 @@ __device__ __forceinline__ WinPlanLimits win_plan_limits(const KParams &P) {
 // its two halves (passes 0-1, 2-3).  exact_x / exact_y: int(s + k) == int(s) + k, k = -1 .. 2, holds for every pixel's x / y.
 // CH: channels (RGBAZ windows carry a depth plane); Loop: the source wraps horizontally (no corner / edge blocks);
 // Split / Edge: the instantiation stages split blocks / edge blocks; Cap: 16-byte slots of its window buffer.
-template <int CH, bool Loop, bool Split, bool Edge, int Cap, bool Quad>
+template <int CH, bool Loop, bool Split, bool Edge, int Cap, int MaxCols = 64, bool Quad = false>
 __device__ __forceinline__ void win_plan_block(WinBlockT<Quad> &block, const KParams &P, const WinPlanLimits &L, int w_lo_x, int w_hi_x, int w_lo_ya,
                                                int w_hi_ya, int w_lo_yb, int w_hi_yb, bool exact_x, bool exact_y) {
   constexpr int kPlanes = 3;
@@ -187,8 +187,8 @@ __device__ __forceinline__ void win_plan_block(WinBlockT<Quad> &block, const KPa
     b.bw = x_last + 2 - b.x_lo + 1;
     b.bh = y_last + 2 - b.y_lo + 1;
     b.pitch = b.bw | 1; // odd: consecutive window rows start an odd number of 16 B slots apart
-    b.tier = (b.bw <= 64 && win_raw_slots<CH, Split>(b) <= Cap) ? 1 : 0;
-    if (Split && P.win_split != 0 && b.tier == 0 && b.bw <= 64) {
+    b.tier = (b.bw <= MaxCols && win_raw_slots<CH, Split>(b) <= Cap) ? 1 : 0; // (MaxCols: 64 texels per DMA instruction and window row)
+    if (Split && P.win_split != 0 && b.tier == 0 && b.bw <= MaxCols) {
       const int a_lo = ya_first - 1, a_rows = ya_last + 2 - a_lo + 1, b_lo = yb_first - 1, b_rows = yb_last + 2 - b_lo + 1;
       if (win_slots_of_rows<CH>(b.pitch, max(a_rows, b_rows)) <= Cap) {
         b.y_lo = a_lo;
