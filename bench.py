@@ -83,7 +83,7 @@ DEFAULT_SECONDARY = ("equirect_to_rect_bicubic,equirect_to_rect_bicubic_rot,equi
 INTERP_NAMES = {0: "nearest", 1: "bilinear", 2: "bicubic"}
 KERNEL_NAMES = {0: "reproject_tile_kernel (nearest)", 1: "reproject_tile_kernel (bilinear)",
                 2: "reproject_bicubic_win_kernel (LDS window)"}
-TRAFFIC_FILE = os.path.join("profiles", "traffic_r04.json")
+TRAFFIC_FILE = os.path.join("profiles", "traffic_r05.json")
 
 
 def kernel_source_sha():
@@ -101,7 +101,7 @@ def kernel_source_sha():
 
 def measured_traffic(workload):
     """(per 16-frame launch, per single-frame launch) HBM bytes of the dominant kernel from the committed rocprofv3 PMC
-    summary (profiles/traffic_r04.json; tools/collect_traffic.sh on an MI355X: both launch shapes are profiled).  The
+    summary (profiles/traffic_r05.json; tools/collect_traffic.sh on an MI355X: both launch shapes are profiled).  The
     file is stamped with the hash of the kernel sources it was measured on; a stale file yields (None, None)."""
     try:
         with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
@@ -370,6 +370,44 @@ def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_
         single(i)
     torch.cuda.synchronize()
     s_avg, s_min = time_launches(torch, stream, single, 64)
+    # ... and the same single launches dealt alternately to TWO streams (what lrp_context does with consecutive images: the tail
+    # of one launch overlaps the head of the next): wall time per launch between a fork and a join on `stream`
+    side = torch.cuda.Stream(device=stream.device)
+
+    def single_on(i, st):
+        if faces:
+            pkg.reproject_multi(im_in[i % n_res], im_out[i % n_res], 1, wl["interp"], rots, post=post, stream=st)
+        else:
+            pkg.reproject(im_in[i % n_res], im_out[i % n_res][0], 1, wl["interp"], rot, post=post, stream=st)
+
+    def two_stream_us(reps=64):
+        best = None
+        for _ in range(3):
+            e0, e1, ej = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event()
+            e0.record(stream)
+            side.wait_event(e0)
+            for i in range(reps):
+                single_on(i, side if i & 1 else stream)
+            ej.record(side)
+            stream.wait_event(ej)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            best = us if best is None else min(best, us)
+        return best
+
+    one_stream_wall_us = None
+    for i in range(8):
+        single_on(i, side if i & 1 else stream)
+    torch.cuda.synchronize()
+    two_us = two_stream_us()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for i in range(64):
+        single_on(i, stream)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    one_stream_wall_us = e0.elapsed_time(e1) * 1e3 / 64
     prev_geo = pkg.debug_set("geo_cache", 0)
     try:  # (the switch is process-wide: whatever happens in here, the launches after it run the default again)
         for i in range(8):
@@ -412,6 +450,12 @@ def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_
         "single_launch_us": s_avg * 1e3,
         "single_launch_us_min": s_min * 1e3,
         "single_launch_frac": frame_bytes / (s_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "single_launch_us_two_streams": two_us,
+        "single_launch_frac_two_streams": frame_bytes / (two_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+        "single_launch_us_one_stream_wall": one_stream_wall_us,
+        "single_launch_two_streams_note": "64 single launches dealt alternately to two streams (lrp_context alternates its compute streams the same "
+                                          "way), wall time per launch between a fork and a join; ..._one_stream_wall: the same 64 launches on one stream, "
+                                          "measured the same way (no event between the launches)",
         "single_launch_us_uncached": u_avg * 1e3,
         "single_launch_frac_uncached": frame_bytes / (u_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "single_launch_note": "one frame per launch, what reproject::reproject() makes per file: coordinates from the geometry cache "

@@ -183,16 +183,17 @@ lrp::KParams make_params(const lrp_image *in, const lrp_image *out, int num_samp
 // initial values, once, when the library is loaded — nothing on a launch path calls getenv.
 //   kernel: 0 = pixel kernel, 1 = tile kernel everywhere, 2 (default) = tile kernel with the LDS-window kernel for
 //   bicubic, 3 = the same without its shared-coefficient tier and without any work sharing.  All HIP; there is no CPU path.
-enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobGeoBig, kKnobGeoLists, kKnobGeoFillStream, kKnobGeoFillFused, kKnobMultiMerge, kKnobListedLaunches, kKnobMergedLaunches, kKnobCount };
+enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobGeoBig, kKnobGeoLists, kKnobGeoFillStream, kKnobGeoFillFused, kKnobMultiMerge, kKnobContextStreams, kKnobListedLaunches, kKnobMergedLaunches, kKnobCount };
 struct KnobSpec {
   const char *name, *env;
   int lo, hi, initial;
 };
 constexpr int kMaxSideStreams = 5;
-// Listed launches render one block per wavefront: where the blocks that remain are mostly in view (BASELINE configs[3]: 37 % corner
-// blocks) the strips of the enumerating launch win by 2-7 % (their wavefronts fetch the next block's record under the current
-// block); from about half a frame of corner blocks on the listed launch wins (rect -> fisheye 2-3 %, narrower views 10-40 %).
-constexpr unsigned kListedCornerPercent = 45;
+// Listed launches render one block per wavefront, the enumerating launch strips of two (its wavefronts fetch the next block's
+// record under the current block): with the corner runs written by every n-th wavefront the listed launch is level at a third of
+// a frame of corner blocks (BASELINE configs[3], 37 %: RGBA +-1 %, RGBAZ + tonemap 2-4 % ahead) and ahead beyond that (rect ->
+// fisheye 2-3 %, narrower views 10-40 %); below, the plain enumeration stays.
+constexpr unsigned kListedCornerPercent = 30;
 constexpr unsigned kMinWavesForFusedFill = 2048; // wavefronts a listed window launch must have to carry the corner runs itself
 const KnobSpec kKnobs[kKnobCount] = {
     {"kernel", "LRP_KERNEL", 0, 3, 2},
@@ -206,10 +207,11 @@ const KnobSpec kKnobs[kKnobCount] = {
     {"geo_cache", "LRP_GEO_CACHE", 0, 1, 1},        // geometry cache used by single launches (0: every launch computes)
     {"geo_strip", "LRP_GEO_STRIP", 0, lrp::kGeoStripRows, 0}, // blocks per wavefront of a launch that reads the geometry cache (0: automatic)
     {"geo_big", "LRP_GEO_BIG", 0, 1, 1},            // big-window variant of the kernels that read the geometry cache (a rectilinear view rendered into a panorama); 0: the four-wavefront instantiation
-    {"geo_lists", "LRP_GEO_LISTS", 0, 2, 1},        // rendering by block class from the lists of a geometry-cache entry (corner runs by the fill kernel / a share per wavefront, the window kernel over the work list): 0 never, 1 where at least 45 % of the blocks are corner blocks, 2 whenever the lists are known
+    {"geo_lists", "LRP_GEO_LISTS", 0, 2, 1},        // rendering by block class from the lists of a geometry-cache entry (corner runs by the fill kernel / a share per wavefront, the window kernel over the work list): 0 never, 1 where at least 30 % of the blocks are corner blocks, 2 whenever the lists are known
     {"geo_fill_stream", "LRP_GEO_FILL_STREAM", 0, 1, 0}, // the fill kernel of a listed launch: 0 in front of the window kernel on the caller's stream, 1 beside it on a side stream of the device
     {"geo_fill_fused", "LRP_GEO_FILL_FUSED", 0, 1, 1}, // the corner runs of a listed launch as a share per wavefront of the window kernel (0: always the fill kernel)
-    {"multi_merge", "LRP_MULTI_MERGE", 0, 1, 1},     // lrp_reproject_multi_device: the outputs whose geometry-cache entries exist in ONE launch (blockIdx.z = output); 0: a launch per output
+    {"multi_merge", "LRP_MULTI_MERGE", 0, 1, 1},     // lrp_reproject_multi_device: the outputs whose geometry-cache entries exist in ONE launch; 0: a launch per output
+    {"context_streams", "LRP_CONTEXT_STREAMS", 0, 1, 1}, // lrp_context: consecutive images alternate between two compute streams (0: one)
     {"listed_launches", "LRP_LISTED_LAUNCHES_UNUSED", 0, 0, 0}, // a counter, not a switch: launches rendered by block class so far (set 0 to reset; tests, bench)
     {"merged_launches", "LRP_MERGED_LAUNCHES_UNUSED", 0, 0, 0}, // a counter: multi-output launches so far
 };
@@ -599,6 +601,12 @@ struct lrp_context {
   std::mutex mutex; // submissions from several host threads are serialised
   int device = 0;
   hipStream_t up = nullptr, run = nullptr, down = nullptr;
+  // Consecutive images alternate between two compute streams (contexts with more than one slot): the tail of image i's
+  // launch — the last 6 % of a single 4K launch run with the wave slots draining — overlaps the head of image i + 1's.
+  // Same-box A/B, single launches of one geometry, wall time per launch: headline 115.2 -> 107.7 us, equirect -> rect
+  // 109.0 -> 102.0, equirect -> fisheye rotated 146.4 -> 138.1 (three streams: no further gain).
+  hipStream_t run2 = nullptr;
+  unsigned run_next = 0;
   std::vector<Slot> slots;
   size_t next = 0;
 };
@@ -1058,6 +1066,7 @@ int lrp_context_create(lrp_context **ctx, int device, int n_streams) {
   c->slots.resize((size_t)n_streams);
   hipError_t e = hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->run, hipStreamNonBlocking);
+  if (e == hipSuccess && n_streams > 1) e = hipStreamCreateWithFlags(&c->run2, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->down, hipStreamNonBlocking);
   for (auto &s : c->slots) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming);
@@ -1075,7 +1084,7 @@ int lrp_context_create(lrp_context **ctx, int device, int n_streams) {
 void lrp_context_destroy(lrp_context *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  for (hipStream_t st : {ctx->up, ctx->run, ctx->down})
+  for (hipStream_t st : {ctx->up, ctx->run, ctx->run2, ctx->down})
     if (st) {
       (void)hipStreamSynchronize(st);
       (void)hipStreamDestroy(st);
@@ -1125,24 +1134,25 @@ int submit_locked(lrp_context *ctx, const lrp_image *in, int in_format, int in_p
                              hipMemcpyHostToDevice, ctx->up));
   LRP_HIP_TRY(hipEventRecord(s.uploaded, ctx->up));
   // kernels: after the upload, and after the previous download has read the destination buffers
-  LRP_HIP_TRY(hipStreamWaitEvent(ctx->run, s.uploaded, 0));
-  if (s.used) LRP_HIP_TRY(hipStreamWaitEvent(ctx->run, s.downloaded, 0));
+  const hipStream_t run = (ctx->run2 != nullptr && knob(kKnobContextStreams) != 0 && (ctx->run_next++ & 1u) != 0) ? ctx->run2 : ctx->run;
+  LRP_HIP_TRY(hipStreamWaitEvent(run, s.uploaded, 0));
+  if (s.used) LRP_HIP_TRY(hipStreamWaitEvent(run, s.downloaded, 0));
   if (!in_plain) {
     hipError_t e = lrp::launch_decode_pixels(s.d_in_packed.ptr, in_format, in_pch, (float *)s.d_in.ptr, in->channels, in_px,
-                                             ctx->device, ctx->run);
+                                             ctx->device, run);
     if (e != hipSuccess) return hip_fail(e, "pixel decode kernel launch");
   }
   lrp_image din = *in, dout = *out;
   din.data = (float *)s.d_in.ptr;
   dout.data = (float *)s.d_out.ptr;
-  int st = enqueue_reproject(&din, &dout, num_samples, interpolation, rotation, post, ctx->device, ctx->run);
+  int st = enqueue_reproject(&din, &dout, num_samples, interpolation, rotation, post, ctx->device, run);
   if (st != LRP_OK) return st;
   if (!out_plain) {
     hipError_t e = lrp::launch_encode_pixels((const float *)s.d_out.ptr, out->channels, s.d_out_packed.ptr, out_format, out_pch,
-                                             out_fill, out_px, ctx->device, ctx->run);
+                                             out_fill, out_px, ctx->device, run);
     if (e != hipSuccess) return hip_fail(e, "pixel encode kernel launch");
   }
-  LRP_HIP_TRY(hipEventRecord(s.computed, ctx->run));
+  LRP_HIP_TRY(hipEventRecord(s.computed, run));
   // download
   LRP_HIP_TRY(hipStreamWaitEvent(ctx->down, s.computed, 0));
   LRP_HIP_TRY(hipMemcpyAsync(out->data, out_plain ? s.d_out.ptr : s.d_out_packed.ptr, out_plain ? out_bytes : out_packed,
@@ -1201,7 +1211,8 @@ int lrp_context_wait(lrp_context *ctx) {
   if (st != LRP_OK) return st;
   int result = LRP_OK;
   std::lock_guard<std::mutex> lock(ctx->mutex);
-  for (hipStream_t stream : {ctx->up, ctx->run, ctx->down}) {
+  for (hipStream_t stream : {ctx->up, ctx->run, ctx->run2, ctx->down}) {
+    if (!stream) continue;
     hipError_t e = hipStreamSynchronize(stream);
     if (e != hipSuccess && result == LRP_OK) result = hip_fail(e, "hipStreamSynchronize");
   }

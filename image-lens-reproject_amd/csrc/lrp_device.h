@@ -13,8 +13,8 @@
 namespace lrp {
 
 // Workgroup -> tile (see kXcdBand in lrp_params.h); false: surplus workgroup.
-template <int Band = kXcdBand> __device__ __forceinline__ bool xcd_tile(int tiles_x, int tiles_y, int &tx, int &ty) {
-  const int xcd = (int)(blockIdx.x % kXcds), j = (int)(blockIdx.x / kXcds); // j: index within the XCD
+template <int Band = kXcdBand> __device__ __forceinline__ bool xcd_tile(int tiles_x, int tiles_y, int &tx, int &ty, uint32_t workgroup = blockIdx.x) {
+  const int xcd = (int)(workgroup % kXcds), j = (int)(workgroup / kXcds); // j: index within the XCD
   const int row = j / tiles_x; // row of tiles among this XCD's
   tx = j - row * tiles_x;
   ty = ((row / Band) * kXcds + xcd) * Band + row % Band;

@@ -14,7 +14,7 @@ enum : int { kRect = 0, kEquidistant = 1, kEquirect = 4 };
 // (reference LoopHorizontally, src/reproject.cpp:386-394).
 enum : int { kInRect = 0, kInEquidistant = 1, kInEquirect = 2, kInEquirectLoop = 3 };
 constexpr int kMaxBatch = 16; // frames of one geometry rendered by one launch (blockIdx.y = frame)
-constexpr int kMaxFaces = 8;  // outputs of one source rendered by one launch (blockIdx.z = output; a cubemap has six)
+constexpr int kMaxFaces = 8;  // outputs of one source rendered by one launch (interleaved workgroup by workgroup; a cubemap has six)
 constexpr int kXcds = 8; // XCDs (private L2s) of an MI355X; blockIdx % 8 labels the blocks that share one
 // XCD-aware tile numbering.  The dispatcher deals workgroup i to XCD i % 8.  The rows of tiles are cut
 // into bands of kXcdBand rows and the bands dealt round-robin to the XCDs: XCD k walks bands k, k + 8,
@@ -106,8 +106,8 @@ struct KParams {
   uint32_t geo_n_work, geo_n_runs;
   // Multi-output launch (GeoRead window kernels without the frame loop; lrp_reproject_multi_device): face_n > 0 outputs of ONE
   // source — same size, channels and lenses, each with its own rotation, i.e. its own geometry-cache entry — rendered by one
-  // launch, blockIdx.z = output: one ramp and one tail instead of face_n, and the wavefronts of cheap and of expensive faces
-  // (a cubemap's pole faces cost twice its side faces) fill each other's gaps.
+  // launch (the outputs interleaved workgroup by workgroup): one ramp and one tail instead of face_n, and the wavefronts of cheap
+  // and of expensive faces (a cubemap's pole faces cost twice its side faces) fill each other's gaps.
   int32_t face_n;
   float *face_dst[kMaxFaces];
   float *face_xy[kMaxFaces];

@@ -136,9 +136,21 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   const int frame0 = Pk.batch_n > 0 ? (int)blockIdx.y * frames_per_wave : 0;
   const int n_frames = (Frames && Pk.batch_n > 0) ? min(frames_per_wave, Pk.batch_n - frame0) : 1;
   auto frame_src = [&](int f) { return Pk.batch_n > 0 ? Pk.batch_src[frame0 + f] : Pk.src; };
+  // A multi-output launch (lrp_params.h face_n): consecutive workgroups of an XCD take the same block of consecutive outputs —
+  // every output advances at the same pace, so the cheap and the expensive ones (a cubemap's pole faces cost twice its side
+  // faces) are mixed from the first wavefront to the last, and the launch has one tail instead of the most expensive output's.
+  int face = 0;
+  uint32_t workgroup = blockIdx.x;
+  if constexpr (GeoRead && !Frames) {
+    if (Pk.face_n > 0) {
+      const uint32_t in_xcd = blockIdx.x / kXcds;
+      face = (int)(in_xcd % (uint32_t)Pk.face_n);
+      workgroup = in_xcd / (uint32_t)Pk.face_n * kXcds + blockIdx.x % kXcds;
+    }
+  }
   auto frame_dst = [&](int f) {
     if constexpr (GeoRead && !Frames)
-      if (Pk.face_n > 0) return Pk.face_dst[blockIdx.z];
+      if (Pk.face_n > 0) return Pk.face_dst[face];
     return Pk.batch_n > 0 ? Pk.batch_dst[frame0 + f] : Pk.dst;
   };
   KParams P = Pk; // src / dst: the frame being rendered (set_frame below)
@@ -146,8 +158,8 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   P.dst = frame_dst(0);
   if constexpr (GeoRead && !Frames) {
     if (Pk.face_n > 0) { // a multi-output launch: this workgroup's output (frame_dst) and its geometry (lrp_params.h)
-      P.geo_xy = Pk.face_xy[blockIdx.z];
-      P.geo_box = Pk.face_box[blockIdx.z];
+      P.geo_xy = Pk.face_xy[face];
+      P.geo_box = Pk.face_box[face];
     }
   }
   constexpr bool Loop = (InMode == kInEquirectLoop);
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
       fill_share();
       return;
     }
-  } else if (!xcd_tile<kWinXcdBand>(P.tiles_x, P.tiles_y, tx, ty)) return; // whole workgroup
+  } else if (!xcd_tile<kWinXcdBand>(P.tiles_x, P.tiles_y, tx, ty, workgroup)) return; // whole workgroup
 #if defined(LRP_WAVE_STAMPS)
   const unsigned long long stamp_start = wall_clock64();
 #endif
@@ -1215,12 +1227,11 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
     if (P.geo_n_work == 0) return hipSuccess;       // every block is a corner block
     grid_x = P.geo_n_work;
   }
-  unsigned grid_z = 1;
   if (GeoRead && P.face_n > 0) {
     if (P.face_n > kMaxFaces || P.batch_n > 0 || P.geo_work != nullptr) return hipErrorInvalidValue;
-    grid_z = (unsigned)P.face_n;
+    grid_x *= (unsigned)P.face_n; // (the outputs interleaved inside every XCD's sequence of workgroups)
   }
-  hipLaunchKernelGGL(fn, dim3(grid_x, (unsigned)groups, grid_z), dim3(kWinThreads), 0, stream, P);
+  hipLaunchKernelGGL(fn, dim3(grid_x, (unsigned)groups), dim3(kWinThreads), 0, stream, P);
   return hipGetLastError();
 }
 

@@ -420,3 +420,158 @@ def test_host_buffer_entry_points_use_the_cache(lrp, torch_cuda):
         assert golden_cases.digest(out) == SMALL["reproject"][name]
     s1 = lrp.geometry_cache_stats()
     assert s1["fills"] == s0["fills"] + 1 and s1["hits"] == s0["hits"] + 2
+
+
+def test_eight_threads_one_evicting(lrp, oracle, torch_cuda):
+    """Seven host threads render their own geometry over and over (hits) while an eighth walks through new geometries under a
+    cap that holds about eight entries, so that every one of its calls evicts somebody's entry: retired buffers are taken over
+    behind their events or freed outside the lock — nothing on the launch path synchronises the device
+    (csrc/lrp_geocache.cpp).  Every image against the live oracle; the launch calls of the non-evicting threads stay short."""
+    import time
+
+    torch = torch_cuda
+    iw, ih, ow, oh, c = 96, 80, 72, 67, 4
+    src = cases.hash_noise(ih, iw, c, seed=0xE71C, planted=True)
+    d_in = torch.from_numpy(src).cuda()
+    lin, lout = lrp.LensInfo.equirectangular(), lrp.LensInfo.rectilinear(18.0, 36.0, ow, oh)
+    rots = [lrp.rotation_matrix(0.05 * k, -0.03 * k, 0.01 * k) for k in range(7 + 24)]
+    wants = [oracle.reproject(lin, src, lout, ow, oh, 1, 2, r) for r in rots]
+    one = lrp.geometry_cache_stats()
+    entry_bytes = ((ow * oh * 8 + 255) // 256) * 256 + 8192  # (map + records + lists, roughly)
+    lrp.geometry_cache_configure(8 * entry_bytes, 1)
+    errors, latencies = [], [[] for _ in range(7)]
+    barrier = threading.Barrier(8)
+
+    def render(k, stream):
+        out = torch.full((oh, ow, c), -12345.0, dtype=torch.float32, device="cuda")
+        t0 = time.perf_counter()
+        lrp.reproject(lrp.Image(lin, iw, ih, c, d_in), lrp.Image(lout, ow, oh, c, out), 1, 2, rots[k], stream=stream)
+        dt = time.perf_counter() - t0
+        stream.synchronize()
+        if not np.array_equal(out.cpu().numpy().view(np.uint32), wants[k].view(np.uint32)):
+            errors.append(("bits", k))
+        return dt
+
+    def steady(t):
+        try:
+            stream = torch.cuda.Stream()
+            barrier.wait()
+            for _ in range(40):
+                latencies[t].append(render(t, stream))
+        except Exception as exc:  # noqa: BLE001
+            errors.append((t, repr(exc)))
+
+    def evictor():
+        try:
+            stream = torch.cuda.Stream()
+            barrier.wait()
+            for rnd in range(3):
+                for k in range(7, 7 + 24):
+                    render(k, stream)
+        except Exception as exc:  # noqa: BLE001
+            errors.append(("evictor", repr(exc)))
+
+    threads = [threading.Thread(target=steady, args=(t,)) for t in range(7)] + [threading.Thread(target=evictor)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+    st = lrp.geometry_cache_stats()
+    assert st["evictions"] - one["evictions"] >= 40 and st["hits"] - one["hits"] >= 100, st
+    assert st["bytes"] <= st["max_bytes"]
+    med = sorted(x for lat in latencies for x in lat[2:])
+    assert med[len(med) // 2] < 2e-3, f"median launch call of the steady threads {med[len(med) // 2] * 1e3:.2f} ms (max {med[-1] * 1e3:.2f} ms)"
+
+
+def test_two_8k_output_geometries_fit_the_default_cap(lrp, torch_cuda):
+    """Two 8192^2 output geometries (537 MB of coordinates each) alternate: under the default cap — min(4 GiB, 2 % of the
+    device's memory), at least two entries of the largest geometry seen — both stay resident (hits, no eviction), and the cached
+    launches render what the computing launches render (device checksums)."""
+    torch = torch_cuda
+    lrp.geometry_cache_configure(-2, 1)  # the default cap
+    n_in, n_out, c = 1024, 8192, 3
+    d_in = torch.empty((n_in, n_in, c), dtype=torch.float32, device="cuda")
+    lrp.synth_fill(d_in, n_in, n_in, c, 0x8192)
+    lin, lout = lrp.LensInfo.equirectangular(), lrp.LensInfo.rectilinear(18.0, 36.0, n_out, n_out)
+    rots = [lrp.rotation_matrix(0.0, 0.0, 0.0), lrp.rotation_matrix(1.0, -0.4, 0.1)]
+    d_out = torch.empty((n_out, n_out, c), dtype=torch.float32, device="cuda")
+
+    def render(k):
+        d_out.fill_(-1.0)
+        lrp.reproject(lrp.Image(lin, n_in, n_in, c, d_in), lrp.Image(lout, n_out, n_out, c, d_out), 1, 2, rots[k])
+        torch.cuda.synchronize()
+        return lrp.checksums([d_out])[0]
+
+    prev = lrp.debug_set("geo_cache", 0)
+    want = [render(0), render(1)]
+    lrp.debug_set("geo_cache", prev)
+    s0 = lrp.geometry_cache_stats()
+    for rnd in range(3):
+        for k in (0, 1):
+            assert render(k) == want[k], (rnd, k)
+    s1 = lrp.geometry_cache_stats()
+    assert s1["fills"] - s0["fills"] == 2 and s1["hits"] - s0["hits"] == 4 and s1["evictions"] == s0["evictions"], (s0, s1)
+    assert s1["entries"] == 2 and s1["bytes"] > 2 * 8192 * 8192 * 8 and s1["max_bytes"] >= s1["bytes"]
+
+
+def test_key_ignores_the_union_members_a_lens_does_not_have(lrp, torch_cuda):
+    """A C caller sets focal_length of a rectilinear lens and leaves the other three floats of the union indeterminate: the
+    geometry is the same, the cache key must be too (every such call missed, filled and evicted)."""
+    torch = torch_cuda
+    name, case = _bicubic_cases(lrp)[0]
+    src, lin, lout, rot = _small_setup(lrp, torch, case)
+    d_in = torch.from_numpy(src).cuda()
+    s0 = lrp.geometry_cache_stats()
+    for junk in (0.0, 1.5, -7.0e30, float("nan")):
+        def garbage(lens):
+            if int(lens.type) == int(lrp.LensType.EQUIRECTANGULAR):
+                return lens
+            p = list(lens.params)
+            keep = 1
+            return lrp.LensInfo(lens.type, tuple(p[:keep] + [junk] * (4 - keep)), lens.sensor_width, lens.sensor_height)
+
+        d_out = torch.full((case["oh"], case["ow"], case["c"]), -1.0, dtype=torch.float32, device="cuda")
+        lrp.reproject(lrp.Image(garbage(lin), case["iw"], case["ih"], case["c"], d_in), lrp.Image(garbage(lout), case["ow"], case["oh"], case["c"], d_out),
+                      1, 2, rot)
+        torch.cuda.synchronize()
+        assert golden_cases.digest(d_out.cpu().numpy()) == SMALL["reproject"][name]
+    s1 = lrp.geometry_cache_stats()
+    if int(lin.type) != int(lrp.LensType.EQUIRECTANGULAR) or int(lout.type) != int(lrp.LensType.EQUIRECTANGULAR):
+        assert s1["fills"] - s0["fills"] == 1 and s1["hits"] - s0["hits"] == 3, (s0, s1)
+
+
+def test_two_streams_race_on_one_geometry_with_different_pixels(lrp, oracle, torch_cuda):
+    """Single launches of ONE geometry dealt alternately to two streams — what lrp_context does with consecutive images so that
+    the tail of one launch overlaps the head of the next —: different pixels in every launch, the entry filled by the first
+    launch while the second is already enqueued on the other stream; and the same through a BatchContext with three slots
+    (two compute streams inside).  Every image against the live oracle."""
+    torch = torch_cuda
+    iw, ih, ow, oh, c = 200, 120, 147, 131, 4
+    lin, lout = lrp.LensInfo.equidistant(3.14159265), lrp.LensInfo.rectilinear(18.0, 36.0, ow, oh)
+    rot = lrp.rotation_matrix(0.3, -0.2, 0.1)
+    srcs = [cases.hash_noise(ih, iw, c, seed=0x2570 + k, planted=(k % 2 == 0)) for k in range(8)]
+    wants = [oracle.reproject(lin, s, lout, ow, oh, 1, 2, rot) for s in srcs]
+    d_ins = [torch.from_numpy(s).cuda() for s in srcs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for rnd in range(3):
+        outs = [torch.full((oh, ow, c), -12345.0, dtype=torch.float32, device="cuda") for _ in srcs]
+        torch.cuda.synchronize()
+        for k in range(8):
+            lrp.reproject(lrp.Image(lin, iw, ih, c, d_ins[k]), lrp.Image(lout, ow, oh, c, outs[k]), 1, 2, rot, stream=streams[k & 1])
+        torch.cuda.synchronize()
+        for k in range(8):
+            cases.assert_same_bits(outs[k].cpu().numpy(), wants[k], f"round {rnd}, image {k} on stream {k & 1}")
+    st = lrp.geometry_cache_stats()
+    assert st["fills"] >= 1 and st["hits"] >= 16, st
+    for streams_knob in (1, 0):
+        prev = lrp.debug_set("context_streams", streams_knob)
+        host_outs = [np.full((oh, ow, c), -1.0, dtype=np.float32) for _ in srcs]
+        with lrp.BatchContext(0, 3) as ctx:
+            for k in range(8):
+                ctx.submit(lrp.Image(lin, iw, ih, c, srcs[k]), lrp.Image(lout, ow, oh, c, host_outs[k]), 1, 2, rot)
+            ctx.wait()
+        lrp.debug_set("context_streams", prev)
+        for k in range(8):
+            cases.assert_same_bits(host_outs[k], wants[k], f"BatchContext (context_streams {streams_knob}), image {k}")

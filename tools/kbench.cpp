@@ -7,7 +7,9 @@
 //
 // Build (tools/build_kbench.sh):
 //   hipcc -O2 -std=c++17 tools/kbench.cpp -Iinclude -L<pkg>/lib -llrp_hip -Wl,-rpath,<pkg>/lib -o tools/kbench
-// Usage: kbench [--size N] [--reps R] [--warmup W] [--distinct D] [--channels C] [--ns S] [--batch B] [--geo 0|1] [--set name=value] [--sum] [workload ...]
+// Usage: kbench [--size N] [--reps R] [--warmup W] [--distinct D] [--channels C] [--ns S] [--batch B] [--geo 0|1] [--set name=value] [--sum] [--streams S] [workload ...]
+//   --streams S: launch i goes to stream i % S (no events in between); the figure is wall time per launch between the first launch and the
+//   last stream's completion — S = 1 and S = 2 compare back-to-back launches on one stream with launches whose tails and heads may overlap
 //   --batch B: every launch renders B frames (lrp_reproject_batch_device, B <= distinct); times are per launch / B
 //   --geo 0: single launches compute their coordinates in every launch (geometry cache off); --set: lrp_debug_set
 #include <hip/hip_runtime.h>
@@ -101,7 +103,7 @@ static uint64_t fnv1a(const void *p, size_t n) {
 }
 
 int main(int argc, char **argv) {
-  int size = 4096, reps = 20, distinct = 4, channels = 4, ns = 1, out_size = 0, warmup = 100, batch = 0;
+  int size = 4096, reps = 20, distinct = 4, channels = 4, ns = 1, out_size = 0, warmup = 100, batch = 0, n_streams = 0;
   bool sum = false, post = false;
   std::vector<std::string> names;
   for (int i = 1; i < argc; ++i) {
@@ -115,6 +117,7 @@ int main(int argc, char **argv) {
     else if (a == "--channels") channels = next();
     else if (a == "--ns") ns = next();
     else if (a == "--batch") batch = next();
+    else if (a == "--streams") n_streams = next();
     else if (a == "--geo") lrp_debug_set("geo_cache", next());
     else if (a == "--set" && i + 1 < argc) {
       std::string kv = argv[++i];
@@ -208,6 +211,38 @@ int main(int argc, char **argv) {
       out.data = dst[i % distinct];
       LRP_OKAY(lrp_reproject_device(&in, &out, ns, W->interp, W->has_rot ? rot : nullptr, post ? &pp : nullptr, 0, stream));
     };
+    if (n_streams > 0) { // wall time per launch over S streams
+      std::vector<hipStream_t> ss((size_t)n_streams);
+      for (auto &q : ss) HIP_OK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+      auto launch_on = [&](int i) {
+        in.data = src[i % distinct];
+        out.data = dst[i % distinct];
+        LRP_OKAY(lrp_reproject_device(&in, &out, ns, W->interp, W->has_rot ? rot : nullptr, post ? &pp : nullptr, 0, ss[(size_t)(i % n_streams)]));
+      };
+      for (int i = 0; i < warmup; ++i) launch_on(i);
+      HIP_OK(hipDeviceSynchronize());
+      float best = 1e30f;
+      for (int rep = 0; rep < 5; ++rep) {
+        HIP_OK(hipEventRecord(e0, ss[0]));
+        for (int k = 1; k < n_streams; ++k) HIP_OK(hipStreamWaitEvent(ss[(size_t)k], e0, 0));
+        for (int i = 0; i < reps; ++i) launch_on(i);
+        for (int k = 1; k < n_streams; ++k) { // join into stream 0
+          hipEvent_t j;
+          HIP_OK(hipEventCreateWithFlags(&j, hipEventDisableTiming));
+          HIP_OK(hipEventRecord(j, ss[(size_t)k]));
+          HIP_OK(hipStreamWaitEvent(ss[0], j, 0));
+          HIP_OK(hipEventDestroy(j));
+        }
+        HIP_OK(hipEventRecord(e1, ss[0]));
+        HIP_OK(hipEventSynchronize(e1));
+        float ms;
+        HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+      }
+      printf("%-18s %d streams: %8.1f us per launch (best of 5 runs of %d launches)\n", W->name, n_streams, best * 1e3 / reps, reps);
+      for (auto &q : ss) HIP_OK(hipStreamDestroy(q));
+      continue;
+    }
     if (batch > 0 && warmup > 100 / batch) warmup = 100 / batch + 2;
     // ~20 ms of back-to-back launches first: the chip settles its clock over ~10 ms of load
     for (int i = 0; i < warmup; ++i) launch(i);

@@ -8,7 +8,8 @@ The probe therefore launches a calibration kernel with known traffic in front of
 (stand-alone post_process on a 4096^2 RGBA frame: 268435456 B read, 268435456 B written) and the
 read-side factor measured on it is applied to the reprojection kernels.  The dispatches are
 attributed to workloads by their ORDER (tools/traffic_probe.py writes it): the calibration
-launches separate them; the first frames of each group are dropped."""
+launches separate the groups — warm-up groups are skipped, a measured group is the sum of ALL its dispatches (window
+launches, fill launches, merged multi-output launches) divided by its frames."""
 import collections
 import csv
 import glob
@@ -22,7 +23,7 @@ import bench  # noqa: E402  (kernel_source_sha: the stamp bench.py checks before
 src_dir, out_path = sys.argv[1], sys.argv[2]
 KNOWN = 4096 * 4096 * 4 * 4
 order = json.load(open(os.path.join(src_dir, "order.json")))
-SKIP = ("build_tables_kernel", "build_xsep_kernel", "synth_fill_kernel", "checksum_kernel", "__amd_rocclr")
+SKIP = ("build_tables_kernel", "build_xsep_kernel", "synth_fill_kernel", "checksum_kernel", "__amd_rocclr", "geo_build_lists_kernel")
 
 
 def dispatches(counter, pass_dir=None, scale=1024.0):
@@ -48,12 +49,13 @@ def per_workload(counter, pass_dir=None, scale=1024.0):
             cur.append((k, v))
     out = {}
     for o, g in zip(order, groups):
-        lpf, frames, drop = o["launches_per_frame"], o["frames"], o.get("drop", 1)
-        if len(g) != lpf * frames:
-            out[o["workload"]] = None  # the launch sequence is not what the probe says: do not guess
+        if o["workload"] is None:  # a warm-up group
             continue
-        kept = g[lpf * drop:]  # drop the first frame(s): table builds, the launch that fills the geometry cache
-        out[o["workload"]] = (sum(v for _k, v in kept) / (frames - drop), sorted({k for k, _v in kept}), frames - drop)
+        frames = o["frames"]
+        if not g or len(groups) != len(order):
+            out[o["workload"]] = None  # the dispatch sequence is not what the probe says: do not guess
+            continue
+        out[o["workload"]] = (sum(v for _k, v in g) / frames, sorted({k for k, _v in g}), frames, len(g) / frames)
     return (sum(cal) / len(cal) if cal else None), out
 
 
@@ -85,16 +87,20 @@ if glob.glob(os.path.join(src_dir, "RDREQ", "**", "*counter_collection.csv"), re
     cal_rq = request_bytes(lambda p: p[0])
     result["_calibration"]["read_requests_by_size"] = cal_rq
     for o in order:
+        if o["workload"] is None:
+            continue
         rq = request_bytes(lambda p, wl=o["workload"]: (p[1].get(wl) or (None,))[0])
         if rq:
             by_size[o["workload"]] = rq
 for o in order:
     wl = o["workload"]
+    if wl is None:
+        continue
     f, w = fetch.get(wl), write.get(wl)
     if not f or not w:
         continue
     rd, wr = f[0] * read_factor, w[0]
-    result[wl] = {"kernels": f[1], "frames_averaged": f[2], "launches_per_frame": o["launches_per_frame"], "FETCH_SIZE_bytes_raw": f[0],
+    result[wl] = {"kernels": f[1], "frames_averaged": f[2], "launches_per_frame": f[3], "FETCH_SIZE_bytes_raw": f[0],
                   "WRITE_SIZE_bytes_raw": w[0], "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
     if wl in by_size:
         result[wl]["read_requests_by_size"] = by_size[wl]
