@@ -73,13 +73,16 @@ WORKLOADS = {
     # the same mapping, RGBA, no tonemap
     "rect_to_equirect_bicubic": dict(in_lens="rect", out_lens="eqr", interp=2, rot=(0.0, 0.0, 0.0), channels=4,
                                      size=4096),
+    # the reference's --samples 2 on the down-scale its README asks it for (src/reproject.cpp:294-298): 4096^2 -> 2048^2, four
+    # sub-samples per pixel through the window kernel's SS instantiations
+    "fisheye_to_rect_bicubic_half_ns2": dict(in_lens="eqd", out_lens="rect", interp=2, rot=None, channels=4, size=4096, out_size=2048, ns=2),
     # BASELINE.json configs[4]: one 8192^2 RGB panorama -> six 2048^2 rectilinear faces, bicubic; a "frame" is a cubemap
     "cubemap_8k_rgb": dict(in_lens="eqr", out_lens="rect", interp=2, channels=3, size=8192, out_size=2048,
                            faces=[(0.0, 0.0, 0.0), (90.0, 0.0, 0.0), (180.0, 0.0, 0.0), (270.0, 0.0, 0.0), (0.0, 90.0, 0.0),
                                   (0.0, -90.0, 0.0)], rot=None),
 }
 DEFAULT_SECONDARY = ("equirect_to_rect_bicubic,equirect_to_rect_bicubic_rot,equirect_to_fisheye_bilinear,"
-                     "equirect_to_fisheye_bicubic_rot,rect_to_equirect_bicubic_rgbaz_post,cubemap_8k_rgb")
+                     "equirect_to_fisheye_bicubic_rot,rect_to_equirect_bicubic_rgbaz_post,cubemap_8k_rgb,fisheye_to_rect_bicubic_half_ns2")
 INTERP_NAMES = {0: "nearest", 1: "bilinear", 2: "bicubic"}
 KERNEL_NAMES = {0: "reproject_tile_kernel (nearest)", 1: "reproject_tile_kernel (bilinear)",
                 2: "reproject_bicubic_win_kernel (LDS window)"}
@@ -184,7 +187,7 @@ def cpu_baseline(pkg, wl, seconds_target):
             left = rows
             while left > 0:
                 n = min(left, size)
-                L.lrpo_reproject_rows(ctypes.byref(cin), ctypes.byref(cout), 1, wl["interp"], rp, 0, n)
+                L.lrpo_reproject_rows(ctypes.byref(cin), ctypes.byref(cout), wl.get("ns", 1), wl["interp"], rp, 0, n)
                 left -= n
             done[t] = time.perf_counter()
 
@@ -332,6 +335,7 @@ def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_
     out_size = dsts[0][0].shape[0]
     lin, lout = make_lens(pkg, wl["in_lens"], size, size), make_lens(pkg, wl["out_lens"], out_size, out_size)
     post = wl.get("post")
+    ns = wl.get("ns", 1)
     faces = wl.get("faces")
     n_res = len(srcs)
     im_in = [pkg.Image(lin, size, size, c, s) for s in srcs]
@@ -343,7 +347,7 @@ def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_
         nb = 1
 
         def batched(i):
-            pkg.reproject_multi(im_in[i % n_res], im_out[i % n_res], 1, wl["interp"], rots, post=post, stream=stream)
+            pkg.reproject_multi(im_in[i % n_res], im_out[i % n_res], ns, wl["interp"], rots, post=post, stream=stream)
 
         single = batched
     else:
@@ -352,10 +356,10 @@ def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_
 
         def batched(i):
             ids = [(i * nb + k) % n_res for k in range(nb)]
-            pkg.reproject_batch([im_in[j] for j in ids], [im_out[j][0] for j in ids], 1, wl["interp"], rot, post=post, stream=stream)
+            pkg.reproject_batch([im_in[j] for j in ids], [im_out[j][0] for j in ids], ns, wl["interp"], rot, post=post, stream=stream)
 
         def single(i):
-            pkg.reproject(im_in[i % n_res], im_out[i % n_res][0], 1, wl["interp"], rot, post=post, stream=stream)
+            pkg.reproject(im_in[i % n_res], im_out[i % n_res][0], ns, wl["interp"], rot, post=post, stream=stream)
 
     if timed_region_ms:  # the headline workload: the launches of the timed region itself
         b_avg, b_min = sum(timed_region_ms) / len(timed_region_ms), min(timed_region_ms)
@@ -376,9 +380,9 @@ def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_
 
     def single_on(i, st):
         if faces:
-            pkg.reproject_multi(im_in[i % n_res], im_out[i % n_res], 1, wl["interp"], rots, post=post, stream=st)
+            pkg.reproject_multi(im_in[i % n_res], im_out[i % n_res], ns, wl["interp"], rots, post=post, stream=st)
         else:
-            pkg.reproject(im_in[i % n_res], im_out[i % n_res][0], 1, wl["interp"], rot, post=post, stream=st)
+            pkg.reproject(im_in[i % n_res], im_out[i % n_res][0], ns, wl["interp"], rot, post=post, stream=st)
 
     def two_stream_us(reps=64):
         best = None
@@ -561,7 +565,7 @@ def main():
     batch_out = [im_out[k % n_res] for k in range(len(shard))]
     launches_per_step = len(shard) if args.per_frame_launches else -(-len(shard) // FRAMES_PER_LAUNCH)
     # the frames of a step share one geometry: one launch per 16 frames, descriptors marshalled once
-    groups = [pkg.PreparedBatch(batch_in[k:k + FRAMES_PER_LAUNCH], batch_out[k:k + FRAMES_PER_LAUNCH], 1, wl["interp"], rot, post=post)
+    groups = [pkg.PreparedBatch(batch_in[k:k + FRAMES_PER_LAUNCH], batch_out[k:k + FRAMES_PER_LAUNCH], wl.get("ns", 1), wl["interp"], rot, post=post)
               for k in range(0, len(shard), FRAMES_PER_LAUNCH)] if not args.per_frame_launches else []
     # HIP events around every launch of the timed region, on the stream it is launched on (roofline.achieved)
     events = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in groups]
@@ -570,7 +574,7 @@ def main():
     def step(timed=None):
         if args.per_frame_launches:
             for k in range(len(shard)):
-                pkg.reproject(batch_in[k], batch_out[k], 1, wl["interp"], rot, post=post, stream=streams[k % len(streams)])
+                pkg.reproject(batch_in[k], batch_out[k], wl.get("ns", 1), wl["interp"], rot, post=post, stream=streams[k % len(streams)])
             return
         for gi, g in enumerate(groups):
             if timed is not None:

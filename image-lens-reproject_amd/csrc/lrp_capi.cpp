@@ -183,7 +183,7 @@ lrp::KParams make_params(const lrp_image *in, const lrp_image *out, int num_samp
 // initial values, once, when the library is loaded — nothing on a launch path calls getenv.
 //   kernel: 0 = pixel kernel, 1 = tile kernel everywhere, 2 (default) = tile kernel with the LDS-window kernel for
 //   bicubic, 3 = the same without its shared-coefficient tier and without any work sharing.  All HIP; there is no CPU path.
-enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobGeoBig, kKnobGeoLists, kKnobGeoFillStream, kKnobGeoFillFused, kKnobMultiMerge, kKnobContextStreams, kKnobListedLaunches, kKnobMergedLaunches, kKnobCount };
+enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobGeoBig, kKnobGeoLists, kKnobGeoFillStream, kKnobGeoFillFused, kKnobMultiMerge, kKnobContextStreams, kKnobWinSS, kKnobListedLaunches, kKnobMergedLaunches, kKnobCount };
 struct KnobSpec {
   const char *name, *env;
   int lo, hi, initial;
@@ -212,6 +212,7 @@ const KnobSpec kKnobs[kKnobCount] = {
     {"geo_fill_fused", "LRP_GEO_FILL_FUSED", 0, 1, 1}, // the corner runs of a listed launch as a share per wavefront of the window kernel (0: always the fill kernel)
     {"multi_merge", "LRP_MULTI_MERGE", 0, 1, 1},     // lrp_reproject_multi_device: the outputs whose geometry-cache entries exist in ONE launch; 0: a launch per output
     {"context_streams", "LRP_CONTEXT_STREAMS", 0, 1, 1}, // lrp_context: consecutive images alternate between two compute streams (0: one)
+    {"win_ss", "LRP_WIN_SS", 0, 1, 1},              // bicubic with num_samples == 2 through the window kernel's supersampling instantiations (0: the tile kernel, as for any other num_samples > 1)
     {"listed_launches", "LRP_LISTED_LAUNCHES_UNUSED", 0, 0, 0}, // a counter, not a switch: launches rendered by block class so far (set 0 to reset; tests, bench)
     {"merged_launches", "LRP_MERGED_LAUNCHES_UNUSED", 0, 0, 0}, // a counter: multi-output launches so far
 };
@@ -366,8 +367,10 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     // 84.2, equirect -> fisheye rotated 127.4 -> 118.6 with plain pixels + frames instead of mirrored pixels / rays).
     const bool batch_plain = n_batch >= 4 && interpolation != LRP_BICUBIC && num_samples == 1;
     if (P.quad && batch_plain) P.quad = 0;
-    const bool window = interpolation == LRP_BICUBIC && kernel_choice() >= 2 && num_samples == 1 &&
+    // (num_samples == 2 — the reference's --samples 2 — has its own instantiations: plain blocks, no mirror mode, no cache)
+    const bool window = interpolation == LRP_BICUBIC && kernel_choice() >= 2 && (num_samples == 1 || (num_samples == 2 && knob(kKnobWinSS) != 0)) &&
                         (out->channels == 4 || out->channels == 3 || out->channels == 5);
+    const bool window1 = window && num_samples == 1;
     // Equidistant target, rotated (or an equirectangular source): the four mirror pixels still
     // share the ray through the output lens (tile kernels only).
     if (!band && !P.quad && !window && !batch_plain && quad_enabled() && kernel_choice() != 3 && num_samples == 1 &&
@@ -383,10 +386,10 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     // still share the ray through the output lens
     // (not for a batch: its wavefronts share ALL of the coordinate math between up to 16 frames on plain blocks at
     // four wavefronts per SIMD — equirect -> fisheye rotated 143 us against 147 with shared rays at three)
-    if (window && P.win_mode == 0 && !band && quad_enabled() && mirror_modes_enabled() && kernel_choice() != 3 &&
+    if (window1 && P.win_mode == 0 && !band && quad_enabled() && mirror_modes_enabled() && kernel_choice() != 3 &&
         out->lens.type == LRP_FISHEYE_EQUIDISTANT && n_batch < 4)
       P.win_mode = 4;
-    if (window && P.win_mode == 0 && !band && quad_enabled() && mirror_modes_enabled() && kernel_choice() != 3 && P.has_rot) {
+    if (window1 && P.win_mode == 0 && !band && quad_enabled() && mirror_modes_enabled() && kernel_choice() != 3 && P.has_rot) {
       const float *R = P.rot;
       auto tiny = [](float v) { return !(std::fabs(v) >= 0x1p-20f); }; // (also true for a NaN)
       if (P.xsep_tab != nullptr && (symmetry & 2) && R[3] == 0.0f && R[5] == 0.0f && !tiny(R[4]))
@@ -421,7 +424,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     // batched nearest keeps the frame loop (69.4 against 72.9 us).
     const bool tile_single = !window && interpolation != LRP_BICUBIC && num_samples == 1 && (n_batch <= 0 || interpolation == LRP_BILINEAR) &&
                              !(interpolation == LRP_NEAREST && P.quad != 0) && !cheap_coordinates;
-    if ((window || tile_single) && !band && kernel_choice() == 2 && knob(kKnobGeoCache) != 0) {
+    if ((window1 || tile_single) && !band && kernel_choice() == 2 && knob(kKnobGeoCache) != 0) {
       lrp::GeoKey key;
       std::memset(&key, 0, sizeof(key));
       key.device = device;
@@ -431,7 +434,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
       key.has_rot = P.has_rot;
       key.out_lens = lrp::geo_canonical_lens(P.out_lens, out->lens.type), key.in_lens = lrp::geo_canonical_lens(P.in_lens, in->lens.type);
       if (P.has_rot) std::memcpy(key.rot, P.rot, sizeof(key.rot));
-      if (merge != nullptr && window && n_batch <= 0 && knob(kKnobMultiMerge) != 0 && lrp::geo_peek(key, true)) {
+      if (merge != nullptr && window1 && n_batch <= 0 && knob(kKnobMultiMerge) != 0 && lrp::geo_peek(key, true)) {
         merge->ready = true;
         merge->P = P;
         merge->P.col_tab = merge->P.row_tab = merge->P.xsep_tab = nullptr; // (the kernels that read the cache use no table; the lease ends here)
@@ -440,7 +443,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
         merge->in_mode = im;
         return LRP_OK;
       }
-      lrp::geo_acquire(key, window, stream, &geo);
+      lrp::geo_acquire(key, window1, stream, &geo);
       if (geo.mode != 0) {
         P.geo_mode = geo.mode;
         P.geo_xy = geo.xy;

@@ -83,7 +83,13 @@ __device__ unsigned g_tier_stats[8]; // coefficient, raw, direct, corner, beyond
 // the plain-block instantiation (P.geo_mode == 1) the first time a geometry is rendered; the loaded values are the
 // stored ones, so the rendered bits are the same.  No lens math is compiled in: the output lens is irrelevant (kRect by
 // convention), plain blocks only.
-template <int OutLens, int InMode, int QMode, int CH, bool Frames = false, bool GeoRead = false>
+// SS: the supersampling instantiation, num_samples == 2 (the reference's --samples 2, src/reproject.cpp:294-298, what its README
+// asks for when an image is scaled down by two).  A block is 16 x 4 OUTPUT pixels, a lane owns one of them, and the four
+// "passes" of the block are the pixel's four sub-samples in the reference's order (k = 2 ssx + ssy): the window is the bounding
+// box of all of them, every pass samples it like a pass of an ordinary block, the samples are summed in registers in that order
+// (0.0f + s0 + s1 + s2 + s3, :334-336) and pass 3 stores sum * 0.25f (:338-341).  Plain blocks that compute their coordinates;
+// no geometry cache (its map holds one coordinate pair per pixel), no frame loop.
+template <int OutLens, int InMode, int QMode, int CH, bool Frames = false, bool GeoRead = false, bool SS = false>
 #ifndef LRP_WIN_MINWAVES5
 #define LRP_WIN_MINWAVES5 3 // RGBAZ: 168 VGPRs (the 80 registers of a direct-path tap set do not fit 128 without spilling)
 #endif
@@ -113,6 +119,8 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   constexpr int kAllMirrors = (MirX ? 1 : 0) | (MirY ? 2 : 0); // the image mirrored in every mirrored axis
   using WinBlock = WinBlockT<Quad>;
   static_assert(CH == 3 || CH == 4 || CH == 5, "window kernel: RGB, RGBA or RGBAZ");
+  static_assert(!SS || (QMode == 0 && !Frames && !GeoRead), "supersampling: plain blocks that compute their coordinates");
+  constexpr int kBlockRows = SS ? kPassRows : kBlkH; // output rows of a block (SS: the four passes are the sub-samples of ONE row group)
   static_assert(QMode != 2 || (OutLens != kEquidistant && InMode != kInEquidistant), "rows-only mirroring goes through the column-separable source x");
   static_assert(QMode != 3 || OutLens == kRect, "columns-only mirroring needs vz == -1");
   static_assert(!GeoRead || (QMode == 0 && (OutLens == kRect || (OutLens == kEquirect && InMode == kInRect && !Frames))),
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   constexpr bool kBigWin = GeoRead && OutLens == kEquirect;
   constexpr int kCap = kBigWin ? (CH == 5 ? LRP_WIN_CAP_BIG5 : LRP_WIN_CAP_BIG) : kWinCap; // 16-byte slots of this instantiation's window buffer
   constexpr int kMaxPassCols = kBigWin ? 128 : 64;          // widest pass window (texels): DMA instructions per window row = ceil(bw / 64)
-  constexpr bool kGeoWrite = !GeoRead && !Frames && QMode == 0 && kWinWaves == 1; // (P.geo_mode == 1: the side output)
+  constexpr bool kGeoWrite = !GeoRead && !Frames && QMode == 0 && kWinWaves == 1 && !SS; // (P.geo_mode == 1: the side output)
   const bool geo_write = kGeoWrite && (Pk.geo_mode == 1 || Pk.geo_mode == 3) && blockIdx.y == 0; // wave-uniform (3: the extremes only — the map is there; a batched launch: its first frame writes)
   // Frames of a batched launch share one geometry: the source coordinates of a pixel, the window of a block and its tier
   // are the same in every frame.  A wavefront therefore renders its strip for `frames_per_wave` consecutive frames
@@ -290,7 +298,9 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   int prow, pcol; // this lane's pixel of a pass
   win_lane_pixel(lane, prow, pcol);
   const int x = tx * (kBlkW * kWinWaves) + wave * kBlkW + pcol;
-  const int y_lane = P.y_offset + ty * (quad ? kBlkH : kBlkH * Gs) + prow; // + kBlkH * g + kPassRows * pass
+  const int y_lane = P.y_offset + ty * (quad ? kBlkH : kBlockRows * Gs) + prow; // + kBlockRows * g + kPassRows * pass
+  // output row of this lane's pixel in pass k of strip block g (plain blocks; SS: every pass is the same pixel)
+  auto pixel_row = [&](int g, int k) { return y_lane + (quad ? 0 : kBlockRows * block_row(g)) + (SS ? 0 : kPassRows * k); };
   const int xe = x < qw ? x : qw - 1;
   const int in_w = P.in_w;
   SrcView src = source_view<2, CH>(P);
@@ -308,7 +318,8 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   }
   ColTerms col{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   if constexpr (!GeoRead) col = column_terms<OutLens>(P, xe, 0);
-  ColTerms col_m = col; // the mirrored column
+  ColTerms col_m = col; // the mirrored column (SS: the column's second horizontal sub-sample)
+  if constexpr (SS) col_m = column_terms<OutLens>(P, xe, 1);
   if constexpr (MirX && !kSharedRays) col_m = column_terms<OutLens>(P, P.out_w - 1 - xe, 0);
   // Stage-1 results of the four quadrant pixels of this lane, kept for the whole strip:
   //   rectilinear / equidistant source: (qa, qb) = plane coordinates (u, v); a mirror image negates them;
@@ -432,8 +443,8 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     if (!quad || g == 0) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int yk = y_lane + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
-        row_v[k] = row_term<OutLens>(P, yk < qh ? yk : qh - 1, 0);
+        const int yk = pixel_row(g, k);
+        row_v[k] = row_term<OutLens>(P, yk < qh ? yk : qh - 1, SS ? (k & 1) : 0);
       }
     }
     if (quad && g == 0) {
@@ -500,12 +511,14 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     // for the whole kernel: 80-100 MB of scratch traffic per 4K frame.  Opaque here, those few multiplies run per block.)
     ColTerms col_g = col;
     if constexpr (!Quad && LRP_OPAQUE_COL != 0) asm volatile("" : "+v"(col_g.a), "+v"(col_g.b), "+v"(col_g.nx), "+v"(col_g.nz), "+v"(col_g.sx));
+    ColTerms col_s = col_m; // SS: sub-samples 2, 3 (ssx == 1)
+    if constexpr (SS && LRP_OPAQUE_COL != 0) asm volatile("" : "+v"(col_s.a), "+v"(col_s.b), "+v"(col_s.nx), "+v"(col_s.nz), "+v"(col_s.sx));
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int yk = y_lane + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
+      const int yk = pixel_row(g, k);
       const int ye = yk < qh ? yk : qh - 1;
       if (!quad)
-        pixel_source_rt<OutLens, InMode>(P, col_g, row_v[k], ye, 0, b.sx[k], b.sy[k]);
+        pixel_source_rt<OutLens, InMode>(P, (SS && k >= 2) ? col_s : col_g, row_v[k], ye, SS ? (k & 1) : 0, b.sx[k], b.sy[k]);
       else
         quad_xy(gm, k, b.sx[k], b.sy[k]);
       note_pixel(e, k, b.sx[k], b.sy[k]);
@@ -855,14 +868,14 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     // strip — which spilled — so the row is re-derived from an opaque copy here: an add and a min per pass)
     int y_base = y_lane;
     asm volatile("" : "+v"(y_base)); // (likewise not hoisted out of the frame loop)
-    const int yk = y_base + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
+    const int yk = y_base + (quad ? 0 : kBlockRows * block_row(g)) + (SS ? 0 : kPassRows * k);
     const int yc = yk < qh ? yk : qh - 1;
     const int gm = image_of(g);
     PassOut o;
     o.xo = (quad && (gm & 1)) ? P.out_w - 1 - xe : xe; // mirrored blocks write the mirrored pixel
     o.yo = (quad && (gm >> 1)) ? P.out_h - 1 - yc : yc;
     const int x_blk = tx * (kBlkW * kWinWaves) + wave * kBlkW;
-    const int y_top = P.y_offset + ty * (quad ? kBlkH : kBlkH * Gs) + (quad ? 0 : kBlkH * block_row(g)) + kPassRows * k;
+    const int y_top = P.y_offset + ty * (quad ? kBlkH : kBlockRows * Gs) + (quad ? 0 : kBlockRows * block_row(g)) + (SS ? 0 : kPassRows * k);
     o.whole = x_blk + kBlkW <= qw && y_top + kPassRows <= qh;
     o.mxo = quad && (gm & 1);
     const bool myo = quad && (gm >> 1);
@@ -870,7 +883,18 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     o.row_step = myo ? -P.out_w : P.out_w;
     return o;
   };
+  Px<CH> ss_sum = px_zero<CH>(); // SS: the running sum of this lane's pixel over the passes (= sub-samples) of the block
   auto emit = [&](int g, int k, const Rgba &s, auto as_runs, bool runs_rt = true) {
+    if constexpr (SS) { // src/reproject.cpp:334-341: acc = 0.0f; acc += sample (ssx outer, ssy inner); dst = acc * normalize
+      if (k == 0)
+        ss_sum = accumulate(s);
+      else
+        px_add<CH>(ss_sum, Px<CH>{s.lo, CH >= 4 ? s.hi : f2{0.0f, 0.0f}, CH == 3 ? s.hi.x : s.e});
+      if (k != 3) return;
+      const PassOut o = pass_out(g, k);
+      store_px<CH, false>(P, (uint32_t)o.yo * (uint32_t)P.out_w + (uint32_t)o.xo, ss_sum);
+      return;
+    }
     const Px<CH> a = accumulate(s);
     const PassOut o = pass_out(g, k);
 #if defined(LRP_NO_STORE) // timing experiment: almost no output traffic
@@ -898,8 +922,17 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   // lies in the image whole leaves as 80 sixteen-byte chunks of the repeating five-float pattern straight from registers (no
   // exchange through the LDS).  `before_last` runs in front of the last store (the next window's request).
   auto emit_corner = [&](int g, const Rgba &s, auto before_last) {
-    const Px<CH> a = accumulate(s);
+    Px<CH> a = accumulate(s);
     float c[5];
+    if constexpr (SS) { // four equal sub-samples summed like any others, one store (the block is one pass of pixels)
+#pragma unroll
+      for (int i = 1; i < 4; ++i) px_add<CH>(a, Px<CH>{s.lo, CH >= 4 ? s.hi : f2{0.0f, 0.0f}, CH == 3 ? s.hi.x : s.e});
+      finish_px<CH, false>(P, a, c);
+      before_last();
+      const PassOut o = pass_out(g, 3);
+      store_texel_nt<CH>(P.dst + (size_t)((uint32_t)o.yo * (uint32_t)P.out_w + (uint32_t)o.xo) * CH, c);
+      return;
+    }
     finish_px<CH, true>(P, a, c);
     typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
     v4f_a4 q0{0.0f, 0.0f, 0.0f, 0.0f}, q1{0.0f, 0.0f, 0.0f, 0.0f};
@@ -1159,12 +1192,30 @@ template <int CH> struct WinGeoKernelTable {
   }
 };
 
-// num_samples must be 1 (the pipeline keeps no accumulator across sub-samples).  QMode != 0: P.win_mode == QMode,
-// set by the host only for cells where the mode exists.  GeoRead: P.geo_mode == 2, a single whole-image launch.
-template <int QMode, int CH, bool GeoRead = false>
+// The supersampling instantiations (num_samples == 2): plain blocks, one per (output lens, source mode) cell.
+template <int CH> struct WinSSKernelTable {
+  static TileKernelFn get(int out_idx, int in_mode) {
+    static const TileKernelFn table[3][4] = {
+        {reproject_bicubic_win_kernel<kRect, kInRect, 0, CH, false, false, true>, reproject_bicubic_win_kernel<kRect, kInEquidistant, 0, CH, false, false, true>,
+         reproject_bicubic_win_kernel<kRect, kInEquirect, 0, CH, false, false, true>, reproject_bicubic_win_kernel<kRect, kInEquirectLoop, 0, CH, false, false, true>},
+        {reproject_bicubic_win_kernel<kEquidistant, kInRect, 0, CH, false, false, true>, reproject_bicubic_win_kernel<kEquidistant, kInEquidistant, 0, CH, false, false, true>,
+         reproject_bicubic_win_kernel<kEquidistant, kInEquirect, 0, CH, false, false, true>, reproject_bicubic_win_kernel<kEquidistant, kInEquirectLoop, 0, CH, false, false, true>},
+        {reproject_bicubic_win_kernel<kEquirect, kInRect, 0, CH, false, false, true>, reproject_bicubic_win_kernel<kEquirect, kInEquidistant, 0, CH, false, false, true>,
+         reproject_bicubic_win_kernel<kEquirect, kInEquirect, 0, CH, false, false, true>, reproject_bicubic_win_kernel<kEquirect, kInEquirectLoop, 0, CH, false, false, true>}};
+    return table[out_idx][in_mode];
+  }
+};
+
+// num_samples must be 1 — or 2 for the SS launcher (the pipeline keeps ONE pixel's sum across the four passes of a block).
+// QMode != 0: P.win_mode == QMode, set by the host only for cells where the mode exists.  GeoRead: P.geo_mode == 2, a single
+// whole-image launch.
+template <int QMode, int CH, bool GeoRead = false, bool SS = false>
 inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, hipStream_t stream) {
   static_assert(!GeoRead || QMode == 0, "the geometry cache feeds plain blocks");
+  static_assert(!SS || (QMode == 0 && !GeoRead), "supersampling: plain blocks that compute");
   if (GeoRead && (P.geo_mode != 2 || P.y_offset != 0 || P.y_end != P.out_h)) return hipErrorInvalidValue;
+  if (P.num_samples != (SS ? 2 : 1) || (SS && P.geo_mode != 0)) return hipErrorInvalidValue;
+  constexpr int kRowsPerBlock = SS ? kPassRows : kBlkH; // output rows of a block
   const int rows = P.y_end - P.y_offset;
   if (QMode != 0) {
     // the launch enumerates the top-left quadrant (the top / the left half when one axis is mirrored); a wavefront
@@ -1177,8 +1228,8 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
   } else {
     P.tiles_x = (P.out_w + kBlkW * kWinWaves - 1) / (kBlkW * kWinWaves);
     // strips of LRP_WIN_STRIP blocks when that still leaves >= 8 workgroups per CU, else shorter
-    const int row_blocks = (rows + kBlkH - 1) / kBlkH;
-    int G = LRP_WIN_STRIP;
+    const int row_blocks = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
+    int G = SS ? 4 : LRP_WIN_STRIP; // (SS: a block is four rows of pixels; strips of sixteen rows like everybody's)
     if (GeoRead && P.blocks_per_wave > 0) G = std::min(P.blocks_per_wave, kGeoStripRows); // the caller's override (lrp_debug_set "geo_strip")
     // (a batch whose wavefronts walk several frames pipelines the windows of one block across its frames: one block per
     // wavefront measured 2-3 % faster there — equirect -> fisheye rotated 143 -> 139 us, rect -> rect 130.5 -> 128 —, four 5 % slower)
@@ -1193,6 +1244,7 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
     const int n_faces = (GeoRead && P.face_n > 0) ? P.face_n : 1;
     while (!strip_forced && G > 1 && (long long)P.tiles_x * kWinWaves * ((row_blocks + G - 1) / G) * n_faces < min_waves) G >>= 1;
     if (GeoRead && P.geo_work != nullptr && in_mode != kInRect) return hipErrorInvalidValue; // (lists: the rectilinear source's instantiations)
+    if (GeoRead && n_faces > 1 && !strip_forced) G = 1; // (a multi-output launch has wavefronts enough; 8192^2 -> six 2048^2 faces: 364 us against 370-392 with strips of two)
     if (GeoRead && P.geo_work != nullptr) G = 1; // a listed launch: one block per wavefront, the blocks of the work list only
     P.blocks_per_wave = G;
     P.tiles_y = (row_blocks + G - 1) / G;
@@ -1212,11 +1264,14 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
     if (out_idx == 2 && in_mode == kInRect) F = 1;
     if (frames_override > 0) F = std::max(1, std::min(P.batch_n, frames_override)); // the caller's override (lrp_debug_set "batch_frames": A/B runs, tests)
     if (P.geo_mode == 1 || P.geo_mode == 3) F = 1; // the launch that writes a geometry-cache entry: the instantiations without the frame loop have the side output
+    if (SS) F = 1;
     P.frames_per_wave = F;
     groups = (P.batch_n + F - 1) / F;
   }
   TileKernelFn fn;
-  if constexpr (GeoRead)
+  if constexpr (SS)
+    fn = WinSSKernelTable<CH>::get(out_idx, in_mode);
+  else if constexpr (GeoRead)
     fn = P.frames_per_wave > 1 ? WinGeoFramesKernelTable<CH>::get(in_mode) : WinGeoKernelTable<CH>::get(in_mode, P.big_windows != 0);
   else
     fn = P.frames_per_wave > 1 ? WinKernelTable<QMode, CH, true>::get(out_idx, in_mode) : WinKernelTable<QMode, CH, false>::get(out_idx, in_mode);

@@ -50,6 +50,14 @@ SETTINGS = {
     "multi_fork0": {"geo_cache": 0, "multi_fork": 0},
     "multi_fork3": {"geo_cache": 0, "multi_fork": 3},
     "multi_fork3_geo": {"geo_cache": 1, "multi_fork": 3},
+    # rendering by block class (round 5): never / whenever the lists of an entry are known, the corner runs by the fill kernel
+    # instead of a share per wavefront, that kernel on a side stream
+    "geo_lists0": {"geo_cache": 1, "geo_lists": 0},
+    "geo_lists2": {"geo_cache": 1, "geo_lists": 2},
+    "geo_lists2_fill_kernel": {"geo_cache": 1, "geo_lists": 2, "geo_fill_fused": 0},
+    "geo_lists2_fill_stream": {"geo_cache": 1, "geo_lists": 2, "geo_fill_fused": 0, "geo_fill_stream": 1},
+    "multi_merge0": {"geo_cache": 1, "multi_merge": 0},  # (lrp_reproject_multi_device: a launch per output)
+    "win_ss0": {"geo_cache": 0, "win_ss": 0},  # (bicubic with num_samples == 2 through the tile kernel)
 }
 FRAMES = ["config1_4k_eqd_rect_bc", "config3_4k_rgbaz_rect_eqr_bc_post", "4k_eqr_rect_bc_rot", "config4_8k_rgb_face4"]
 
@@ -82,7 +90,8 @@ class _DeviceSynth:
 
 
 def test_switch_names_and_ranges(lrp):
-    for name in ("kernel", "xsep", "quad", "mirror_modes", "win_edge", "win_split", "batch_frames", "multi_fork", "geo_cache", "geo_strip", "geo_big"):
+    for name in ("kernel", "xsep", "quad", "mirror_modes", "win_edge", "win_split", "batch_frames", "multi_fork", "geo_cache", "geo_strip", "geo_big",
+                 "geo_lists", "geo_fill_fused", "geo_fill_stream", "multi_merge", "context_streams", "win_ss"):
         now = lrp.debug_set(name, -1)
         assert lrp.debug_set(name, now) == now  # setting the current value returns it
         assert lrp.debug_set(name, 10 ** 6) == now and lrp.debug_set(name, -1) == now  # out of range: a query
@@ -111,6 +120,7 @@ def test_small_matrix_under_setting(lrp, torch_cuda, setting):
                 for d in d_outs:
                     lrp.reproject(lrp.Image(lin, case["iw"], case["ih"], case["c"], d_ins[0]),
                                   lrp.Image(lout, case["ow"], case["oh"], case["c"], d), case["ns"], case["interp"], rot)
+                    torch.cuda.synchronize()  # (the block lists of an entry are known once the launch that filled it has completed)
             torch.cuda.synchronize()
             for i, d in enumerate(d_outs):
                 assert golden_cases.digest(d.cpu().numpy()) == SMALL["reproject"][name], f"{setting}: {name} (output {i})"
@@ -131,6 +141,7 @@ def _frame(lrp, torch, case, batched):
     else:
         for o in outs:
             lrp.reproject(lrp.Image(lin, n, n, c, d_in), lrp.Image(lout, m, m, c, o), 1, case["interp"], rot, post=post)
+            torch.cuda.synchronize()  # (the block lists of an entry are known once the launch that filled it has completed)
     torch.cuda.synchronize()
     return outs
 
@@ -149,7 +160,7 @@ def test_whole_frames_under_setting(lrp, torch_cuda, setting):
             torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("setting", ["multi_fork0", "multi_fork3", "multi_fork3_geo", "defaults", "geo_cache"])
+@pytest.mark.parametrize("setting", ["multi_fork0", "multi_fork3", "multi_fork3_geo", "defaults", "geo_cache", "multi_merge0"])
 def test_cubemap_through_multi_under_setting(lrp, torch_cuda, setting):
     """BASELINE configs[4]: the six faces of an 8192^2 RGB panorama in ONE lrp_reproject_multi_device call, twice."""
     torch = torch_cuda
@@ -163,7 +174,11 @@ def test_cubemap_through_multi_under_setting(lrp, torch_cuda, setting):
     with _Knobs(lrp, SETTINGS[setting]):
         for rnd in range(2):
             outs = [torch.full((m, m, c), -1.0, dtype=torch.float32, device="cuda") for _ in names]
+            merged = lrp.debug_set("merged_launches", -1)
             lrp.reproject_multi(lrp.Image(lin, n, n, c, d_in), [lrp.Image(lout, m, m, c, o) for o in outs], 1, case0["interp"], rots)
             torch.cuda.synchronize()
+            if rnd == 1:  # the second call finds six entries: ONE launch for the six faces unless the setting says otherwise
+                cached = SETTINGS[setting].get("geo_cache", 1) == 1 and SETTINGS[setting].get("multi_merge", 1) == 1
+                assert lrp.debug_set("merged_launches", -1) == merged + (1 if cached else 0), setting
             for nm, o in zip(names, outs):
                 assert ffc.frame_digests(o.cpu().numpy())[0] == FULL["frames"][nm]["sha256"], f"{setting}: {nm} (round {rnd})"

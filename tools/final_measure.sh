@@ -1,13 +1,14 @@
 #!/usr/bin/env bash
-# One pass over everything DESIGN.md quotes; run on an MI355X box from the repo root.
-# Writes gpurun_out/final/* (copy what is to be judged into profiles/ with tools/final_collect.sh).
+# ONE pass over everything DESIGN.md quotes; run on an MI355X box from the repo root.  usage: final_measure.sh [round: r05]
+# Writes gpurun_out/final/* (copy what is to be judged into profiles/ with tools/final_collect.sh <round>).
 set -uo pipefail
 R="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd "$R"
+round="${1:-r05}"
 out=gpurun_out/final; rm -rf $out gpurun_out/traffic; mkdir -p $out
-(timeout 1500 python -m pytest tests -m gpu -q > $out/gpu_tests.log 2>&1; echo "exit $?" >> $out/gpu_tests.log); tail -3 $out/gpu_tests.log
+(timeout 2400 python -m pytest tests -m gpu -q > $out/gpu_tests.log 2>&1; echo "exit $?" >> $out/gpu_tests.log); tail -3 $out/gpu_tests.log
 # the PMC traffic first: bench.py reports roofline.traffic only from a file stamped with the sources it runs
-bash tools/collect_traffic.sh > $out/traffic.log 2>&1; tail -2 $out/traffic.log; cp gpurun_out/traffic_r04.json profiles/traffic_r04.json
-(timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?")
+bash tools/collect_traffic.sh $round > $out/traffic.log 2>&1; tail -2 $out/traffic.log; cp gpurun_out/traffic_$round.json profiles/traffic_$round.json
+(timeout 1200 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?")
 ALL="eqd_rect_bc eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch eqr_rect_bc_gen rect_rect_bc eqd_eqd_bc eqr_eqr_bc_rot eqr_eqd_bc_rot rect_eqd_bc rect_eqr_bc eqr_eqd_bl_rot eqr_rect_bl eqr_rect_nn eqr_rect_bl_rot eqr_rect_nn_rot"
 BC="eqd_rect_bc eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch eqr_rect_bc_gen rect_rect_bc eqr_eqd_bc_rot rect_eqr_bc"
 timeout 300 ./tools/kbench --sum --reps 32 --distinct 16 $ALL > $out/kbench_rgba_single.log 2>&1
@@ -17,16 +18,25 @@ timeout 400 ./tools/kbench --sum --reps 8 --batch 16 --distinct 16 --geo 0 $ALL 
 timeout 300 ./tools/kbench --sum --reps 8 --batch 16 --distinct 16 --channels 3 $BC eqr_rect_bl eqr_rect_nn > $out/kbench_rgb_batched.log 2>&1
 timeout 300 ./tools/kbench --sum --reps 8 --batch 16 --distinct 16 --channels 5 $BC eqr_rect_bl eqr_rect_nn > $out/kbench_rgbaz_batched.log 2>&1
 timeout 300 ./tools/kbench --sum --reps 24 --distinct 16 --channels 5 $BC > $out/kbench_rgbaz_single.log 2>&1
-timeout 200 ./tools/kbench --sum --reps 8 --batch 16 --distinct 16 --channels 5 --post rect_eqr_bc > $out/kbench_rgbaz_post_batched.log 2>&1
-timeout 200 ./tools/kbench --sum --reps 24 --distinct 16 --channels 5 --post rect_eqr_bc > $out/kbench_rgbaz_post_single.log 2>&1
+for L in 1 0; do
+  (echo "# geo_lists=$L"; timeout 200 ./tools/kbench --sum --reps 8 --batch 16 --distinct 16 --channels 5 --post --set geo_lists=$L rect_eqr_bc; timeout 200 ./tools/kbench --sum --reps 24 --distinct 16 --channels 5 --post --set geo_lists=$L rect_eqr_bc;
+   timeout 200 ./tools/kbench --sum --reps 8 --batch 16 --distinct 16 --set geo_lists=$L rect_eqr_bc rect_eqd_bc; timeout 200 ./tools/kbench --sum --reps 24 --distinct 16 --set geo_lists=$L rect_eqr_bc rect_eqd_bc) >> $out/kbench_configs3_lists.log 2>&1
+done
 timeout 200 ./tools/kbench --sum --reps 20 --size 8192 --out-size 2048 --channels 3 --distinct 4 eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch > $out/kbench_cubemap_faces.log 2>&1
 timeout 200 ./tools/kbench --sum --reps 20 --size 8192 --out-size 2048 --channels 3 --distinct 4 --geo 0 eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch > $out/kbench_cubemap_faces_geo0.log 2>&1
+timeout 300 python3 tools/cubemap_bench.py 30 > $out/cubemap_bench.log 2>&1
+for S in 1 0; do
+  (echo "# num_samples 2, 4096^2 -> 2048^2, win_ss=$S (1: the window kernel's SS instantiations; 0: the tile kernel)"; timeout 300 ./tools/kbench --sum --reps 20 --distinct 16 --ns 2 --size 4096 --out-size 2048 --set win_ss=$S eqd_rect_bc eqr_rect_bc eqr_rect_bc_gen rect_eqr_bc eqd_eqd_bc;
+   echo "# ... 16-frame launches"; timeout 300 ./tools/kbench --sum --reps 6 --batch 16 --distinct 16 --ns 2 --size 4096 --out-size 2048 --set win_ss=$S eqd_rect_bc eqr_rect_bc;
+   echo "# ... 4096^2 -> 4096^2"; timeout 300 ./tools/kbench --sum --reps 10 --distinct 16 --ns 2 --set win_ss=$S eqd_rect_bc eqr_rect_bc) >> $out/kbench_supersampling.log 2>&1
+done
+(echo "# num_samples 1 and 3 (4096^2 -> 2048^2) for reference"; timeout 300 ./tools/kbench --sum --reps 20 --distinct 16 --ns 1 --size 4096 --out-size 2048 eqd_rect_bc eqr_rect_bc; timeout 300 ./tools/kbench --sum --reps 10 --distinct 16 --ns 3 --size 4096 --out-size 2048 eqd_rect_bc eqr_rect_bc) >> $out/kbench_supersampling.log 2>&1
+for S in 1 2; do timeout 200 ./tools/kbench --reps 64 --distinct 16 --streams $S eqd_rect_bc eqr_rect_bc eqr_eqd_bc_rot rect_eqr_bc; done > $out/kbench_two_streams.log 2>&1
 timeout 300 ./tools/staged_bench > $out/staged.log 2>&1
 (echo "# RGBA"; python3 tools/fov_sweep.py 4 2>&1 | grep focal; echo "# RGBAZ + tonemap"; python3 tools/fov_sweep.py 5 post 2>&1 | grep focal) > $out/fov_sweep.log
-timeout 200 tools/microbench/tap_paths > $out/tap_paths.log 2>&1
 timeout 100 tools/microbench/hbm_stream > $out/hbm_stream.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof_bench -- python3 $R/bench.py --no-cpu-baseline --no-staged > $R/$out/prof_bench.log 2>&1; echo "rocprof rc=$?"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof_bench -- python3 $R/bench.py --no-cpu-baseline --no-staged > $R/$out/prof_bench.log 2>&1; echo "rocprof rc=$?"
 cat $R/$out/prof_bench/*/*kernel_stats.csv | cut -c1-200
 python3 $R/tools/kernel_trace_summary.py $(ls -t $R/$out/prof_bench/*/*kernel_trace.csv | head -1) | tee $R/$out/kernel_trace_by_launch_shape.txt
 i=0
@@ -37,6 +47,10 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   echo "sq batched pass $i rc=$?"
   timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/$out/sq/s$i -- $R/tools/kbench --reps 8 --warmup 20 --distinct 16 eqd_rect_bc eqr_rect_bc_gen > $R/$out/sq_s$i.log 2>&1
   echo "sq single pass $i rc=$?"
+  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/$out/sq/f$i -- $R/tools/kbench --reps 6 --warmup 6 --size 8192 --out-size 2048 --channels 3 --distinct 4 eqr_rect_bc_rot eqr_rect_bc_pitch > $R/$out/sq_f$i.log 2>&1
+  echo "sq faces pass $i rc=$?"
 done
 python3 $R/tools/pmc_summary.py $R/$out/sq > $R/$out/sq_counters.txt
-cat $R/$out/bench.json
+cd $R
+python3 tools/roofline_table.py $out/bench.json $out/kernel_trace_by_launch_shape.txt > $out/roofline.md
+cat $out/bench.json

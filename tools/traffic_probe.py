@@ -53,9 +53,9 @@ for name in names:
     outs = [[pkg.Image(lout, out_size, out_size, c, d) for d in ds] for ds in dsts]
     def single(i):
         if faces:
-            pkg.reproject_multi(ins[i % n_res], outs[i % n_res], 1, wl["interp"], np.stack([bench.make_rot(pkg, f) for f in faces]), post=wl.get("post"))
+            pkg.reproject_multi(ins[i % n_res], outs[i % n_res], wl.get("ns", 1), wl["interp"], np.stack([bench.make_rot(pkg, f) for f in faces]), post=wl.get("post"))
         else:
-            pkg.reproject(ins[i % n_res], outs[i % n_res][0], 1, wl["interp"], bench.make_rot(pkg, wl["rot"]), post=wl.get("post"))
+            pkg.reproject(ins[i % n_res], outs[i % n_res][0], wl.get("ns", 1), wl["interp"], bench.make_rot(pkg, wl["rot"]), post=wl.get("post"))
         torch.cuda.synchronize()
 
     separator()
@@ -68,7 +68,7 @@ for name in names:
     order.append({"workload": name, "frames": REPS, "launches_per_frame": "as dispatched"})
     if not faces:
         def batched():
-            pkg.reproject_batch(ins, [o[0] for o in outs], 1, wl["interp"], bench.make_rot(pkg, wl["rot"]), post=wl.get("post"))
+            pkg.reproject_batch(ins, [o[0] for o in outs], wl.get("ns", 1), wl["interp"], bench.make_rot(pkg, wl["rot"]), post=wl.get("post"))
             torch.cuda.synchronize()
 
         separator()
