@@ -638,7 +638,8 @@ def main():
         for name in [n for n in args.secondary.split(",") if n and n != args.workload]:
             w2 = WORKLOADS[name]
             size2 = w2["size"] * size // wl["size"]  # (--size scales every workload alike: tests)
-            if w2["channels"] == c and size2 == size and not w2.get("faces") and w2.get("depth", -1) == wl.get("depth", -1):
+            if (w2["channels"] == c and size2 == size and not w2.get("faces") and w2.get("depth", -1) == wl.get("depth", -1) and
+                    w2.get("out_size", w2["size"]) == w2["size"] and wl.get("out_size", wl["size"]) == wl["size"]):
                 secondary[name] = kernel_figures(torch, pkg, w2, size, srcs[:res], [[d] for d in dsts[:res]], streams[0], name)
             else:  # its own resident frames: 32 pairs (4 panoramas + cubemaps for configs[4]), far beyond the Infinity Cache
                 s2, d2 = resident_frames(torch, pkg, w2, size2, 4 if w2.get("faces") else min(32, max(res, 1)), dev, 0x5EED1000)

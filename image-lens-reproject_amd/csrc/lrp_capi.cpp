@@ -32,7 +32,8 @@ hipError_t launch_tile_nearest(const KParams &P, int out_idx, int in_mode, hipSt
 hipError_t launch_tile_bilinear(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
 hipError_t launch_tile_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
 hipError_t launch_win_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // (P.geo_mode == 2: the GeoRead kernels)
-hipError_t launch_geo_build_lists(int32_t *box, int out_w, int out_h, int alias_pairs, hipStream_t stream); // lrp_geo_lists.hip
+hipError_t launch_geo_build_lists(int32_t *box, int out_w, int out_h, int in_w, int in_h, int alias_pairs, hipStream_t stream); // lrp_geo_lists.hip
+hipError_t launch_pair_kernel(const KParams &P, hipStream_t stream); // lrp_tile_pair.hip
 hipError_t launch_corner_fill(const KParams &P, hipStream_t stream);
 hipError_t launch_post_process(float *data, uint32_t n_pixels, int channels, float exposure, float reinhard,
                                hipStream_t stream);
@@ -183,7 +184,7 @@ lrp::KParams make_params(const lrp_image *in, const lrp_image *out, int num_samp
 // initial values, once, when the library is loaded — nothing on a launch path calls getenv.
 //   kernel: 0 = pixel kernel, 1 = tile kernel everywhere, 2 (default) = tile kernel with the LDS-window kernel for
 //   bicubic, 3 = the same without its shared-coefficient tier and without any work sharing.  All HIP; there is no CPU path.
-enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobGeoBig, kKnobGeoLists, kKnobGeoFillStream, kKnobGeoFillFused, kKnobMultiMerge, kKnobContextStreams, kKnobWinSS, kKnobListedLaunches, kKnobMergedLaunches, kKnobCount };
+enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobGeoBig, kKnobGeoLists, kKnobGeoFillStream, kKnobGeoFillFused, kKnobGeoPairs, kKnobMultiMerge, kKnobContextStreams, kKnobWinSS, kKnobListedLaunches, kKnobMergedLaunches, kKnobPairLaunches, kKnobCount };
 struct KnobSpec {
   const char *name, *env;
   int lo, hi, initial;
@@ -210,11 +211,13 @@ const KnobSpec kKnobs[kKnobCount] = {
     {"geo_lists", "LRP_GEO_LISTS", 0, 2, 1},        // rendering by block class from the lists of a geometry-cache entry (corner runs by the fill kernel / a share per wavefront, the window kernel over the work list): 0 never, 1 where at least 30 % of the blocks are corner blocks, 2 whenever the lists are known
     {"geo_fill_stream", "LRP_GEO_FILL_STREAM", 0, 1, 0}, // the fill kernel of a listed launch: 0 in front of the window kernel on the caller's stream, 1 beside it on a side stream of the device
     {"geo_fill_fused", "LRP_GEO_FILL_FUSED", 0, 1, 1}, // the corner runs of a listed launch as a share per wavefront of the window kernel (0: always the fill kernel)
+    {"geo_pairs", "LRP_GEO_PAIRS", 0, 1, 0},        // listed launches: 1 = alias pairs of in-view blocks by the pair kernel, two wavefronts per window (default 0: measured level for RGBAZ and 12-17 % slower for RGB / RGBA on BASELINE configs[3], profiles/r05_experiments_ab.txt item 8)
     {"multi_merge", "LRP_MULTI_MERGE", 0, 1, 1},     // lrp_reproject_multi_device: the outputs whose geometry-cache entries exist in ONE launch; 0: a launch per output
     {"context_streams", "LRP_CONTEXT_STREAMS", 0, 1, 1}, // lrp_context: consecutive images alternate between two compute streams (0: one)
     {"win_ss", "LRP_WIN_SS", 0, 1, 1},              // bicubic with num_samples == 2 through the window kernel's supersampling instantiations (0: the tile kernel, as for any other num_samples > 1)
     {"listed_launches", "LRP_LISTED_LAUNCHES_UNUSED", 0, 0, 0}, // a counter, not a switch: launches rendered by block class so far (set 0 to reset; tests, bench)
     {"merged_launches", "LRP_MERGED_LAUNCHES_UNUSED", 0, 0, 0}, // a counter: multi-output launches so far
+    {"pair_launches", "LRP_PAIR_LAUNCHES_UNUSED", 0, 0, 0},     // a counter: launches of the pair kernel so far
 };
 std::atomic<int> g_knobs[kKnobCount];
 const bool g_knobs_initialised = [] { // the one place that reads the environment
@@ -464,14 +467,21 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
           P.geo_runs = reinterpret_cast<const uint32_t *>(P.geo_work + 2 * lrp::geo_work_capacity(out->width, out->height));
           P.geo_n_work = geo.n_work;
           P.geo_n_runs = geo.n_runs;
+          if (knob(kKnobGeoPairs) != 0 && geo.n_pairs != 0) { // alias pairs of in-view blocks: the pair kernel (lrp_pair_kernel.h) ...
+            P.geo_pairs = reinterpret_cast<const int32_t *>(P.geo_runs + 4 * lrp::geo_run_capacity(out->width, out->height));
+            P.geo_n_pairs = geo.n_pairs;
+            P.geo_work = P.geo_pairs + 2 * lrp::geo_pair_capacity(out->width, out->height); // ... and the window kernel over the rest
+            P.geo_n_work = geo.n_rest;
+          }
           // the corner runs: a share per wavefront of the window launch where it has enough wavefronts to spread them over,
           // else (few or no blocks to render: the frame is nearly all corners) the fill kernel at its own, full occupancy
-          if (knob(kKnobGeoFillFused) != 0 && geo.n_work >= kMinWavesForFusedFill && geo.n_runs != 0) {
+          // (P.geo_n_work: the wavefronts of THIS window launch — the rest list when the pair kernel takes the pairs)
+          if (knob(kKnobGeoFillFused) != 0 && P.geo_n_work >= kMinWavesForFusedFill && geo.n_runs != 0) {
             // every stride-th wavefront (odd stride: all XCDs) writes at least one whole run (16 row segments)
             const unsigned long long segs = (unsigned long long)geo.n_runs * 16u;
-            unsigned stride = (unsigned)std::max<unsigned long long>(1, 16ull * geo.n_work / segs) | 1u;
-            stride = std::min(stride, std::max(1u, geo.n_work / 1024u) | 1u); // (at least ~1024 filling wavefronts)
-            const unsigned fillers = (geo.n_work + stride - 1) / stride;
+            unsigned stride = (unsigned)std::max<unsigned long long>(1, 16ull * P.geo_n_work / segs) | 1u;
+            stride = std::min(stride, std::max(1u, P.geo_n_work / 1024u) | 1u); // (at least ~1024 filling wavefronts)
+            const unsigned fillers = (P.geo_n_work + stride - 1) / stride;
             P.geo_fill_stride = stride;
             P.geo_fill_per_wave = (unsigned)((segs + fillers - 1) / fillers);
           }
@@ -485,6 +495,11 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
         if (P.geo_fill_per_wave == 0) {
           const hipError_t fe = fill_corner_runs(P, device, stream);
           if (fe != hipSuccess) return fe;
+        }
+        if (P.geo_n_pairs != 0) {
+          const hipError_t pe = lrp::launch_pair_kernel(P, stream);
+          if (pe != hipSuccess) return pe;
+          g_knobs[kKnobPairLaunches].fetch_add(1, std::memory_order_relaxed);
         }
       }
       if (window) return lrp::launch_win_bicubic(P, oi, im, stream);
@@ -519,7 +534,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
       // the launch above wrote the class bytes of the entry: its block lists are built behind it, and their header follows
       // the records to the host (page-locked; read once the records' event has completed)
       const uint8_t *const header = reinterpret_cast<const uint8_t *>(geo.box) + lrp::geo_lists_offset(out->width, out->height);
-      if (lrp::launch_geo_build_lists(geo.box, out->width, out->height, P.alias_pairs, stream) == hipSuccess &&
+      if (lrp::launch_geo_build_lists(geo.box, out->width, out->height, in->width, in->height, P.alias_pairs, stream) == hipSuccess &&
           hipMemcpyAsync(geo.host_counts, header, (size_t)lrp::kGeoListHeaderWords * 4, hipMemcpyDeviceToHost, stream) == hipSuccess)
         geo.lists_enqueued = true;
       else

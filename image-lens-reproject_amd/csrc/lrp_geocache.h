@@ -49,7 +49,7 @@ struct GeoUse {
   uint32_t *host_counts = nullptr;
   bool lists_enqueued = false;
   bool lists = false;
-  uint32_t n_work = 0, n_runs = 0, n_corner_blocks = 0, n_blocks = 0;
+  uint32_t n_work = 0, n_runs = 0, n_corner_blocks = 0, n_blocks = 0, n_pairs = 0, n_rest = 0;
 };
 
 // Decides, for a launch that is about to be enqueued on `stream` (device already selected), whether it reads the

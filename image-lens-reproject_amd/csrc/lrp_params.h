@@ -104,6 +104,10 @@ struct KParams {
   const int32_t *geo_work;   // [geo_n_work][2]
   const uint32_t *geo_runs;  // [geo_n_runs][4]: block row, first block column, blocks (<= kGeoRunBlocks), corner class 1-4
   uint32_t geo_n_work, geo_n_runs;
+  // ... and the PAIR list: alias pairs of blocks that lie in view whole, rendered by the pair kernel (lrp_pair_kernel.h) from
+  // one window per pair; geo_work then points at the REST list (the work list without them).  Entry = (column, row) of the block in front of the camera.
+  const int32_t *geo_pairs;  // [geo_n_pairs][2]
+  uint32_t geo_n_pairs;
   // Multi-output launch (GeoRead window kernels without the frame loop; lrp_reproject_multi_device): face_n > 0 outputs of ONE
   // source — same size, channels and lenses, each with its own rotation, i.e. its own geometry-cache entry — rendered by one
   // launch (the outputs interleaved workgroup by workgroup): one ramp and one tail instead of face_n, and the wavefronts of cheap
@@ -127,7 +131,7 @@ struct GeoLayout {
   size_t bytes() const { return xy_bytes + box_bytes + list_bytes; }
 };
 // Block lists, behind the class bytes (built once per entry by geo_build_lists, lrp_geo_lists.hip, from the class bytes):
-//   header  kGeoListHeaderWords words: [0] work entries, [1] runs, [2] corner blocks, [3] blocks of the image
+//   header  kGeoListHeaderWords words: [0] work entries, [1] runs, [2] corner blocks, [3] blocks of the image, [4] pair entries, [5] rest entries
 //   work    pairs (block column, block row) of every block that is NOT a corner block, in the order the window kernel's
 //           launch would reach them: entry i goes to workgroup i, i.e. to XCD i % 8, and the entries of one XCD are its
 //           rows of blocks (row % 8 == XCD) in raster order with the corner blocks taken out (alias pairs stay neighbours);
@@ -135,6 +139,9 @@ struct GeoLayout {
 //   runs    maximal runs of horizontally adjacent corner blocks of one class inside an aligned group of kGeoRunBlocks
 //           block columns: (block row, first block column, blocks, class).  Every pixel of a run is the same value
 //           (the clamped corner texel, src/reproject.cpp:114-131), so a run is 16 contiguous row segments of that value.
+//   pairs   (alias geometries only: a rectilinear view into a full-turn panorama, no pitch / roll) the blocks in front of the
+//           camera that lie in view whole and whose partner behind the camera does too, XCD-interleaved like the work list;
+//   rest    the work list without the blocks of the pairs: what the window kernel walks when the pair kernel renders the pairs.
 constexpr int kGeoListHeaderWords = 16;
 constexpr int kGeoRunBlocks = 16;
 inline __host__ __device__ uint32_t geo_image_block_rows(int out_h) { return (uint32_t)(out_h + 15) / 16; }
@@ -142,6 +149,7 @@ inline __host__ __device__ size_t geo_work_capacity(int out_w, int out_h) { // e
   return (size_t)kXcds * ((geo_image_block_rows(out_h) + kXcds - 1) / kXcds) * geo_block_cols(out_w);
 }
 inline __host__ __device__ size_t geo_run_capacity(int out_w, int out_h) { return (size_t)geo_image_block_rows(out_h) * geo_block_cols(out_w); }
+inline __host__ __device__ size_t geo_pair_capacity(int out_w, int out_h) { return geo_work_capacity(out_w, out_h) / 2 + kXcds; } // entries (pairs of ints)
 // Element (float2) of output pixel (x, y) in the coordinate map: row-major.  (A map stored in 16 x 16 tiles — 2 KiB contiguous
 // bytes per block of the window kernel instead of 16 row segments of 128 bytes — measured the same for the window kernels
 // and 2-3 % slower for the tile kernels: profiles/r04_experiments_ab.txt.)
@@ -167,7 +175,8 @@ inline GeoLayout geo_layout(int out_w, int out_h, bool with_boxes) {
   L.xy_bytes = ((size_t)out_w * (size_t)out_h * 8 + 255) & ~(size_t)255; // (the records and lists behind the map start on a 256-byte boundary)
   if (with_boxes) {
     L.box_bytes = geo_lists_offset(out_w, out_h);
-    L.list_bytes = (size_t)kGeoListHeaderWords * 4 + geo_work_capacity(out_w, out_h) * 8 + geo_run_capacity(out_w, out_h) * 16;
+    L.list_bytes = (size_t)kGeoListHeaderWords * 4 + geo_work_capacity(out_w, out_h) * 8 + geo_run_capacity(out_w, out_h) * 16 +
+                   geo_pair_capacity(out_w, out_h) * 8 + geo_work_capacity(out_w, out_h) * 8;
   }
   return L;
 }

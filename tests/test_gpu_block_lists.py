@@ -26,10 +26,12 @@ with open(os.path.join(HERE, "golden", "fullframe_golden.json")) as _f:
 def _fresh_cache(lrp):
     lrp.debug_set("geo_cache", 1)
     prev = lrp.debug_set("geo_lists", 2)
+    prev_pairs = lrp.debug_set("geo_pairs", 1)  # (off by default: here the pair kernel is part of what is tested)
     lrp.geometry_cache_configure(1 << 30, 1)
     lrp.release_cached_tables()
     yield
     lrp.debug_set("geo_lists", prev)
+    lrp.debug_set("geo_pairs", prev_pairs)
     lrp.debug_set("geo_fill_stream", 0)
     lrp.geometry_cache_configure(1 << 30, 1)
     lrp.release_cached_tables()
@@ -89,11 +91,11 @@ def test_listed_launches_against_the_live_oracle(lrp, oracle, torch_cuda, channe
         for got in render(batch=5):
             cases.assert_same_bits(got, want, "listed batch of five, " + what)
         assert _listed(lrp) == n0 + 2 * lists
-        for knob_name in ("geo_fill_fused", "geo_lists"):  # the fill kernel instead of a share per wavefront; no lists at all
+        for knob_name in ("geo_pairs", "geo_fill_fused", "geo_lists"):  # no pair kernel; the fill kernel instead of a share per wavefront; no lists at all
             prev = lrp.debug_set(knob_name, 0)
             cases.assert_same_bits(render()[0], want, f"{knob_name} 0, " + what)
             lrp.debug_set(knob_name, prev)
-        assert _listed(lrp) == n0 + 3 * lists
+        assert _listed(lrp) == n0 + 4 * lists
 
 
 def test_all_corner_one_block_and_no_corner_frames(lrp, oracle, torch_cuda):
@@ -142,9 +144,10 @@ def test_whole_frames_by_block_class(lrp, torch_cuda, name):
     frame(case["seed"] + 99)
     for fill_stream in (0, 1):
         lrp.debug_set("geo_fill_stream", fill_stream)
-        n0 = _listed(lrp)
+        n0, p0 = _listed(lrp), lrp.debug_set("pair_launches", -1)
         d_out = frame(case["seed"])
         assert _listed(lrp) == n0 + 1
+        assert lrp.debug_set("pair_launches", -1) == p0 + 1, "the view and its copy behind the camera: alias pairs by the pair kernel"
         sha, bands, n_nan = ffc.frame_digests(d_out.cpu().numpy())
         bad = [b for b in range(ffc.BANDS) if bands[b] != want["bands"][b]]
         assert not bad, f"{name}: row bands {bad} of {ffc.BANDS} differ from the committed oracle digest (fill_stream {fill_stream})"

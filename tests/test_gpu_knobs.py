@@ -56,6 +56,7 @@ SETTINGS = {
     "geo_lists2": {"geo_cache": 1, "geo_lists": 2},
     "geo_lists2_fill_kernel": {"geo_cache": 1, "geo_lists": 2, "geo_fill_fused": 0},
     "geo_lists2_fill_stream": {"geo_cache": 1, "geo_lists": 2, "geo_fill_fused": 0, "geo_fill_stream": 1},
+    "geo_lists2_pairs1": {"geo_cache": 1, "geo_lists": 2, "geo_pairs": 1},  # (alias pairs of in-view blocks by the pair kernel, two wavefronts per window)
     "multi_merge0": {"geo_cache": 1, "multi_merge": 0},  # (lrp_reproject_multi_device: a launch per output)
     "win_ss0": {"geo_cache": 0, "win_ss": 0},  # (bicubic with num_samples == 2 through the tile kernel)
 }
@@ -91,7 +92,7 @@ class _DeviceSynth:
 
 def test_switch_names_and_ranges(lrp):
     for name in ("kernel", "xsep", "quad", "mirror_modes", "win_edge", "win_split", "batch_frames", "multi_fork", "geo_cache", "geo_strip", "geo_big",
-                 "geo_lists", "geo_fill_fused", "geo_fill_stream", "multi_merge", "context_streams", "win_ss"):
+                 "geo_lists", "geo_fill_fused", "geo_fill_stream", "geo_pairs", "multi_merge", "context_streams", "win_ss"):
         now = lrp.debug_set(name, -1)
         assert lrp.debug_set(name, now) == now  # setting the current value returns it
         assert lrp.debug_set(name, 10 ** 6) == now and lrp.debug_set(name, -1) == now  # out of range: a query
