@@ -25,6 +25,9 @@ def test_frames_per_launch_reads_the_frame_loop_argument():
     assert k.frames_per_launch(win.format("0, 1, 0, 4, false, true"), 1, 16) == 1  # a single GeoRead launch is ONE frame
     assert k.frames_per_launch(win.format("0, 1, 0, 4, false, true"), 16, 16) == 16  # 16 frames, a frame per grid row
     assert k.frames_per_launch(win.format("0, 3, 1, 4, false, false"), 1, 16) == 1
+    assert k.frames_per_launch(win.format("0, 1, 0, 4, true, true, false"), 1, 16) == 16  # (round 5: a seventh argument, SS)
+    assert k.frames_per_launch(win.format("0, 1, 0, 4, false, true, false"), 1, 16) == 1
+    assert k.frames_per_launch(win.format("0, 1, 0, 4, false, false, true"), 1, 16) == 1
     assert k.frames_per_launch("void lrp::reproject_tile_kernel<0, 3, 1, 4, false, true>(lrp::KParams)", 16, 16) == 16
     assert k.frames_per_launch("void lrp::reproject_tile_kernel<0, 3, 0, 4, true, false>(lrp::KParams)", 1, 16) == 16
     assert k.frames_per_launch("lrp::(anonymous namespace)::corner_fill_kernel<5>(lrp::KParams)", 16, 16) == 16

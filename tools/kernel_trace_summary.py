@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
 """Per (kernel, frames per launch) durations from a rocprofv3 --kernel-trace CSV: bench.py launches the
 same kernel with 16 frames (the timed region) and with one frame (single_launch_us), which the --stats summary
-averages together.  The tile and window kernels are templates <..., Frames, GeoRead>: the SECOND-TO-LAST argument says
-whether the instantiation has the frame loop (a wavefront walks `frames_per_wave` frames, grid y = groups of frames: its
-launches are the batch launches, `batch` frames each — bench.py's 16); the last one only says where the coordinates come
-from.  Every other instantiation renders grid y frames per launch (one for a single launch).
+averages together.  The tile and window kernels are templates <OutLens, InMode, Interp | QMode, CH, Frames, GeoRead[, SS]>: the FIFTH
+argument says whether the instantiation has the frame loop (a wavefront walks `frames_per_wave` frames, grid y = groups of frames: its
+launches are the batch launches, `batch` frames each — bench.py's 16); the sixth only says where the coordinates come from.  Every other instantiation renders grid y frames per launch (one for a single launch).
 usage: kernel_trace_summary.py <kernel_trace.csv> [frames per launch of the frame-loop instantiations: 16]"""
 import collections
 import csv
@@ -16,7 +15,7 @@ def frames_per_launch(name, grid_y, batch):
     m = re.search(r"reproject_(?:bicubic_win|tile)_kernel<([^>]*)>", name)
     if m:
         args = [a.strip() for a in m.group(1).split(",")]
-        if len(args) >= 6 and args[-2] == "true":  # the frame loop
+        if len(args) >= 6 and args[4] == "true":  # the frame loop
             return batch
     return grid_y
 
