@@ -32,6 +32,7 @@ def _fresh_cache(lrp):
     yield
     lrp.debug_set("geo_lists", prev)
     lrp.debug_set("geo_pairs", prev_pairs)
+    lrp.debug_set("multi_merge", 0)
     lrp.debug_set("geo_fill_stream", 0)
     lrp.geometry_cache_configure(1 << 30, 1)
     lrp.release_cached_tables()
@@ -161,6 +162,7 @@ def test_outputs_of_one_source_in_one_launch(lrp, oracle, torch_cuda, channels):
     face).  Six and nine outputs (two launches: eight + one), odd sizes, a rectilinear source as well, fused tonemap — every
     face against the live oracle, the counter proving the merged launch ran; `multi_merge` 0 gives the same bits."""
     torch = torch_cuda
+    lrp.debug_set("multi_merge", 1)  # (off by default: measured level or slower; the path is tested all the same)
     faces = [(0.0, 0.0, 0.0), (90.0, 0.0, 0.0), (180.0, 0.0, 0.0), (270.0, 0.0, 0.0), (0.0, 90.0, 0.0), (0.0, -90.0, 0.0),
              (30.0, -15.0, 5.0), (45.0, 45.0, 0.0), (10.0, 0.0, 80.0)]
     for (iw, ih, ow, oh), in_name, n_faces, post in (((256, 128, 72, 72), "eqr_full", 6, None), ((200, 100, 53, 41), "eqr_full", 9, (1.5, 3.0)),
@@ -189,8 +191,9 @@ def test_outputs_of_one_source_in_one_launch(lrp, oracle, torch_cuda, channels):
         for f, got in enumerate(render()):
             cases.assert_same_bits(got, wants[f], f"second call (one launch), face {f}, " + what)
         assert lrp.debug_set("merged_launches", -1) == m0 + (2 if n_faces > 8 else 1), what
-        prev = lrp.debug_set("multi_merge", 0)
+        lrp.debug_set("multi_merge", 0)
         for f, got in enumerate(render()):
             cases.assert_same_bits(got, wants[f], f"multi_merge 0, face {f}, " + what)
-        lrp.debug_set("multi_merge", prev)
+        lrp.debug_set("multi_merge", 1)
         assert lrp.debug_set("merged_launches", -1) == m0 + (2 if n_faces > 8 else 1)
+    lrp.debug_set("multi_merge", 0)

@@ -57,7 +57,7 @@ SETTINGS = {
     "geo_lists2_fill_kernel": {"geo_cache": 1, "geo_lists": 2, "geo_fill_fused": 0},
     "geo_lists2_fill_stream": {"geo_cache": 1, "geo_lists": 2, "geo_fill_fused": 0, "geo_fill_stream": 1},
     "geo_lists2_pairs1": {"geo_cache": 1, "geo_lists": 2, "geo_pairs": 1},  # (alias pairs of in-view blocks by the pair kernel, two wavefronts per window)
-    "multi_merge0": {"geo_cache": 1, "multi_merge": 0},  # (lrp_reproject_multi_device: a launch per output)
+    "multi_merge1": {"geo_cache": 1, "multi_merge": 1},  # (lrp_reproject_multi_device: the outputs whose entries exist in ONE launch)
     "win_ss0": {"geo_cache": 0, "win_ss": 0},  # (bicubic with num_samples == 2 through the tile kernel)
 }
 FRAMES = ["config1_4k_eqd_rect_bc", "config3_4k_rgbaz_rect_eqr_bc_post", "4k_eqr_rect_bc_rot", "config4_8k_rgb_face4"]
@@ -161,7 +161,7 @@ def test_whole_frames_under_setting(lrp, torch_cuda, setting):
             torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("setting", ["multi_fork0", "multi_fork3", "multi_fork3_geo", "defaults", "geo_cache", "multi_merge0"])
+@pytest.mark.parametrize("setting", ["multi_fork0", "multi_fork3", "multi_fork3_geo", "defaults", "geo_cache", "multi_merge1"])
 def test_cubemap_through_multi_under_setting(lrp, torch_cuda, setting):
     """BASELINE configs[4]: the six faces of an 8192^2 RGB panorama in ONE lrp_reproject_multi_device call, twice."""
     torch = torch_cuda
@@ -178,8 +178,8 @@ def test_cubemap_through_multi_under_setting(lrp, torch_cuda, setting):
             merged = lrp.debug_set("merged_launches", -1)
             lrp.reproject_multi(lrp.Image(lin, n, n, c, d_in), [lrp.Image(lout, m, m, c, o) for o in outs], 1, case0["interp"], rots)
             torch.cuda.synchronize()
-            if rnd == 1:  # the second call finds six entries: ONE launch for the six faces unless the setting says otherwise
-                cached = SETTINGS[setting].get("geo_cache", 1) == 1 and SETTINGS[setting].get("multi_merge", 1) == 1
+            if rnd == 1:  # the second call finds six entries: ONE launch for the six faces where the setting asks for it
+                cached = SETTINGS[setting].get("geo_cache", 1) == 1 and SETTINGS[setting].get("multi_merge", 0) == 1
                 assert lrp.debug_set("merged_launches", -1) == merged + (1 if cached else 0), setting
             for nm, o in zip(names, outs):
                 assert ffc.frame_digests(o.cpu().numpy())[0] == FULL["frames"][nm]["sha256"], f"{setting}: {nm} (round {rnd})"

@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""The automatic choices of enqueue_reproject (csrc/lrp_capi.cpp) against their alternatives, on THIS box: for every policy switch
+that picks a kernel path by a measured rule — block lists, the big-window variant, strip length, frames per wavefront, mirror
+modes against the geometry cache, merged multi-output launches, the supersampling instantiations, the fused corner fill — the
+workloads the rule was measured on are timed with the default and with every other setting of the switch, inside one process
+("thresholds carry single-box A/B numbers in comments and no test that the chosen path is the fast
+one").  Prints one line per (workload, switch) and FAILS (exit 1) when a default is more than `tolerance` slower than the best
+alternative.  usage: policy_check.py [tolerance: 0.05]"""
+import importlib
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+pkg = importlib.import_module("image-lens-reproject_amd")
+tol = float(sys.argv[1]) if len(sys.argv) > 1 else 0.05
+dev = torch.device("cuda", 0)
+N_RES = 16
+_frames = {}
+
+
+def frames(size, c, out_size):
+    key = (size, c, out_size)
+    if key not in _frames:
+        _frames.clear()
+        torch.cuda.empty_cache()
+        srcs, dsts = [], []
+        for k in range(N_RES if size <= 4096 else 4):
+            s = torch.empty((size, size, c), dtype=torch.float32, device=dev)
+            pkg.synth_fill(s, size, size, c, 0x5EED0000 + k, 4 if c == 5 else -1)
+            srcs.append(s)
+            dsts.append(torch.empty((out_size, out_size, c), dtype=torch.float32, device=dev))
+        _frames[key] = (srcs, dsts)
+    return _frames[key]
+
+
+def lens(kind, n):
+    L = pkg.LensInfo
+    return {"rect": L.rectilinear(18.0, 36.0, n, n), "eqd": L.equidistant(3.14159265), "eqr": L.equirectangular()}[kind]
+
+
+def rot(deg):
+    return None if deg is None else pkg.rotation_matrix(*[d * math.pi / 180.0 for d in deg])
+
+
+def time_us(wl, batch, reps):
+    size, out_size, c, ns = wl.get("size", 4096), wl.get("out_size", wl.get("size", 4096)), wl.get("c", 4), wl.get("ns", 1)
+    srcs, dsts = frames(size, c, out_size)
+    lin, lout = lens(wl["inp"], size), lens(wl["out"], out_size)
+    ins = [pkg.Image(lin, size, size, c, s) for s in srcs]
+    outs = [pkg.Image(lout, out_size, out_size, c, d) for d in dsts]
+    R, post = rot(wl.get("deg")), wl.get("post")
+    n = len(srcs)
+
+    def launch(i):
+        if batch:
+            pkg.reproject_batch(ins[:batch], outs[:batch], ns, wl["interp"], R, post=post)
+        else:
+            pkg.reproject(ins[i % n], outs[i % n], ns, wl["interp"], R, post=post)
+
+    for i in range(4):  # the launch that fills the cache, the lists, then the steady state
+        launch(i)
+        torch.cuda.synchronize()
+    for i in range(12):
+        launch(i)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(reps):
+            launch(i)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps / (batch or 1)
+        best = us if best is None else min(best, us)
+    return best
+
+
+HEAD = dict(inp="eqd", out="rect", interp=2, deg=None)
+GEN = dict(inp="eqr", out="rect", interp=2, deg=(30.0, -15.0, 5.0))
+C3 = dict(inp="rect", out="eqr", interp=2, deg=(0.0, 0.0, 0.0))
+C3Z = dict(C3, c=5, post=(2.0, 4.0))
+RFE = dict(inp="rect", out="eqd", interp=2, deg=None)
+BL = dict(inp="eqr", out="eqd", interp=1, deg=(30.0, -15.0, 5.0))
+NN = dict(inp="eqr", out="rect", interp=0, deg=(0.0, 0.0, 0.0))
+SS = dict(HEAD, out_size=2048, ns=2)
+CHECKS = [  # (what, workload, batch, switch, settings: the first is the default)
+    ("block lists, configs[3] RGBA single", C3, 0, "geo_lists", (1, 0, 2)),
+    ("block lists, configs[3] RGBAZ + tonemap single", C3Z, 0, "geo_lists", (1, 0, 2)),
+    ("block lists, configs[3] RGBAZ + tonemap batch16", C3Z, 16, "geo_lists", (1, 0, 2)),
+    ("block lists, rect -> fisheye single", RFE, 0, "geo_lists", (1, 0, 2)),
+    ("corner fill as shares, configs[3] RGBAZ + tonemap single", C3Z, 0, "geo_fill_fused", (1, 0)),
+    ("pair kernel (off), configs[3] RGBAZ + tonemap batch16", C3Z, 16, "geo_pairs", (0, 1)),
+    ("big-window variant, configs[3] RGBA single", C3, 0, "geo_big", (1, 0)),
+    ("strip length of reading launches, headline single", HEAD, 0, "geo_strip", (0, 1, 2, 4)),
+    ("strip length of reading launches, general rotation single", GEN, 0, "geo_strip", (0, 1, 2, 4)),
+    ("frames per wavefront, headline batch16", HEAD, 16, "batch_frames", (0, 1, 4, 16)),
+    ("frames per wavefront, configs[3] RGBA batch16", C3, 16, "batch_frames", (0, 1, 16)),
+    ("geometry cache, headline single", HEAD, 0, "geo_cache", (1, 0)),
+    ("geometry cache, general rotation single", GEN, 0, "geo_cache", (1, 0)),
+    ("geometry cache, bilinear rotated single", BL, 0, "geo_cache", (1, 0)),
+    ("geometry cache, bilinear rotated batch16", BL, 16, "geo_cache", (1, 0)),
+    ("geometry cache, nearest without a rotation single", NN, 0, "geo_cache", (1, 0)),
+    ("supersampling instantiations, 4096^2 -> 2048^2 num_samples 2 single", SS, 0, "win_ss", (1, 0)),
+]
+bad = 0
+print(f"# default against the alternatives of every policy switch, us per frame (tolerance {tol:.0%}); box: {torch.cuda.get_device_name(0)}")
+for what, wl, batch, switch, settings in CHECKS:
+    times = {}
+    for v in settings + (settings[0],):  # (the default first AND last: the better of the two, so that drift over the run does not decide)
+        prev = pkg.debug_set(switch, v)
+        pkg.release_cached_tables()
+        t = time_us(wl, batch, 6 if batch else 24)
+        times[v] = min(t, times.get(v, t))
+        pkg.debug_set(switch, prev)
+    default, best = times[settings[0]], min(times.values())
+    ok = default <= best * (1.0 + tol)
+    bad += 0 if ok else 1
+    print(f"{'ok  ' if ok else 'SLOW'} {what:70s} {switch}: " + "  ".join(f"{v}: {t:7.1f}" for v, t in times.items()) + f"   default / best = {default / best:.3f}", flush=True)
+# merged multi-output launches (its own entry point)
+faces = [(0.0, 0.0, 0.0), (90.0, 0.0, 0.0), (180.0, 0.0, 0.0), (270.0, 0.0, 0.0), (0.0, 90.0, 0.0), (0.0, -90.0, 0.0)]
+_frames.clear()
+torch.cuda.empty_cache()
+n, m, c = 8192, 2048, 3
+srcs = []
+for k in range(3):
+    s = torch.empty((n, n, c), dtype=torch.float32, device=dev)
+    pkg.synth_fill(s, n, n, c, 0x5EED0000 + k, -1)
+    srcs.append(s)
+dsts = [[torch.empty((m, m, c), dtype=torch.float32, device=dev) for _ in range(6)] for _ in srcs]
+rots = np.stack([rot(f) for f in faces])
+lin, lout = pkg.LensInfo.equirectangular(), pkg.LensInfo.rectilinear(18.0, 36.0, m, m)
+times = {}
+for v in (0, 1):
+    prev = pkg.debug_set("multi_merge", v)
+    for i in range(6):
+        pkg.reproject_multi(pkg.Image(lin, n, n, c, srcs[i % 3]), [pkg.Image(lout, m, m, c, d) for d in dsts[i % 3]], 1, 2, rots)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(24):
+        pkg.reproject_multi(pkg.Image(lin, n, n, c, srcs[i % 3]), [pkg.Image(lout, m, m, c, d) for d in dsts[i % 3]], 1, 2, rots)
+    e1.record()
+    torch.cuda.synchronize()
+    times[v] = e0.elapsed_time(e1) * 1e3 / 24
+    pkg.debug_set("multi_merge", prev)
+ok = times[0] <= min(times.values()) * (1.0 + tol)
+bad += 0 if ok else 1
+print(f"{'ok  ' if ok else 'SLOW'} {'cubemap 8192^2 -> six 2048^2 faces, six launches (default) against one':70s} multi_merge: 0: {times[0]:7.1f}  1: {times[1]:7.1f}   default / best = {times[0] / min(times.values()):.3f}")
+print(f"# {bad} of {len(CHECKS) + 1} defaults more than {tol:.0%} behind their best alternative")
+sys.exit(1 if bad else 0)
