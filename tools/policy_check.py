@@ -136,7 +136,7 @@ dsts = [[torch.empty((m, m, c), dtype=torch.float32, device=dev) for _ in range(
 rots = np.stack([rot(f) for f in faces])
 lin, lout = pkg.LensInfo.equirectangular(), pkg.LensInfo.rectilinear(18.0, 36.0, m, m)
 times = {}
-for v in (0, 1):
+for v in (0, 1, 0, 1, 0, 1):  # (alternating, the best of three each: the first launches on fresh allocations are slower whatever the setting)
     prev = pkg.debug_set("multi_merge", v)
     for i in range(6):
         pkg.reproject_multi(pkg.Image(lin, n, n, c, srcs[i % 3]), [pkg.Image(lout, m, m, c, d) for d in dsts[i % 3]], 1, 2, rots)
@@ -147,7 +147,8 @@ for v in (0, 1):
         pkg.reproject_multi(pkg.Image(lin, n, n, c, srcs[i % 3]), [pkg.Image(lout, m, m, c, d) for d in dsts[i % 3]], 1, 2, rots)
     e1.record()
     torch.cuda.synchronize()
-    times[v] = e0.elapsed_time(e1) * 1e3 / 24
+    t = e0.elapsed_time(e1) * 1e3 / 24
+    times[v] = min(t, times.get(v, t))
     pkg.debug_set("multi_merge", prev)
 ok = times[0] <= min(times.values()) * (1.0 + tol)
 bad += 0 if ok else 1
