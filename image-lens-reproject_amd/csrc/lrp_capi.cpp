@@ -212,7 +212,7 @@ const KnobSpec kKnobs[kKnobCount] = {
     {"geo_fill_stream", "LRP_GEO_FILL_STREAM", 0, 1, 0}, // the fill kernel of a listed launch: 0 in front of the window kernel on the caller's stream, 1 beside it on a side stream of the device
     {"geo_fill_fused", "LRP_GEO_FILL_FUSED", 0, 1, 1}, // the corner runs of a listed launch as a share per wavefront of the window kernel (0: always the fill kernel)
     {"geo_pairs", "LRP_GEO_PAIRS", 0, 1, 0},        // listed launches: 1 = alias pairs of in-view blocks by the pair kernel, two wavefronts per window (default 0: measured level for RGBAZ and 12-17 % slower for RGB / RGBA on BASELINE configs[3], profiles/r05_experiments_ab.txt item 8)
-    {"multi_merge", "LRP_MULTI_MERGE", 0, 1, 0},     // lrp_reproject_multi_device: 1 = the outputs whose geometry-cache entries exist in ONE launch; default 0, a launch per output over the caller's stream and a side stream (measured level to 10 % faster than the merged launch: 358-376 against 357-409 us per 8192^2 -> six 2048^2 cubemap)
+    {"multi_merge", "LRP_MULTI_MERGE", 0, 1, 0},     // lrp_reproject_multi_device: 1 = the outputs whose geometry-cache entries exist in ONE launch; default 0, a launch per output over the caller's stream and a side stream (measured level: 360-365 against 359-363 us per 8192^2 -> six 2048^2 cubemap)
     {"context_streams", "LRP_CONTEXT_STREAMS", 0, 1, 1}, // lrp_context: consecutive images alternate between two compute streams (0: one)
     {"win_ss", "LRP_WIN_SS", 0, 1, 1},              // bicubic with num_samples == 2 through the window kernel's supersampling instantiations (0: the tile kernel, as for any other num_samples > 1)
     {"listed_launches", "LRP_LISTED_LAUNCHES_UNUSED", 0, 0, 0}, // a counter, not a switch: launches rendered by block class so far (set 0 to reset; tests, bench)

@@ -123,7 +123,7 @@ int lrp_debug_kernel(int choice);
  * 30 % of the frame, 2 whenever the lists are known), "geo_fill_fused" (0: the corner runs of such a launch always by the fill kernel, not as a share per
  * wavefront of the window kernel), "geo_fill_stream" (1: that fill kernel on a side stream), "geo_pairs" (1: the pair kernel — alias pairs of in-view blocks, a rectilinear view
  * and its copy behind the camera in a full panorama, two wavefronts per staged window — in a listed launch; default 0: not faster), "multi_merge" (1: lrp_reproject_multi_device merges the outputs whose
- * geometry-cache entries exist into one launch; default 0: a launch per output, measured level or faster), "merged_launches" (a counter), "context_streams" (0: an lrp_context keeps all its kernels on one compute stream instead of alternating two),
+ * geometry-cache entries exist into one launch; default 0: a launch per output, measured level), "merged_launches" (a counter), "context_streams" (0: an lrp_context keeps all its kernels on one compute stream instead of alternating two),
  * "listed_launches" (a counter: launches rendered by block class so far; 0 resets).  Sets the value for subsequent calls of all threads
  * and returns the previous one; a value outside the switch's range only queries; an unknown name returns -1.  The
  * environment variables LRP_XSEP, LRP_QUAD, ... supply the initial values once, when the library is loaded. */
