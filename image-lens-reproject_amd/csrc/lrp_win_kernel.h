@@ -1229,7 +1229,10 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
     P.tiles_x = (P.out_w + kBlkW * kWinWaves - 1) / (kBlkW * kWinWaves);
     // strips of LRP_WIN_STRIP blocks when that still leaves >= 8 workgroups per CU, else shorter
     const int row_blocks = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
-    int G = SS ? 4 : LRP_WIN_STRIP; // (SS: a block is four rows of pixels; strips of sixteen rows like everybody's)
+#ifndef LRP_SS_STRIP
+#define LRP_SS_STRIP 4
+#endif
+    int G = SS ? LRP_SS_STRIP : LRP_WIN_STRIP; // (SS: a block is four rows of pixels; strips of sixteen rows like everybody's)
     if (GeoRead && P.blocks_per_wave > 0) G = std::min(P.blocks_per_wave, kGeoStripRows); // the caller's override (lrp_debug_set "geo_strip")
     // (a batch whose wavefronts walk several frames pipelines the windows of one block across its frames: one block per
     // wavefront measured 2-3 % faster there — equirect -> fisheye rotated 143 -> 139 us, rect -> rect 130.5 -> 128 —, four 5 % slower)
