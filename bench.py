@@ -589,6 +589,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # N > 1: the first collective of a process group sets the communicator up (RCCL: seconds, the GPU idle meanwhile).  It runs
+    # HERE, in front of the settling launches, so that the barrier in front of the timed region is a fast one on a GPU that is
+    # at its loaded clock — a first launch after idle is 10-25 % slower, and at 8 GPUs the whole timed region is ~60 ms.
+    barrier()
     t_settle = time.perf_counter()
     while time.perf_counter() - t_settle < args.settle_seconds:
         step()

@@ -3,6 +3,7 @@
 set -euo pipefail
 R="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd "$R"
 f=gpurun_out/final; r=${1:-r05}
+cp gpurun_out/traffic_${r}.json profiles/traffic_${r}.json # (written on the GPU box; only gpurun_out/ travels back)
 cp $f/bench.json profiles/${r}_bench.json
 cat "$(ls -t $f/prof_bench/*/*kernel_stats.csv | head -1)" > profiles/${r}_bench_kernel_stats.csv # (the newest: gpurun merges the passes of a round into one directory)
 cp $f/kernel_trace_by_launch_shape.txt profiles/${r}_bench_kernel_trace_by_launch_shape.txt
@@ -18,5 +19,6 @@ cp $f/sq_counters.txt profiles/${r}_sq_counters.txt
 cp $f/staged.log profiles/${r}_staged_pcie.txt
 cp $f/fov_sweep.log profiles/${r}_rect_eqr_fov_sweep.txt
 [ -f $f/hbm_stream.log ] && cp $f/hbm_stream.log profiles/${r}_hbm_stream_microbench.txt
+[ -f $f/policy_check.txt ] && cp $f/policy_check.txt profiles/${r}_policy_check.txt
 tail -3 $f/gpu_tests.log > profiles/${r}_gpu_tests_tail.txt
 echo "collected into profiles/${r}_*"

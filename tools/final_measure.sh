@@ -52,5 +52,6 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
 done
 python3 $R/tools/pmc_summary.py $R/$out/sq > $R/$out/sq_counters.txt
 cd $R
+(timeout 900 python3 tools/policy_check.py 0.05 2>&1 | grep -v amdgpu.ids > $out/policy_check.txt; echo "policy_check rc=$?" >> $out/policy_check.txt)
 python3 tools/roofline_table.py $out/bench.json $out/kernel_trace_by_launch_shape.txt > $out/roofline.md
 cat $out/bench.json
