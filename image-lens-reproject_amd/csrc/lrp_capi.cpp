@@ -33,6 +33,7 @@ hipError_t launch_tile_bilinear(const KParams &P, int out_idx, int in_mode, hipS
 hipError_t launch_tile_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
 hipError_t launch_win_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // (P.geo_mode == 2: the GeoRead kernels)
 hipError_t launch_geo_build_lists(int32_t *box, int out_w, int out_h, int in_w, int in_h, int alias_pairs, hipStream_t stream); // lrp_geo_lists.hip
+hipError_t launch_geo_census(int32_t *box, int out_w, int out_h, int in_w, int in_h, bool clear_header, hipStream_t stream); // lrp_geo_lists.hip
 hipError_t launch_pair_kernel(const KParams &P, hipStream_t stream); // lrp_tile_pair.hip
 hipError_t launch_corner_fill(const KParams &P, hipStream_t stream);
 hipError_t launch_post_process(float *data, uint32_t n_pixels, int channels, float exposure, float reinhard,
@@ -184,7 +185,7 @@ lrp::KParams make_params(const lrp_image *in, const lrp_image *out, int num_samp
 // initial values, once, when the library is loaded — nothing on a launch path calls getenv.
 //   kernel: 0 = pixel kernel, 1 = tile kernel everywhere, 2 (default) = tile kernel with the LDS-window kernel for
 //   bicubic, 3 = the same without its shared-coefficient tier and without any work sharing.  All HIP; there is no CPU path.
-enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobGeoBig, kKnobGeoLists, kKnobGeoFillStream, kKnobGeoFillFused, kKnobGeoPairs, kKnobMultiMerge, kKnobContextStreams, kKnobWinSS, kKnobListedLaunches, kKnobMergedLaunches, kKnobPairLaunches, kKnobCount };
+enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobGeoBig, kKnobGeoLists, kKnobGeoFillStream, kKnobGeoFillFused, kKnobGeoPairs, kKnobMultiMerge, kKnobContextStreams, kKnobWinTapDma, kKnobGeoCensus, kKnobWinSS, kKnobListedLaunches, kKnobMergedLaunches, kKnobPairLaunches, kKnobBigLaunches, kKnobCount };
 struct KnobSpec {
   const char *name, *env;
   int lo, hi, initial;
@@ -195,6 +196,7 @@ constexpr int kMaxSideStreams = 5;
 // a frame of corner blocks (BASELINE configs[3], 37 %: RGBA +-1 %, RGBAZ + tonemap 2-4 % ahead) and ahead beyond that (rect ->
 // fisheye 2-3 %, narrower views 10-40 %); below, the plain enumeration stays.
 constexpr unsigned kListedCornerPercent = 30;
+constexpr unsigned kBigWidePercent = 30; // in-view blocks no 10 KiB window stages, per cent: from there on the big-window variant renders a panorama source
 constexpr unsigned kMinWavesForFusedFill = 2048; // wavefronts a listed window launch must have to carry the corner runs itself
 const KnobSpec kKnobs[kKnobCount] = {
     {"kernel", "LRP_KERNEL", 0, 3, 2},
@@ -207,17 +209,20 @@ const KnobSpec kKnobs[kKnobCount] = {
     {"multi_fork", "LRP_MULTI_FORK", 0, kMaxSideStreams, 1},    // side streams of lrp_reproject_multi_device
     {"geo_cache", "LRP_GEO_CACHE", 0, 1, 1},        // geometry cache used by single launches (0: every launch computes)
     {"geo_strip", "LRP_GEO_STRIP", 0, lrp::kGeoStripRows, 0}, // blocks per wavefront of a launch that reads the geometry cache (0: automatic)
-    {"geo_big", "LRP_GEO_BIG", 0, 1, 1},            // big-window variant of the kernels that read the geometry cache (a rectilinear view rendered into a panorama); 0: the four-wavefront instantiation
+    {"geo_big", "LRP_GEO_BIG", 0, 2, 1},            // big-window variant of the kernels that read the geometry cache (a rectilinear view rendered into a panorama); 0: the four-wavefront instantiation
     {"geo_lists", "LRP_GEO_LISTS", 0, 2, 1},        // rendering by block class from the lists of a geometry-cache entry (corner runs by the fill kernel / a share per wavefront, the window kernel over the work list): 0 never, 1 where at least 30 % of the blocks are corner blocks, 2 whenever the lists are known
     {"geo_fill_stream", "LRP_GEO_FILL_STREAM", 0, 1, 0}, // the fill kernel of a listed launch: 0 in front of the window kernel on the caller's stream, 1 beside it on a side stream of the device
     {"geo_fill_fused", "LRP_GEO_FILL_FUSED", 0, 1, 1}, // the corner runs of a listed launch as a share per wavefront of the window kernel (0: always the fill kernel)
     {"geo_pairs", "LRP_GEO_PAIRS", 0, 1, 0},        // listed launches: 1 = alias pairs of in-view blocks by the pair kernel, two wavefronts per window (default 0: measured level for RGBAZ and 12-17 % slower for RGB / RGBA on BASELINE configs[3], profiles/r05_experiments_ab.txt item 8)
     {"multi_merge", "LRP_MULTI_MERGE", 0, 1, 0},     // lrp_reproject_multi_device: 1 = the outputs whose geometry-cache entries exist in ONE launch; default 0, a launch per output over the caller's stream and a side stream (measured level: 360-365 against 359-363 us per 8192^2 -> six 2048^2 cubemap)
     {"context_streams", "LRP_CONTEXT_STREAMS", 0, 1, 1}, // lrp_context: consecutive images alternate between two compute streams (0: one)
+    {"win_tapdma", "LRP_WIN_TAPDMA", 0, 1, 1},      // window kernel: passes whose window fits no buffer fetch their taps a quad of lanes per pixel row through LDS-DMA (0: a gather per lane and tap)
+    {"geo_census", "LRP_GEO_CENSUS", 0, 1, 1},      // the census of a new geometry-cache entry's windows (lrp_geo_lists.hip; what the automatic choice of the big-window variant reads); 0: not taken
     {"win_ss", "LRP_WIN_SS", 0, 1, 1},              // bicubic with num_samples == 2 through the window kernel's supersampling instantiations (0: the tile kernel, as for any other num_samples > 1)
     {"listed_launches", "LRP_LISTED_LAUNCHES_UNUSED", 0, 0, 0}, // a counter, not a switch: launches rendered by block class so far (set 0 to reset; tests, bench)
     {"merged_launches", "LRP_MERGED_LAUNCHES_UNUSED", 0, 0, 0}, // a counter: multi-output launches so far
     {"pair_launches", "LRP_PAIR_LAUNCHES_UNUSED", 0, 0, 0},     // a counter: launches of the pair kernel so far
+    {"big_launches", "LRP_BIG_LAUNCHES_UNUSED", 0, 0, 0},       // a counter: window launches through the big-window variant so far
 };
 std::atomic<int> g_knobs[kKnobCount];
 const bool g_knobs_initialised = [] { // the one place that reads the environment
@@ -382,6 +387,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     P.win_coef = kernel_choice() == 2;
     P.win_edge = (kernel_choice() == 2 && win_edge_enabled()) ? 1 : 0;
     P.win_split = (kernel_choice() == 2 && win_split_enabled()) ? 1 : 0;
+    P.win_tapdma = knob(kKnobWinTapDma) != 0 ? 1 : 0;
     // Mirror mode of the window kernel (lrp_kernel_v2.h QMode): both axes without a rotation; rows only for a pan,
     // columns only for a pitch into a rectilinear target.  Signed zeros count as zeros in the matrix tests.
     P.win_mode = P.quad == 1 ? 1 : 0;
@@ -455,7 +461,14 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
         P.quad = 0; // (tile kernels: the plain path writes / the GeoRead kernels read the map)
         P.blocks_per_wave = knob(kKnobGeoStrip); // 0: the launcher decides
         P.rgbaz_runs = (out->lens.type == LRP_EQUIRECTANGULAR && in->lens.type == LRP_RECTILINEAR) ? 1 : 0;
-        P.big_windows = knob(kKnobGeoBig) != 0 ? P.rgbaz_runs : 0;
+        // The big-window variant (lrp_win_kernel.h kBigWin: 20 KiB of LDS per wavefront, two wavefronts per SIMD, tap DMA): a
+        // rectilinear view rendered into a panorama; and any geometry out of a rectilinear or panorama source whose census
+        // (lrp_geo_lists.hip) says that at least kBigWidePercent % of its in-view blocks have windows the 10 KiB buffer of the
+        // four-wavefront kernels cannot stage (a cubemap's pole faces: 97 -> 80 us, a rectilinear view into a fisheye frame
+        // 160 -> 145; a cubemap's side faces and the ~1:1 mappings have no such block and lose 25-30 % there).
+        const bool wide = geo.mode == 2 && geo.lists && im != lrp::kInEquidistant && geo.n_inview != 0 &&
+                          (unsigned long long)geo.n_wide * 100u >= (unsigned long long)geo.n_inview * kBigWidePercent;
+        P.big_windows = knob(kKnobGeoBig) == 2 ? 1 : knob(kKnobGeoBig) != 0 ? (P.rgbaz_runs != 0 || wide ? 1 : 0) : 0; // (2: wherever the variant is instantiated)
         // Rendering by block class (lrp_params.h "Block lists"): once the lists of the entry are known, the corner blocks
         // — every pixel the one clamped corner texel — are written by the store-only fill kernel and the window kernel
         // walks the work list, which holds no corner block.  Where corner blocks are rare the plain enumeration stays.
@@ -502,6 +515,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
           g_knobs[kKnobPairLaunches].fetch_add(1, std::memory_order_relaxed);
         }
       }
+      if (window && P.geo_mode == 2 && P.big_windows != 0) g_knobs[kKnobBigLaunches].fetch_add(1, std::memory_order_relaxed);
       if (window) return lrp::launch_win_bicubic(P, oi, im, stream);
       if (interpolation == LRP_NEAREST) return lrp::launch_tile_nearest(P, oi, im, stream);
       if (interpolation == LRP_BILINEAR) return lrp::launch_tile_bilinear(P, oi, im, stream);
@@ -530,11 +544,16 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
         e = launch();
       }
     }
-    if (e == hipSuccess && window && im == lrp::kInRect && (geo.mode == 1 || geo.mode == 3) && geo.host_counts != nullptr && knob(kKnobGeoLists) != 0) {
-      // the launch above wrote the class bytes of the entry: its block lists are built behind it, and their header follows
-      // the records to the host (page-locked; read once the records' event has completed)
+    if (e == hipSuccess && window && (geo.mode == 1 || geo.mode == 3) && geo.host_counts != nullptr) {
+      // the launch above wrote the box records and the class bytes of the entry: the block lists (rectilinear source) and the
+      // census of its windows are built behind it, and their header follows the records to the host (page-locked; read once
+      // the records' event has completed)
       const uint8_t *const header = reinterpret_cast<const uint8_t *>(geo.box) + lrp::geo_lists_offset(out->width, out->height);
-      if (lrp::launch_geo_build_lists(geo.box, out->width, out->height, in->width, in->height, P.alias_pairs, stream) == hipSuccess &&
+      const bool with_lists = im == lrp::kInRect && knob(kKnobGeoLists) != 0, with_census = knob(kKnobGeoCensus) != 0 && im != lrp::kInEquidistant;
+      if (!with_lists && !with_census) {
+        // (nothing to tell the host about this entry)
+      } else if ((!with_lists || lrp::launch_geo_build_lists(geo.box, out->width, out->height, in->width, in->height, P.alias_pairs, stream) == hipSuccess) &&
+          (!with_census || lrp::launch_geo_census(geo.box, out->width, out->height, in->width, in->height, !with_lists, stream) == hipSuccess) &&
           hipMemcpyAsync(geo.host_counts, header, (size_t)lrp::kGeoListHeaderWords * 4, hipMemcpyDeviceToHost, stream) == hipSuccess)
         geo.lists_enqueued = true;
       else
@@ -773,7 +792,7 @@ int enqueue_merged_outputs(const std::vector<MergeCandidate> &cand, lrp_image *o
     P.alias_pairs = 0; // (per-geometry: the faces differ in their rotations)
     P.blocks_per_wave = knob(kKnobGeoStrip);
     P.rgbaz_runs = (outs[merged[0]].lens.type == LRP_EQUIRECTANGULAR && in->lens.type == LRP_RECTILINEAR) ? 1 : 0;
-    P.big_windows = knob(kKnobGeoBig) != 0 ? P.rgbaz_runs : 0;
+    P.big_windows = knob(kKnobGeoBig) == 2 ? 1 : knob(kKnobGeoBig) != 0 ? P.rgbaz_runs : 0; // (2: wherever the variant is instantiated — experiments)
     P.face_n = n_merged;
     for (int k = 0; k < n_merged; ++k) {
       P.face_dst[k] = outs[merged[k]].data;

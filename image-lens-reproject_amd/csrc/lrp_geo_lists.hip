@@ -10,6 +10,8 @@
 // window kernel they occupy two-per-SIMD wave slots and leave as 320-byte pieces.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "lrp_corner_fill.h"
 
 namespace lrp {
@@ -170,6 +172,53 @@ template <int CH> __global__ __launch_bounds__(64 * kFillWaves) void corner_fill
 }
 
 } // namespace
+
+// ---- the census ------------------------------------------------------------------------------------------------------
+// How many blocks of the geometry lie in the source whole (header[7]) and how many of THOSE have a window that the 10 KiB
+// buffer of the four-wavefront kernels cannot stage, neither whole nor as two halves (header[6]: the plan of lrp_win_plan.h
+// win_plan_block for RGB / RGBA, 64 columns, 640 slots) — such blocks fall to pass windows and per-pixel gathers there, and
+// are what the big-window variant with its tap DMA is for (a cubemap's pole faces: three quarters of the blocks; its side
+// faces: none).  The host reads the two counts with the list header and picks the variant per geometry.
+constexpr int kCensusThreads = 256, kCensusCap = 640, kCensusCols = 64;
+__global__ __launch_bounds__(kCensusThreads) void geo_census_kernel(const int32_t *box, uint32_t n_blocks, int in_w, int in_h, uint32_t *header) {
+  const int one = (int)f2u(1.0f), x_hi = (int)f2u((float)(in_w - 2)), y_hi = (int)f2u((float)(in_h - 2));
+  uint32_t in_view = 0, wide = 0;
+  for (uint32_t i = blockIdx.x * kCensusThreads + threadIdx.x; i < n_blocks; i += gridDim.x * kCensusThreads) {
+    const int32_t *const r = box + (size_t)i * 8;
+    if ((r[6] & 7) != 7 || r[0] < one || r[1] >= x_hi || min(r[2], r[4]) < one || max(r[3], r[5]) >= y_hi) continue;
+    ++in_view;
+    const int x_first = (int)u2f((uint32_t)r[0]), x_last = (int)u2f((uint32_t)r[1]);
+    const int ya_first = (int)u2f((uint32_t)r[2]), ya_last = (int)u2f((uint32_t)r[3]), yb_first = (int)u2f((uint32_t)r[4]), yb_last = (int)u2f((uint32_t)r[5]);
+    const int bw = x_last - x_first + 4, pitch = bw | 1;
+    const int bh = max(ya_last, yb_last) - min(ya_first, yb_first) + 4, a_rows = ya_last - ya_first + 4, b_rows = yb_last - yb_first + 4;
+    const bool staged = bw <= kCensusCols && (pitch * bh <= kCensusCap || pitch * max(a_rows, b_rows) <= kCensusCap);
+    wide += staged ? 0u : 1u;
+  }
+  // (wave-wide sums, one atomic per wavefront and count)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    in_view += __shfl_down(in_view, off);
+    wide += __shfl_down(wide, off);
+  }
+  if ((threadIdx.x & 63u) == 0) {
+    if (wide != 0) atomicAdd(&header[6], wide);
+    if (in_view != 0) atomicAdd(&header[7], in_view);
+  }
+}
+
+// Behind the launch that wrote the box records of an entry, on its stream (and behind launch_geo_build_lists where that
+// runs: `clear_header` false).
+hipError_t launch_geo_census(int32_t *box, int out_w, int out_h, int in_w, int in_h, bool clear_header, hipStream_t stream) {
+  uint32_t *const header = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(box) + geo_lists_offset(out_w, out_h));
+  if (clear_header) {
+    const hipError_t e = hipMemsetAsync(header, 0, (size_t)kGeoListHeaderWords * 4, stream);
+    if (e != hipSuccess) return e;
+  }
+  const uint32_t n_blocks = geo_block_cols(out_w) * geo_image_block_rows(out_h);
+  const unsigned grid = (unsigned)std::min<uint32_t>(256u, (n_blocks + kCensusThreads - 1) / kCensusThreads);
+  hipLaunchKernelGGL(geo_census_kernel, dim3(grid > 0 ? grid : 1), dim3(kCensusThreads), 0, stream, box, n_blocks, in_w, in_h, header);
+  return hipGetLastError();
+}
 
 // Behind the launch that wrote the class bytes of an entry, on its stream.  `box` = the entry's first box record.
 hipError_t launch_geo_build_lists(int32_t *box, int out_w, int out_h, int in_w, int in_h, int alias_pairs, hipStream_t stream) {

@@ -68,7 +68,7 @@ struct Entry {
   // block lists: the header's copy arrives in host_counts behind the launch that builds them
   uint32_t *host_counts = nullptr; // page-locked, kGeoListHeaderWords words
   bool lists_pending = false, lists_known = false;
-  uint32_t counts[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 // An evicted buffer: reusable by a stream that waits for `events`, returnable to the driver once they have completed.
@@ -266,7 +266,7 @@ void geo_acquire(const GeoKey &key, bool want_boxes, hipStream_t stream, GeoUse 
           refresh_lists(e);
           if (e.lists_known) {
             use->lists = true;
-            use->n_work = e.counts[0], use->n_runs = e.counts[1], use->n_corner_blocks = e.counts[2], use->n_blocks = e.counts[3], use->n_pairs = e.counts[4], use->n_rest = e.counts[5];
+            use->n_work = e.counts[0], use->n_runs = e.counts[1], use->n_corner_blocks = e.counts[2], use->n_blocks = e.counts[3], use->n_pairs = e.counts[4], use->n_rest = e.counts[5], use->n_wide = e.counts[6], use->n_inview = e.counts[7];
           }
         }
       }

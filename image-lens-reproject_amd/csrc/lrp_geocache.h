@@ -50,6 +50,7 @@ struct GeoUse {
   bool lists_enqueued = false;
   bool lists = false;
   uint32_t n_work = 0, n_runs = 0, n_corner_blocks = 0, n_blocks = 0, n_pairs = 0, n_rest = 0;
+  uint32_t n_wide = 0, n_inview = 0; // the census of the entry (lrp_geo_lists.hip geo_census): blocks in view whole / those of them no 10 KiB window stages
 };
 
 // Decides, for a launch that is about to be enqueued on `stream` (device already selected), whether it reads the

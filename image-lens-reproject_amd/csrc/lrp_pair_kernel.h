@@ -96,10 +96,16 @@ __global__ __launch_bounds__(128, CH == 5 ? 3 : 4) void reproject_pair_kernel(co
     int x_lo, y_lo, bw, bh, pitch;
     bool staged;
   };
-  auto window_of = [&](int i) { // the window of step i for both blocks (wave-uniform)
+  auto window_of = [&](int i, int n) { // the window of steps i .. i + n - 1 for both blocks (wave-uniform)
     Win w;
-    const int lo_x = __builtin_amdgcn_readfirstlane(min(s_ext[0][i][0], s_ext[1][i][0])), hi_x = __builtin_amdgcn_readfirstlane(max(s_ext[0][i][1], s_ext[1][i][1]));
-    const int lo_y = __builtin_amdgcn_readfirstlane(min(s_ext[0][i][2], s_ext[1][i][2])), hi_y = __builtin_amdgcn_readfirstlane(max(s_ext[0][i][3], s_ext[1][i][3]));
+    int lo_x = min(s_ext[0][i][0], s_ext[1][i][0]), hi_x = max(s_ext[0][i][1], s_ext[1][i][1]);
+    int lo_y = min(s_ext[0][i][2], s_ext[1][i][2]), hi_y = max(s_ext[0][i][3], s_ext[1][i][3]);
+    if (n == 2) {
+      lo_x = min(lo_x, min(s_ext[0][i + 1][0], s_ext[1][i + 1][0])), hi_x = max(hi_x, max(s_ext[0][i + 1][1], s_ext[1][i + 1][1]));
+      lo_y = min(lo_y, min(s_ext[0][i + 1][2], s_ext[1][i + 1][2])), hi_y = max(hi_y, max(s_ext[0][i + 1][3], s_ext[1][i + 1][3]));
+    }
+    lo_x = __builtin_amdgcn_readfirstlane(lo_x), hi_x = __builtin_amdgcn_readfirstlane(hi_x);
+    lo_y = __builtin_amdgcn_readfirstlane(lo_y), hi_y = __builtin_amdgcn_readfirstlane(hi_y);
     w.x_lo = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)lo_x)) - 1;
     w.y_lo = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)lo_y)) - 1;
     w.bw = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)hi_x)) + 2 - w.x_lo + 1;
@@ -107,6 +113,21 @@ __global__ __launch_bounds__(128, CH == 5 ? 3 : 4) void reproject_pair_kernel(co
     w.pitch = w.bw | 1;
     w.staged = w.bw <= 128 && win_slots_of_rows<CH>(w.pitch, w.bh) <= kCap; // (two DMA instructions per row at most)
     return w;
+  };
+#ifndef LRP_PAIR_HALVES
+#define LRP_PAIR_HALVES 1 // steps 0-1 and 2-3 share ONE window where the union of both fits (one round trip and two barriers fewer)
+#endif
+  // a stage: one window and the `n` steps that sample it
+  auto plan = [&](int i, Win &w, int &n) {
+    n = 1;
+    if (LRP_PAIR_HALVES != 0 && (i & 1) == 0) {
+      w = window_of(i, 2);
+      if (w.staged) {
+        n = 2;
+        return;
+      }
+    }
+    w = window_of(i, 1);
   };
   // rows wave, wave + 2, ... of window `w` by this wavefront: LDS-DMA, one window row per instruction and 64 columns, lanes
   // beyond the width masked off (lrp_win_kernel.h issue())
@@ -132,69 +153,87 @@ __global__ __launch_bounds__(128, CH == 5 ? 3 : 4) void reproject_pair_kernel(co
 #ifndef LRP_PAIR_PIPELINE
 #define LRP_PAIR_PIPELINE 1 // the window of step i + 1 is requested behind the taps of step i, ahead of its arithmetic and its store (0: after the store)
 #endif
-  Win cur = window_of(0);
+  Win cur;
+  int cur_n;
+  plan(0, cur, cur_n);
   if (cur.staged) request(cur);
+  int i = 0;
 #pragma unroll 1
-  for (int i = 0; i < 4; ++i) {
-    const int k = wave == 0 ? i : 3 - i; // this wavefront's pass of step i
+  while (i < 4) {
+    const int next_i = i + cur_n;
     Win nxt = cur;
-    if (i < 3) nxt = window_of(i + 1);
-    // (k is wave-uniform but not a constant: the four coordinate pairs are selected, not indexed — no scratch)
-    const float psx = k == 0 ? sx[0] : k == 1 ? sx[1] : k == 2 ? sx[2] : sx[3], psy = k == 0 ? sy[0] : k == 1 ? sy[1] : k == 2 ? sy[2] : sy[3];
-    Rgba s;
-    bool requested_next = false;
-    if (cur.staged) {
-      // vmcnt retires in order: the window was requested BEFORE the previous step's store — at least one store per lane and
-      // step —, so "at most one operation outstanding" means the window has landed (the first window: nothing younger)
-      if (i == 0 || LRP_PAIR_PIPELINE == 0)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-      __syncthreads(); // ... and so have the partner's rows
-      const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
-      const int slot0 = __mul24((int)ty_ - 1 - cur.y_lo, cur.pitch) + ((int)tx_ - 1 - cur.x_lo);
-      s = win_tier_raw<CH>(s_win + slot0, cur.pitch, reinterpret_cast<const float *>(s_win + cur.pitch * cur.bh) + slot0, psx - tx_, psy - ty_, [&]() {
-        // behind this wavefront's last read of the window: once both wavefronts are here the next window may overwrite it
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (LRP_PAIR_PIPELINE != 0 && i < 3 && nxt.staged) {
+    int nxt_n = 1;
+    if (next_i < 4) plan(next_i, nxt, nxt_n);
+    const bool more = next_i < 4 && nxt.staged;
+#pragma unroll 1
+    for (int j = 0; j < cur_n; ++j) {
+      const int step = i + j;
+      const bool first = j == 0, last = j == cur_n - 1;
+      const int k = wave == 0 ? step : 3 - step; // this wavefront's pass of the step
+      // (k is wave-uniform but not a constant: the four coordinate pairs are selected, not indexed — no scratch)
+      const float psx = k == 0 ? sx[0] : k == 1 ? sx[1] : k == 2 ? sx[2] : sx[3], psy = k == 0 ? sy[0] : k == 1 ? sy[1] : k == 2 ? sy[2] : sy[3];
+      Rgba s;
+      bool requested_next = false;
+      if (cur.staged) {
+        if (first) {
+          // vmcnt retires in order: the window was requested BEFORE the previous step's store — at least one store per lane and
+          // step —, so "at most one operation outstanding" means the window has landed (the first window: nothing younger)
+          if (i == 0 || LRP_PAIR_PIPELINE == 0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+          // (a bare s_barrier: __syncthreads() is a fence as well — s_waitcnt vmcnt(0) lgkmcnt(0) in front of the barrier — and
+          // would make every step wait for the previous step's STORE to be acknowledged; the waits that matter are the counted ones)
+          asm volatile("s_barrier" ::: "memory"); // ... and so have the partner's rows
+        }
+        const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
+        const int slot0 = __mul24((int)ty_ - 1 - cur.y_lo, cur.pitch) + ((int)tx_ - 1 - cur.x_lo);
+        s = win_tier_raw<CH>(s_win + slot0, cur.pitch, reinterpret_cast<const float *>(s_win + cur.pitch * cur.bh) + slot0, psx - tx_, psy - ty_, [&]() {
+          if (!last) return;
+          // behind this wavefront's last read of the window: once both wavefronts are here the next window may overwrite it
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          asm volatile("s_barrier" ::: "memory");
+          if (LRP_PAIR_PIPELINE != 0 && more) {
+            request(nxt);
+            requested_next = true;
+          }
+        });
+      } else {
+        // nothing of this step reads the window: the next one is requested in front of this step's gathers
+        if (LRP_PAIR_PIPELINE != 0 && more) {
           request(nxt);
           requested_next = true;
         }
-      });
-    } else {
-      // nothing of this step reads the window: the next one is requested in front of this step's gathers
-      if (LRP_PAIR_PIPELINE != 0 && i < 3 && nxt.staged) {
-        request(nxt);
-        requested_next = true;
+        if constexpr (CH == 5) {
+          const Px<5> s5 = sample_direct<2, false, 5>(P, src, psx, psy);
+          s = Rgba{s5.lo, s5.hi, s5.e};
+        } else {
+          s = sample_direct<2, false, 4, false, 4 * CH>(P, src, psx, psy);
+        }
       }
+      // src/reproject.cpp:334-341 with num_samples == 1: (0.0f + s) * 1.0f, the fused post_process, the store
+      Rgba a4 = px_zero<4>();
+      px_add<4>(a4, s);
+      if constexpr (CH == 5) a4.e = 0.0f + s.e;
+      const Px<CH> a{a4.lo, CH >= 4 ? a4.hi : f2{0.0f, 0.0f}, CH == 3 ? a4.hi.x : a4.e};
+      const int y_top = y_blk + kPassRows * k;
+      const int ye = min(y_top + prow, P.out_h - 1);
+      bool stored_as_run = false;
       if constexpr (CH == 5) {
-        const Px<5> s5 = sample_direct<2, false, 5>(P, src, psx, psy);
-        s = Rgba{s5.lo, s5.hi, s5.e};
-      } else {
-        s = sample_direct<2, false, 4, false, 4 * CH>(P, src, psx, psy);
+        if (x_blk + kBlkW <= P.out_w && y_top + kPassRows <= P.out_h) { // the pass lies in the image whole: four runs of 16 pixels
+          float c[5];
+          finish_px<5, true>(P, a, c);
+          store_rgbaz_run<4>(P, out_lds, prow * kBlkW + pcol, (uint32_t)y_top * (uint32_t)P.out_w + (uint32_t)x_blk, P.out_w, c);
+          stored_as_run = true;
+        }
       }
+      // (lanes / rows beyond the image hold the pixel they were clamped to and write its value to its place again)
+      if (!stored_as_run) store_px<CH, true>(P, (uint32_t)ye * (uint32_t)P.out_w + (uint32_t)xe, a);
+      if (last && more && !requested_next) request(nxt);
     }
-    // src/reproject.cpp:334-341 with num_samples == 1: (0.0f + s) * 1.0f, the fused post_process, the store
-    Rgba a4 = px_zero<4>();
-    px_add<4>(a4, s);
-    if constexpr (CH == 5) a4.e = 0.0f + s.e;
-    const Px<CH> a{a4.lo, CH >= 4 ? a4.hi : f2{0.0f, 0.0f}, CH == 3 ? a4.hi.x : a4.e};
-    const int y_top = y_blk + kPassRows * k;
-    const int ye = min(y_top + prow, P.out_h - 1);
-    bool stored_as_run = false;
-    if constexpr (CH == 5) {
-      if (x_blk + kBlkW <= P.out_w && y_top + kPassRows <= P.out_h) { // the pass lies in the image whole: four runs of 16 pixels
-        float c[5];
-        finish_px<5, true>(P, a, c);
-        store_rgbaz_run<4>(P, out_lds, prow * kBlkW + pcol, (uint32_t)y_top * (uint32_t)P.out_w + (uint32_t)x_blk, P.out_w, c);
-        stored_as_run = true;
-      }
-    }
-    // (lanes / rows beyond the image hold the pixel they were clamped to and write its value to its place again)
-    if (!stored_as_run) store_px<CH, true>(P, (uint32_t)ye * (uint32_t)P.out_w + (uint32_t)xe, a);
-    if (i < 3 && nxt.staged && !requested_next) request(nxt);
+    i = next_i;
     cur = nxt;
+    cur_n = nxt_n;
   }
 }
 

@@ -89,6 +89,7 @@ struct KParams {
   int32_t win_mode;                 // window kernel: 0 plain blocks, 1 blocks mirrored in both axes (== quad 1), 2 rows only (pan), 3 columns only (pitch), 4 shared rays (equidistant target, any rotation)
   int32_t win_edge;    // window kernel: blocks beyond one side of the source stage one source row / column (LRP_WIN_EDGE=0: per-pixel gathers)
   int32_t win_split;   // window kernel: blocks whose window exceeds the buffer stage the windows of their two halves one after the other (LRP_WIN_SPLIT=0: per-pixel gathers)
+  int32_t win_tapdma;  // window kernel: a pass whose window fits no buffer fetches its taps quad by quad through LDS-DMA (lrp_win_kernel.h tap_dma; 0: per-pixel gathers)
   // Geometry cache (lrp_geocache.h): what a single launch would re-derive from the geometry alone — the source
   // coordinates of every output pixel and, for the window kernel, the window extremes of every 16 x 16 block — kept in
   // HBM between calls.  geo_mode 0: not used; 1: this launch computes as usual and writes the entry as a side output;
@@ -132,6 +133,7 @@ struct GeoLayout {
 };
 // Block lists, behind the class bytes (built once per entry by geo_build_lists, lrp_geo_lists.hip, from the class bytes):
 //   header  kGeoListHeaderWords words: [0] work entries, [1] runs, [2] corner blocks, [3] blocks of the image, [4] pair entries, [5] rest entries
+//           [6] blocks in view whole that no 10 KiB window stages, [7] blocks in view whole (the census, lrp_geo_lists.hip)
 //   work    pairs (block column, block row) of every block that is NOT a corner block, in the order the window kernel's
 //           launch would reach them: entry i goes to workgroup i, i.e. to XCD i % 8, and the entries of one XCD are its
 //           rows of blocks (row % 8 == XCD) in raster order with the corner blocks taken out (alias pairs stay neighbours);

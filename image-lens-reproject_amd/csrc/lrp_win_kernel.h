@@ -123,8 +123,8 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   constexpr int kBlockRows = SS ? kPassRows : kBlkH; // output rows of a block (SS: the four passes are the sub-samples of ONE row group)
   static_assert(QMode != 2 || (OutLens != kEquidistant && InMode != kInEquidistant), "rows-only mirroring goes through the column-separable source x");
   static_assert(QMode != 3 || OutLens == kRect, "columns-only mirroring needs vz == -1");
-  static_assert(!GeoRead || (QMode == 0 && (OutLens == kRect || (OutLens == kEquirect && InMode == kInRect && !Frames))),
-                "GeoRead: plain blocks, one instantiation per source mode (+ the big-window variant of the rectilinear source)");
+  static_assert(!GeoRead || (QMode == 0 && (OutLens == kRect || (OutLens == kEquirect && !Frames))),
+                "GeoRead: plain blocks, one instantiation per source mode (+ the big-window variants)");
   // The big-window variant (GeoRead, "OutLens" kEquirect by convention; chosen by the host for a rectilinear view rendered
   // into a panorama, BASELINE configs[3]): the in-view blocks of that mapping are minified 3-5 x 1.5-3 — the window of a 16 x 4
   // PASS is ~67 x 11 texels, too wide for one DMA instruction per row and too large for 10 KiB next to three other
@@ -194,7 +194,22 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   // fisheye-target kernels the extra code cost 2.5 % (equirect -> fisheye single launches 247 -> 253 us).
   constexpr bool kPassWin = (kSplit || (GeoRead && OutLens == kEquirect)) && LRP_WIN_PASSWIN != 0 && (OutLens == kRect || GeoRead || (InMode == kInRect && CH == 5));
   constexpr int kPlanes = 3;
-  __shared__ float4 s_win[kWinWaves][kCap];
+#ifndef LRP_WIN_ROLLED_UNSTAGED
+#define LRP_WIN_ROLLED_UNSTAGED 1 // the big-window variant: blocks with nothing staged run their passes in one rolled loop (below)
+#endif
+#ifndef LRP_WIN_PASS_PIPELINE
+#define LRP_WIN_PASS_PIPELINE 1 // ... and request what pass k + 1 reads behind the taps of pass k (0: in front of pass k + 1, on the spot)
+#endif
+#ifndef LRP_WIN_TAPDMA
+#define LRP_WIN_TAPDMA 1 // the big-window variant: tap DMA (below) compiled in
+#endif
+  // Tap DMA (big-window variant; tap_dma below) needs 1024 slots for the colour taps of a pass — and, RGBAZ, 1024 floats for their
+  // depths behind them: exactly the 18.75 KiB window + the 1.25 KiB exchange buffer of the stores, which therefore lie in ONE
+  // array (the exchange buffer is written behind the pixel's last tap read and read back before the next pass requests anything).
+  constexpr bool kTapDma = kBigWin && kWinWaves == 1 && LRP_WIN_TAPDMA != 0 && LRP_WIN_ROLLED_UNSTAGED != 0;
+  constexpr int kOutSlots = (CH == 5 && kTapDma) ? 80 : 0; // 320 floats
+  static_assert(!kTapDma || (CH == 5 ? (kCap + kOutSlots) * 16 >= 1024 * 20 : kCap >= 1027), "tap DMA: 16 taps x 64 pixels");
+  __shared__ float4 s_win[kWinWaves][kCap + kOutSlots];
 
   // A listed launch may also hand every wavefront a share of the corner runs (Pk.geo_fill_per_wave row segments each,
   // lrp_corner_fill.h): a few store instructions at the very end of its life, when nothing else of it is live and nothing
@@ -312,7 +327,9 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   float4 *const win0 = s_win[wave];
   constexpr bool kRunsEverywhere = CH == 5 && (OutLens == kEquirect || GeoRead) && InMode == kInRect; // (GeoRead: and P.rgbaz_runs)
   float *out_lds = nullptr; // RGBAZ: the wavefront's exchange buffer of store_rgbaz_run (three waves per SIMD: the LDS is there)
-  if constexpr (CH == 5) {
+  if constexpr (CH == 5 && kOutSlots != 0) {
+    out_lds = reinterpret_cast<float *>(win0 + kCap);
+  } else if constexpr (CH == 5) {
     __shared__ __attribute__((aligned(16))) float s_out[kWinWaves][320];
     out_lds = s_out[wave];
   }
@@ -1007,6 +1024,91 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     s = window_sample(w, psx, psy, last_pass);
     return true;
   };
+  // Tap DMA (big-window variant).  A pass whose window fits no buffer — the view minified four times and more: the 4 x 4
+  // footprints of neighbouring pixels no longer overlap, a window would stage mostly texels nobody reads — gathers 16 taps per
+  // pixel; a gather per lane touches 64 different cache lines per instruction (BASELINE configs[3]: 38 % of the in-view pixels,
+  // 45 M of the launch's 54 M L1 accesses, PMC).  Here the FOUR LANES OF A QUAD fetch the four consecutive texels of one pixel's
+  // tap row — 64 bytes, one line or two — by LDS-DMA: instruction (t, r) fetches row r of pixel t of every quad into 64
+  // consecutive slots, 16 instructions (RGBAZ: + 16 for the depths) land the pass's 1024 taps in LDS at 16 slots per pixel, and
+  // the pixel reads them back as a window of pitch 64 (the raw-tap tier: same taps, same operations, same bits).  Bank
+  // conflicts: RGBA / RGB skew the four groups by one slot each (conflict-free); RGBAZ has not one spare byte, its quads are
+  // rotated by t positions within their row of 16 lanes instead (two-way).
+  // The passes of a block with nothing staged (the rolled loop below): pass k + 1 is planned and REQUESTED behind the last tap
+  // read of pass k — its own window where that fits, else its taps — so that its round trip runs under the arithmetic and the
+  // store of pass k (a wavefront of this variant has one neighbour on its SIMD to cover for it, not three).
+  struct PassWin {
+    int x_lo, y_lo, bw, bh, pitch;
+  };
+  const uint32_t pass_lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win0);
+  auto plan_pass = [&](PassWin &w, float psx, float psy) -> bool { // (interior: the coordinates are >= 1, their bits order like integers)
+    int lo_x = (int)f2u(psx), hi_x = lo_x, lo_y = (int)f2u(psy), hi_y = lo_y, d0 = 0, d1 = 0;
+    wave_box(lo_x, hi_x, lo_y, hi_y, d0, d1);
+    w.x_lo = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)lo_x)) - 1;
+    w.y_lo = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)lo_y)) - 1;
+    w.bw = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)hi_x)) + 2 - w.x_lo + 1;
+    w.bh = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)hi_y)) + 2 - w.y_lo + 1;
+    w.pitch = w.bw | 1;
+    return w.bw <= kMaxPassCols && slots_of_rows(w.pitch, w.bh) <= kCap;
+  };
+  auto request_pass = [&](const PassWin &w) { // one window row and 64 columns per instruction, lanes beyond the width masked off (issue())
+    const int n_chunks = (w.bw + 63) >> 6;
+    for (int chunk = 0; chunk < n_chunks; ++chunk)
+      if (chunk * 64 + lane < w.bw) {
+        const uint32_t lane_bytes = (uint32_t)(w.x_lo + chunk * 64 + lane) * (4u * CH);
+        const char *row = reinterpret_cast<const char *>(P.src) + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)w.y_lo * src.row_bytes));
+        uint32_t lds = pass_lds0 + (uint32_t)(chunk * 64) * 16u, lds_d = pass_lds0 + (uint32_t)(w.pitch * w.bh) * 16u + (uint32_t)(chunk * 64) * 4u;
+        for (int r = 0; r < w.bh; ++r) {
+          if constexpr (CH == 3)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %2" : : "s"(lds), "v"(lane_bytes), "s"(row) : "memory", "m0");
+          else
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds), "v"(lane_bytes), "s"(row) : "memory", "m0");
+          if constexpr (CH == 5) // depth: the float plane behind the colour plane
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(lds_d), "v"(lane_bytes), "s"(row + 16) : "memory", "m0");
+          row += src.row_bytes;
+          lds += (uint32_t)w.pitch * 16u;
+          lds_d += (uint32_t)w.pitch * 4u;
+        }
+      }
+  };
+  auto request_taps = [&](float psx, float psy) {
+    const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
+    constexpr uint32_t T = 4u * CH;
+    const uint32_t v0 = __umul24((uint32_t)((int)ty_ - 1), src.row_bytes) + (uint32_t)((int)tx_ - 1) * T; // tap (0, 0) of this lane's pixel
+    const char *const base = reinterpret_cast<const char *>(P.src);
+    const int j = lane & 3;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      // the lane whose pixel this lane helps to fetch in group t
+      const int from = CH == 5 ? ((lane & 48) | ((((lane >> 2) - t) & 3) << 2) | t) : ((lane & ~3) | t);
+      const uint32_t vt = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)v0) + (uint32_t)j * T;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t off = vt + (uint32_t)r * src.row_bytes;
+        const uint32_t lds = pass_lds0 + (uint32_t)(((4 * t + r) * 64 + (CH == 5 ? 0 : t)) * 16);
+        if constexpr (CH == 3)
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %2" : : "s"(lds), "v"(off), "s"(base) : "memory", "m0");
+        else
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds), "v"(off), "s"(base) : "memory", "m0");
+        if constexpr (CH == 5) {
+          const uint32_t lds_d = pass_lds0 + 1024u * 16u + (uint32_t)((4 * t + r) * 64 * 4);
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(lds_d), "v"(off), "s"(base + 16) : "memory", "m0");
+        }
+      }
+    }
+  };
+  // plans pass `k` (coordinates psx, psy) and requests what it will read: 1 its own window `w`, 2 its taps, 0 nothing (it gathers)
+  auto prepare_pass = [&](PassWin &w, float psx, float psy) -> int {
+    if (!all_interior(psx, psy, 1.0f, src.x_hi, src.y_hi, 2.0f)) return 0;
+    const bool fits = kPassWin && P.win_split != 0 && plan_pass(w, psx, psy);
+    if (!fits && !(kTapDma && P.win_tapdma != 0)) return 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // every earlier read of the buffer (and of the exchange buffer in its tail) has returned
+    if (fits) {
+      request_pass(w);
+      return 1;
+    }
+    request_taps(psx, psy);
+    return 2;
+  };
 #pragma unroll 1
   for (int g = 0; g < G; ++g) {
    g_loop = g;
@@ -1056,6 +1158,105 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
       if (!dma_early && has_next()) issue_next();
       if (last_frame) cur = nxt;
       continue;
+    }
+    // The big-window variant: a block with nothing staged — its four passes take a window of their own, tap DMA or gathers,
+    // decided pass by pass — runs them in ONE rolled loop: the three paths exist once instead of four times (the unrolled passes
+    // below then hold the staged tiers only), 27 KB less code and the registers of the staged tiers are not shared with the
+    // gathers' 80 tap registers.
+    constexpr bool kRolledUnstaged = kBigWin && LRP_WIN_ROLLED_UNSTAGED != 0;
+    if constexpr (kRolledUnstaged) {
+      if (!t_staged && !t_coef && t_edge == 0) {
+        // (k is wave-uniform but not a constant: the coordinates are selected, not indexed — no scratch)
+        // (... and from opaque copies: a chain of selects over the elements of one array is turned back into an indexed load)
+        float x0 = cur.sx[0], x1 = cur.sx[1], x2 = cur.sx[2], x3 = cur.sx[3], y0 = cur.sy[0], y1 = cur.sy[1], y2 = cur.sy[2], y3 = cur.sy[3];
+        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));
+        auto pass_x = [&](int k) { return k == 0 ? x0 : k == 1 ? x1 : k == 2 ? x2 : x3; };
+        auto pass_y = [&](int k) { return k == 0 ? y0 : k == 1 ? y1 : k == 2 ? y2 : y3; };
+        // (RGBAZ: on the spot — its taps fill the buffer to the last byte, the exchange buffer of the stores in its tail included,
+        // and can only be requested once the previous pass has left; with the request in two places its kernel is 3 % slower)
+        constexpr bool kPipeline = LRP_WIN_PASS_PIPELINE != 0 && kOutSlots == 0;
+        PassWin w;
+        int kind = 0;
+        bool behind_store = true; // what this pass reads was requested behind the previous pass's store: nothing younger in flight
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+          if (k == 3 && g + 1 < G && last_frame) geo_plan(nxt, geo_class(g + 1));
+          const float psx = pass_x(k), psy = pass_y(k);
+          if constexpr (!kPipeline) { // planned, requested, waited for and read on the spot
+            const bool last_pass = k == 3;
+            Rgba s;
+            if (kPassWin && P.win_split != 0 && pass_window(psx, psy, s, last_pass)) {
+              // (rendered from the window of this pass)
+            } else if (kTapDma && P.win_tapdma != 0 && all_interior(psx, psy, 1.0f, src.x_hi, src.y_hi, 2.0f)) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // every earlier read of the buffer (and of the exchange buffer in its tail) has returned
+              request_taps(psx, psy);
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the taps (and every older store)
+              const int j = lane & 3;
+              const int slot0 = CH == 5 ? (256 * j + (lane & 48) + ((((lane >> 2) + j) & 3) << 2)) : (257 * j + (lane & ~3));
+              s = win_tier_raw<CH>(win0 + slot0, 64, reinterpret_cast<const float *>(win0 + 1024) + slot0, psx - __builtin_truncf(psx), psy - __builtin_truncf(psy), [&]() {
+                if (last_pass) next_window(); // behind the last reads of the taps
+              });
+            } else {
+              if (last_pass) next_window(); // nothing staged: no tap of this block reads the window
+              if constexpr (CH == 5) {
+                const Px<5> s5 = sample_direct<2, Loop, 5, LRP_WIN_MINWAVES5 >= 4>(P, src, psx, psy);
+                s = Rgba{s5.lo, s5.hi, s5.e};
+              } else {
+                s = sample_direct<2, Loop, 4, (LRP_WIN_MINWAVES >= 5), 4 * CH>(P, src, psx, psy);
+              }
+            }
+            emit(g, k, s, std::integral_constant<bool, kRunsEverywhere>{}, !GeoRead || P.rgbaz_runs != 0);
+            continue;
+          }
+          if (k == 0) {
+            kind = prepare_pass(w, psx, psy);
+            behind_store = true;
+          }
+          const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
+          int next_kind = 0;
+          PassWin wn = w;
+          // behind the pass's last read of the buffer: the next block's window (last pass), else what pass k + 1 reads
+          auto after_reads = [&]() {
+            if (k == 3)
+              next_window();
+            else if (kPipeline)
+              next_kind = prepare_pass(wn, pass_x(k + 1), pass_y(k + 1));
+          };
+          Rgba s;
+          if (kind != 0) {
+            // vmcnt retires in order: what this pass reads was requested in front of the previous pass's store, or behind it
+            if (behind_store)
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else
+              asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            if (kind == 1) {
+              const int slot0 = __mul24((int)ty_ - 1 - w.y_lo, w.pitch) + ((int)tx_ - 1 - w.x_lo);
+              s = win_tier_raw<CH>(win0 + slot0, w.pitch, reinterpret_cast<const float *>(win0 + w.pitch * w.bh) + slot0, psx - tx_, psy - ty_, after_reads);
+            } else { // (the taps: a window of constant pitch — every row offset is an immediate of the read)
+              const int j = lane & 3;
+              const int slot0 = CH == 5 ? (256 * j + (lane & 48) + ((((lane >> 2) + j) & 3) << 2)) : (257 * j + (lane & ~3));
+              s = win_tier_raw<CH>(win0 + slot0, 64, reinterpret_cast<const float *>(win0 + 1024) + slot0, psx - tx_, psy - ty_, after_reads);
+            }
+          } else {
+            after_reads(); // nothing of this pass reads the buffer
+            if constexpr (CH == 5) {
+              const Px<5> s5 = sample_direct<2, Loop, 5, LRP_WIN_MINWAVES5 >= 4>(P, src, psx, psy);
+              s = Rgba{s5.lo, s5.hi, s5.e};
+            } else {
+              s = sample_direct<2, Loop, 4, (LRP_WIN_MINWAVES >= 5), 4 * CH>(P, src, psx, psy);
+            }
+          }
+          emit(g, k, s, std::integral_constant<bool, kRunsEverywhere>{}, !GeoRead || P.rgbaz_runs != 0);
+          if constexpr (kPipeline) {
+            behind_store = false;
+            kind = next_kind;
+            w = wn;
+          }
+        }
+        if (!dma_early && has_next()) issue_next();
+        if (last_frame) cur = nxt;
+        continue;
+      }
     }
     if (t_edge == 1 || t_edge == 2) edge_plane(cur);
 #pragma unroll
@@ -1111,6 +1312,8 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
           const int slot0 = cur.org() + __mul24((int)ty_ - 1 - (kSplit ? cur.first_row_of(half) : cur.y_lo), cur.spitch()) + ((int)tx_ - 1 - cur.x_lo);
           s = win_tier_raw<CH>(win + slot0, cur.spitch(),
                                reinterpret_cast<const float *>(win + cur.pitch * (kSplit ? cur.rows_of(half) : cur.bh)) + slot0, psx - tx_, psy - ty_, after_reads);
+        } else if (kRolledUnstaged) {
+          __builtin_unreachable(); // (rendered by the rolled loop above)
         } else if (kPassWin && P.win_split != 0 && pass_window(psx, psy, s, last_pass)) {
           // (rendered from the window of this pass)
         } else {
@@ -1186,8 +1389,11 @@ template <int CH> struct WinGeoKernelTable {
         reproject_bicubic_win_kernel<kRect, kInRect, 0, CH, false, true>, reproject_bicubic_win_kernel<kRect, kInEquidistant, 0, CH, false, true>,
         reproject_bicubic_win_kernel<kRect, kInEquirect, 0, CH, false, true>, reproject_bicubic_win_kernel<kRect, kInEquirectLoop, 0, CH, false, true>};
     if (big_windows && in_mode == kInRect) return reproject_bicubic_win_kernel<kEquirect, kInRect, 0, CH, false, true>;
-    // (a big-window variant for the wrapping panorama source, measured: the pole face of the 8192^2 -> 2048^2 cubemap 108.6 ->
-    // 103.9 us, its side faces 59.8 -> 67.2, every 4096^2 mapping out of a panorama 20-25 % slower — not instantiated)
+    // ... and of the panorama sources, for geometries whose census says so (lrp_capi.cpp kBigWidePercent)
+    if (big_windows && in_mode == kInEquirect) return reproject_bicubic_win_kernel<kEquirect, kInEquirect, 0, CH, false, true>;
+    if (big_windows && in_mode == kInEquirectLoop) return reproject_bicubic_win_kernel<kEquirect, kInEquirectLoop, 0, CH, false, true>;
+    // (round 4, without tap DMA: the pole face of the 8192^2 -> 2048^2 cubemap 108.6 -> 103.9 us, its side faces 59.8 -> 67.2, every
+    // 4096^2 mapping out of a panorama 20-25 % slower; round 5 with tap DMA: pole face 97 -> 80, side faces 48 -> 60 — hence per geometry)
     return table[in_mode];
   }
 };
@@ -1265,6 +1471,7 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
     // a rectilinear view inside a panorama: a quarter of the strips (the ones in view) carry most of the frame's time and
     // gain nothing from shared coordinates (they wait for gathers) — 16 frames long they unbalance the launch (223 -> 256 us)
     if (out_idx == 2 && in_mode == kInRect) F = 1;
+    if (GeoRead && P.big_windows != 0) F = 1; // (the big-window variant has no frame loop: a wavefront per block and frame)
     if (frames_override > 0) F = std::max(1, std::min(P.batch_n, frames_override)); // the caller's override (lrp_debug_set "batch_frames": A/B runs, tests)
     if (P.geo_mode == 1 || P.geo_mode == 3) F = 1; // the launch that writes a geometry-cache entry: the instantiations without the frame loop have the side output
     if (SS) F = 1;

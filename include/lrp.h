@@ -118,12 +118,14 @@ int lrp_debug_kernel(int choice);
  * "win_edge", "win_split", "geo_cache" (0 / 1: a sharing or staging path of the tile / window kernels off / on — the bits
  * do not change), "batch_frames" (frames per wavefront of a batched launch, 0 = automatic),
  * "multi_fork" (side streams of lrp_reproject_multi_device, 0-5), "geo_strip" (blocks per wavefront of a launch that reads the
- * geometry cache, 0 = automatic), "geo_big" (0: no big-window variant for a rectilinear view rendered into a panorama),
+ * geometry cache, 0 = automatic), "geo_big" (the big-window variant of those kernels: 1 = a rectilinear view rendered into a panorama and every geometry whose census says that
+ * 30 % of its in-view blocks are too large for a 10 KiB window, 0 = never, 2 = always),
  * "geo_lists" (rendering by block class from the lists of a geometry-cache entry: 0 never, 1 where corner blocks are at least
  * 30 % of the frame, 2 whenever the lists are known), "geo_fill_fused" (0: the corner runs of such a launch always by the fill kernel, not as a share per
  * wavefront of the window kernel), "geo_fill_stream" (1: that fill kernel on a side stream), "geo_pairs" (1: the pair kernel — alias pairs of in-view blocks, a rectilinear view
  * and its copy behind the camera in a full panorama, two wavefronts per staged window — in a listed launch; default 0: not faster), "multi_merge" (1: lrp_reproject_multi_device merges the outputs whose
- * geometry-cache entries exist into one launch; default 0: a launch per output, measured level), "merged_launches" (a counter), "context_streams" (0: an lrp_context keeps all its kernels on one compute stream instead of alternating two),
+ * geometry-cache entries exist into one launch; default 0: a launch per output, measured level), "merged_launches", "big_launches" (counters), "context_streams" (0: an lrp_context keeps all its kernels on one compute stream instead of alternating two),
+ * "win_tapdma" (0: passes of the big-window variant whose window fits no buffer gather per lane instead of fetching their taps quad by quad through LDS-DMA),
  * "listed_launches" (a counter: launches rendered by block class so far; 0 resets).  Sets the value for subsequent calls of all threads
  * and returns the previous one; a value outside the switch's range only queries; an unknown name returns -1.  The
  * environment variables LRP_XSEP, LRP_QUAD, ... supply the initial values once, when the library is loaded. */

@@ -65,7 +65,9 @@ def _small_setup(lrp, torch, case):
 
 
 def _small_render(lrp, torch, case, d_in, lin, lout, rot, stream=None, interp=None):
-    d_out = torch.full((case["oh"], case["ow"], case["c"]), -12345.0, dtype=torch.float32, device="cuda")
+    # (the fill of the output runs on the stream the launch goes to: torch's streams do not wait for its default stream)
+    with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
+        d_out = torch.full((case["oh"], case["ow"], case["c"]), -12345.0, dtype=torch.float32, device="cuda")
     lrp.reproject(lrp.Image(lin, case["iw"], case["ih"], case["c"], d_in),
                   lrp.Image(lout, case["ow"], case["oh"], case["c"], d_out), 1, case["interp"] if interp is None else interp, rot,
                   stream=stream)
@@ -443,7 +445,8 @@ def test_eight_threads_one_evicting(lrp, oracle, torch_cuda):
     barrier = threading.Barrier(8)
 
     def render(k, stream):
-        out = torch.full((oh, ow, c), -12345.0, dtype=torch.float32, device="cuda")
+        with torch.cuda.stream(stream):  # (the fill on the stream of the launch: torch's streams do not wait for its default stream)
+            out = torch.full((oh, ow, c), -12345.0, dtype=torch.float32, device="cuda")
         t0 = time.perf_counter()
         lrp.reproject(lrp.Image(lin, iw, ih, c, d_in), lrp.Image(lout, ow, oh, c, out), 1, 2, rots[k], stream=stream)
         dt = time.perf_counter() - t0
