@@ -129,11 +129,14 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   // into a panorama, BASELINE configs[3]): the in-view blocks of that mapping are minified 3-5 x 1.5-3 — the window of a 16 x 4
   // PASS is ~67 x 11 texels, too wide for one DMA instruction per row and too large for 10 KiB next to three other
   // wavefronts' — so this variant holds 20 KiB per wavefront (two wavefronts per SIMD, no register limit to speak of) and
-  // stages pass windows up to 128 texels wide.  tools/microbench/row_gather.hip: rows of that shape arrive at 7.7 TB/s by
+  // stages the windows of single passes (and fetches the taps of the passes that have none: tap DMA below).  tools/microbench/row_gather.hip: rows of that shape arrive at 7.7 TB/s by
   // LDS-DMA with 8 wavefronts per CU, a window each in flight; per-pixel gathers of the same bytes at 4.5 TB/s in this kernel.
   constexpr bool kBigWin = GeoRead && OutLens == kEquirect;
   constexpr int kCap = kBigWin ? (CH == 5 ? LRP_WIN_CAP_BIG5 : LRP_WIN_CAP_BIG) : kWinCap; // 16-byte slots of this instantiation's window buffer
-  constexpr int kMaxPassCols = kBigWin ? 128 : 64;          // widest pass window (texels): DMA instructions per window row = ceil(bw / 64)
+#ifndef LRP_BIG_PASSCOLS
+#define LRP_BIG_PASSCOLS 64 // (128 — two DMA instructions per row for the wider ones — measured 1 % slower once such passes can fetch their taps instead)
+#endif
+  constexpr int kMaxPassCols = kBigWin ? LRP_BIG_PASSCOLS : 64; // widest pass window (texels): DMA instructions per window row = ceil(bw / 64)
   constexpr bool kGeoWrite = !GeoRead && !Frames && QMode == 0 && kWinWaves == 1 && !SS; // (P.geo_mode == 1: the side output)
   const bool geo_write = kGeoWrite && (Pk.geo_mode == 1 || Pk.geo_mode == 3) && blockIdx.y == 0; // wave-uniform (3: the extremes only — the map is there; a batched launch: its first frame writes)
   // Frames of a batched launch share one geometry: the source coordinates of a pixel, the window of a block and its tier
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
 #define LRP_BIG_SPLIT4 1 // the big-window RGBA variant stages half blocks too, like the RGBAZ one (rect -> equirect 4096^2: 210 -> 203 us single, 191 -> 184 batched)
 #endif
 #ifndef LRP_BIG_MAXCOLS
-#define LRP_BIG_MAXCOLS 64 // widest block / half-block window of the big-window variant (pass windows: 128)
+#define LRP_BIG_MAXCOLS 64 // widest block / half-block window of the big-window variant (pass windows: LRP_BIG_PASSCOLS)
 #endif
   constexpr bool kSplit = LRP_WIN_SPLIT != 0 && !Frames && (InMode == kInEquirect || InMode == kInEquirectLoop || (InMode == kInRect && CH == 5) || (kBigWin && LRP_BIG_SPLIT4 != 0));
   constexpr int kMaxStagedCols = kBigWin ? LRP_BIG_MAXCOLS : 64;
@@ -203,13 +206,17 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
 #ifndef LRP_WIN_TAPDMA
 #define LRP_WIN_TAPDMA 1 // the big-window variant: tap DMA (below) compiled in
 #endif
-  // Tap DMA (big-window variant; tap_dma below) needs 1024 slots for the colour taps of a pass — and, RGBAZ, 1024 floats for their
+  // Tap DMA (big-window variant; request_taps below) needs 1024 slots for the colour taps of a pass — and, RGBAZ, 1024 floats for their
   // depths behind them: exactly the 18.75 KiB window + the 1.25 KiB exchange buffer of the stores, which therefore lie in ONE
   // array (the exchange buffer is written behind the pixel's last tap read and read back before the next pass requests anything).
   constexpr bool kTapDma = kBigWin && kWinWaves == 1 && LRP_WIN_TAPDMA != 0 && LRP_WIN_ROLLED_UNSTAGED != 0;
   constexpr int kOutSlots = (CH == 5 && kTapDma) ? 80 : 0; // 320 floats
   static_assert(!kTapDma || (CH == 5 ? (kCap + kOutSlots) * 16 >= 1024 * 20 : kCap >= 1027), "tap DMA: 16 taps x 64 pixels");
   __shared__ float4 s_win[kWinWaves][kCap + kOutSlots];
+#ifndef LRP_BIG_PASS_SLOTS
+#define LRP_BIG_PASS_SLOTS 4096
+#endif
+  constexpr int kPassCap = (kTapDma && LRP_BIG_PASS_SLOTS < kCap) ? LRP_BIG_PASS_SLOTS : kCap; // largest window of a single pass (experiments: beyond the 1024 slots of its taps a window holds more texels than tap DMA fetches)
 
   // A listed launch may also hand every wavefront a share of the corner runs (Pk.geo_fill_per_wave row segments each,
   // lrp_corner_fill.h): a few store instructions at the very end of its life, when nothing else of it is live and nothing
@@ -1011,7 +1018,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     w.bw = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)hi_x)) + 2 - w.x_lo + 1;
     w.bh = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)hi_y)) + 2 - w.y_lo + 1;
     w.pitch = w.bw | 1;
-    if (w.bw > kMaxPassCols || slots_of_rows(w.pitch, w.bh) > kCap) return false;
+    if (w.bw > kMaxPassCols || slots_of_rows(w.pitch, w.bh) > kPassCap) return false;
     w.tier = 1;
     return true;
   };
@@ -1048,7 +1055,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     w.bw = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)hi_x)) + 2 - w.x_lo + 1;
     w.bh = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)hi_y)) + 2 - w.y_lo + 1;
     w.pitch = w.bw | 1;
-    return w.bw <= kMaxPassCols && slots_of_rows(w.pitch, w.bh) <= kCap;
+    return w.bw <= kMaxPassCols && slots_of_rows(w.pitch, w.bh) <= kPassCap;
   };
   auto request_pass = [&](const PassWin &w) { // one window row and 64 columns per instruction, lanes beyond the width masked off (issue())
     const int n_chunks = (w.bw + 63) >> 6;

@@ -109,7 +109,7 @@ PANORAMA_CASES = [
 @pytest.mark.parametrize("channels", [3, 4, 5])
 def test_big_window_variant_of_every_source_against_the_live_oracle(lrp, oracle, torch_cuda, channels):
     """geo_big 2 sends every launch that reads a geometry-cache entry through the big-window variant of its source (rectilinear,
-    panorama, wrapping panorama): pass windows up to 128 texels wide, tap DMA, per-pixel gathers at the seam — against the
+    panorama, wrapping panorama): windows of single passes, tap DMA, per-pixel gathers at the seam — against the
     four-wavefront instantiations (geo_big 0), the automatic choice (1) and the oracle."""
     torch = torch_cuda
     for iw, ih, in_name, ow, oh, out_name, rot_name, post in PANORAMA_CASES:

@@ -14,6 +14,7 @@ cp $f/roofline.md profiles/${r}_roofline.md
 cp $f/kbench_configs3_lists.log profiles/${r}_kbench_configs3_lists.txt
 (cat $f/kbench_cubemap_faces.log; echo "# geometry cache off"; cat $f/kbench_cubemap_faces_geo0.log; echo "# the whole cubemap (lrp_reproject_multi_device)"; grep multi_merge $f/cubemap_bench.log) > profiles/${r}_kbench_cubemap_faces.txt
 cp $f/kbench_supersampling.log profiles/${r}_kbench_supersampling.txt
+[ -f $f/kbench_tap_dma.log ] && cp $f/kbench_tap_dma.log profiles/${r}_kbench_tap_dma.txt
 cp $f/kbench_two_streams.log profiles/${r}_kbench_two_streams.txt
 cp $f/sq_counters.txt profiles/${r}_sq_counters.txt
 cp $f/staged.log profiles/${r}_staged_pcie.txt

@@ -22,6 +22,19 @@ for L in 1 0; do
   (echo "# geo_lists=$L"; timeout 200 ./tools/kbench --sum --reps 8 --batch 16 --distinct 16 --channels 5 --post --set geo_lists=$L rect_eqr_bc; timeout 200 ./tools/kbench --sum --reps 24 --distinct 16 --channels 5 --post --set geo_lists=$L rect_eqr_bc;
    timeout 200 ./tools/kbench --sum --reps 8 --batch 16 --distinct 16 --set geo_lists=$L rect_eqr_bc rect_eqd_bc; timeout 200 ./tools/kbench --sum --reps 24 --distinct 16 --set geo_lists=$L rect_eqr_bc rect_eqd_bc) >> $out/kbench_configs3_lists.log 2>&1
 done
+(for T in 1 0; do
+   echo "# win_tapdma=$T: rect_eqr_bc single RGBA / batch16 RGBA / single RGBAZ + tonemap / batch16 RGBAZ + tonemap / single RGB"
+   timeout 200 ./tools/kbench --sum --reps 24 --distinct 16 --set win_tapdma=$T rect_eqr_bc | grep -v "^#"; timeout 200 ./tools/kbench --sum --reps 8 --batch 16 --distinct 16 --set win_tapdma=$T rect_eqr_bc | grep -v "^#"
+   timeout 200 ./tools/kbench --sum --reps 24 --distinct 16 --channels 5 --post --set win_tapdma=$T rect_eqr_bc | grep -v "^#"; timeout 200 ./tools/kbench --sum --reps 8 --batch 16 --distinct 16 --channels 5 --post --set win_tapdma=$T rect_eqr_bc | grep -v "^#"
+   timeout 200 ./tools/kbench --sum --reps 24 --distinct 16 --channels 3 --set win_tapdma=$T rect_eqr_bc | grep -v "^#"
+ done
+ for B in 1 0 2; do
+   echo "# geo_big=$B (1: by the census of the entry; 0: never; 2: always): rect_eqd_bc single RGBA / batch16 RGBA / batch16 RGBAZ + tonemap, eqr_rect_bc_gen single RGBA, 8192^2 -> 2048^2 RGB side face / pole face"
+   timeout 200 ./tools/kbench --sum --reps 24 --distinct 16 --set geo_big=$B rect_eqd_bc | grep -v "^#"; timeout 200 ./tools/kbench --sum --reps 8 --batch 16 --distinct 16 --set geo_big=$B rect_eqd_bc | grep -v "^#"
+   timeout 200 ./tools/kbench --sum --reps 8 --batch 16 --distinct 16 --channels 5 --post --set geo_big=$B rect_eqd_bc | grep -v "^#"
+   timeout 200 ./tools/kbench --sum --reps 24 --distinct 16 --set geo_big=$B eqr_rect_bc_gen | grep -v "^#"
+   timeout 200 ./tools/kbench --sum --reps 20 --size 8192 --out-size 2048 --channels 3 --distinct 4 --set geo_big=$B eqr_rect_bc_rot eqr_rect_bc_pitch | grep -v "^#"
+ done) > $out/kbench_tap_dma.log 2>&1
 timeout 200 ./tools/kbench --sum --reps 20 --size 8192 --out-size 2048 --channels 3 --distinct 4 eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch > $out/kbench_cubemap_faces.log 2>&1
 timeout 200 ./tools/kbench --sum --reps 20 --size 8192 --out-size 2048 --channels 3 --distinct 4 --geo 0 eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch > $out/kbench_cubemap_faces_geo0.log 2>&1
 timeout 300 python3 tools/cubemap_bench.py 30 > $out/cubemap_bench.log 2>&1
@@ -52,6 +65,6 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
 done
 python3 $R/tools/pmc_summary.py $R/$out/sq > $R/$out/sq_counters.txt
 cd $R
-(timeout 900 python3 tools/policy_check.py 0.05 2>&1 | grep -v amdgpu.ids > $out/policy_check.txt; echo "policy_check rc=$?" >> $out/policy_check.txt)
+(timeout 1800 python3 tools/policy_check.py 0.05 2>&1 | grep -v amdgpu.ids > $out/policy_check.txt; echo "policy_check rc=$?" >> $out/policy_check.txt)
 python3 tools/roofline_table.py $out/bench.json $out/kernel_trace_by_launch_shape.txt > $out/roofline.md
 cat $out/bench.json
