@@ -102,6 +102,8 @@ CHECKS = [  # (what, workload, batch, switch, settings: the first is the default
     ("big-window variant by census, general rotation single (no wide block: stays out)", GEN, 0, "geo_big", (1, 0, 2)),
     ("big-window variant by census, 8192^2 -> 2048^2 pole face RGB", dict(inp="eqr", out="rect", interp=2, deg=(0.0, 90.0, 0.0), size=8192, out_size=2048, c=3), 0, "geo_big", (1, 0, 2)),
     ("big-window variant by census, 8192^2 -> 2048^2 side face RGB", dict(inp="eqr", out="rect", interp=2, deg=(90.0, 0.0, 0.0), size=8192, out_size=2048, c=3), 0, "geo_big", (1, 0, 2)),
+    ("big-window variant by census, 8192^2 -> 2048^2 face pitched 45 degrees RGB", dict(inp="eqr", out="rect", interp=2, deg=(0.0, 45.0, 0.0), size=8192, out_size=2048, c=3), 0, "geo_big", (1, 0, 2)),
+    ("big-window variant by census, 8192^2 -> 2048^2 face pitched 65 degrees RGB", dict(inp="eqr", out="rect", interp=2, deg=(20.0, 65.0, 0.0), size=8192, out_size=2048, c=3), 0, "geo_big", (1, 0, 2)),
     ("tap DMA, configs[3] RGBA single", C3, 0, "win_tapdma", (1, 0)),
     ("tap DMA, configs[3] RGBAZ + tonemap batch16", C3Z, 16, "win_tapdma", (1, 0)),
     ("strip length of reading launches, headline single", HEAD, 0, "geo_strip", (0, 1, 2, 4)),
