@@ -2,15 +2,15 @@
 # Builds liblrp_hip.so (gfx950) in-tree.  Usage: build.sh [jobs]
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-out="$here/../lib"
-obj="$here/../lib/obj"
+out="${LRP_BUILD_OUT:-$here/../lib}"   # (LRP_BUILD_OUT / LRP_BUILD_FLAGS: variant builds for same-box A/B timing, tools/ablate.sh)
+obj="$out/obj"
 mkdir -p "$out" "$obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 jobs="${1:-$(( $(nproc) + 4 ))}"
 # Parity flags: no FMA contraction, IEEE divide/sqrt, denormals kept, no fast-math.
 FLAGS=(--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off
        -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -fno-gpu-flush-denormals-to-zero
-       -Wall -Wno-unused-function -I"$here" -I"$here/../../include")
+       -Wall -Wno-unused-function -I"$here" -I"$here/../../include" ${LRP_BUILD_FLAGS:-})
 srcs=(lrp_kernels_nn.hip lrp_kernels_bl.hip lrp_kernels_bc.hip lrp_tile_nn.hip lrp_tile_bl.hip lrp_tile_bc.hip lrp_tile_win.hip lrp_tile_winq.hip lrp_tile_win3.hip lrp_tile_winq3.hip lrp_tile_win5.hip lrp_tile_winq5.hip lrp_tile_winy.hip lrp_tile_winx.hip lrp_tile_winy3.hip lrp_tile_winx3.hip lrp_tile_winy5.hip lrp_tile_winx5.hip lrp_tile_winr.hip lrp_tile_winr3.hip lrp_tile_winr5.hip lrp_tile_wing.hip lrp_tile_wing3.hip lrp_tile_wing5.hip lrp_tile_wins.hip lrp_tile_wins3.hip lrp_tile_wins5.hip lrp_tile_pair.hip lrp_tables.hip lrp_geo_lists.hip lrp_aux_kernels.hip lrp_pixel_kernels.hip lrp_capi.cpp lrp_geocache.cpp lrp_host_util.cpp)
 # Per-unit code generation options (measured on MI355X, tools/ablate.sh variants; bits are unaffected):
 #   the plain-block window kernels schedule for instruction-level parallelism: rectilinear -> equirectangular bicubic

@@ -185,7 +185,7 @@ lrp::KParams make_params(const lrp_image *in, const lrp_image *out, int num_samp
 // initial values, once, when the library is loaded — nothing on a launch path calls getenv.
 //   kernel: 0 = pixel kernel, 1 = tile kernel everywhere, 2 (default) = tile kernel with the LDS-window kernel for
 //   bicubic, 3 = the same without its shared-coefficient tier and without any work sharing.  All HIP; there is no CPU path.
-enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobGeoBig, kKnobGeoLists, kKnobGeoFillStream, kKnobGeoFillFused, kKnobGeoPairs, kKnobMultiMerge, kKnobContextStreams, kKnobWinTapDma, kKnobGeoCensus, kKnobWinSS, kKnobListedLaunches, kKnobMergedLaunches, kKnobPairLaunches, kKnobBigLaunches, kKnobCount };
+enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobGeoBig, kKnobGeoLists, kKnobGeoFillStream, kKnobGeoFillFused, kKnobGeoPairs, kKnobMultiMerge, kKnobContextStreams, kKnobWinTapDma, kKnobGeoCensus, kKnobGeoListRecs, kKnobWinSS, kKnobListedLaunches, kKnobMergedLaunches, kKnobPairLaunches, kKnobBigLaunches, kKnobCount };
 struct KnobSpec {
   const char *name, *env;
   int lo, hi, initial;
@@ -218,6 +218,7 @@ const KnobSpec kKnobs[kKnobCount] = {
     {"context_streams", "LRP_CONTEXT_STREAMS", 0, 1, 1}, // lrp_context: consecutive images alternate between two compute streams (0: one)
     {"win_tapdma", "LRP_WIN_TAPDMA", 0, 1, 1},      // window kernel: passes whose window fits no buffer fetch their taps a quad of lanes per pixel row through LDS-DMA (0: a gather per lane and tap)
     {"geo_census", "LRP_GEO_CENSUS", 0, 1, 1},      // the census of a new geometry-cache entry's windows (lrp_geo_lists.hip; what the automatic choice of the big-window variant reads); 0: not taken
+    {"geo_list_recs", "LRP_GEO_LIST_RECS", 0, 1, 1}, // listed launches: a wavefront reads its block's box record from beside its work-list entry, with the entry (0: from the box array, a second round trip)
     {"win_ss", "LRP_WIN_SS", 0, 1, 1},              // bicubic with num_samples == 2 through the window kernel's supersampling instantiations (0: the tile kernel, as for any other num_samples > 1)
     {"listed_launches", "LRP_LISTED_LAUNCHES_UNUSED", 0, 0, 0}, // a counter, not a switch: launches rendered by block class so far (set 0 to reset; tests, bench)
     {"merged_launches", "LRP_MERGED_LAUNCHES_UNUSED", 0, 0, 0}, // a counter: multi-output launches so far
@@ -480,11 +481,13 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
           P.geo_runs = reinterpret_cast<const uint32_t *>(P.geo_work + 2 * lrp::geo_work_capacity(out->width, out->height));
           P.geo_n_work = geo.n_work;
           P.geo_n_runs = geo.n_runs;
+          P.geo_work_rec = knob(kKnobGeoListRecs) != 0 ? reinterpret_cast<const int32_t *>(lists + lrp::geo_work_recs_offset(out->width, out->height)) : nullptr;
           if (knob(kKnobGeoPairs) != 0 && geo.n_pairs != 0) { // alias pairs of in-view blocks: the pair kernel (lrp_pair_kernel.h) ...
             P.geo_pairs = reinterpret_cast<const int32_t *>(P.geo_runs + 4 * lrp::geo_run_capacity(out->width, out->height));
             P.geo_n_pairs = geo.n_pairs;
             P.geo_work = P.geo_pairs + 2 * lrp::geo_pair_capacity(out->width, out->height); // ... and the window kernel over the rest
             P.geo_n_work = geo.n_rest;
+            P.geo_work_rec = nullptr; // (the records lie beside the work list's entries, not the rest list's)
           }
           // the corner runs: a share per wavefront of the window launch where it has enough wavefronts to spread them over,
           // else (few or no blocks to render: the frame is nearly all corners) the fill kernel at its own, full occupancy

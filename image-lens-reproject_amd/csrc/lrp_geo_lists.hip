@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t *s_wa
 // Workgroup 8: the corner runs, rows of blocks top to bottom, groups of kGeoRunBlocks columns left to right.
 __global__ __launch_bounds__(kListThreads) void geo_build_lists_kernel(const uint8_t *classes, uint32_t class_rows, const int32_t *box, int blocks_x,
                                                                        int blocks_y, int alias_pairs, int in_w, int in_h, uint32_t *header,
-                                                                       int32_t *work, uint32_t *runs, int32_t *pairs, int32_t *rest) {
+                                                                       int32_t *work, uint32_t *runs, int32_t *pairs, int32_t *rest, int32_t *recs) {
   __shared__ uint32_t s_wave[kListWaves];
   const int k = (int)blockIdx.x;
   const bool alias = alias_pairs != 0 && (blocks_x & 1) == 0;
@@ -91,6 +91,11 @@ __global__ __launch_bounds__(kListThreads) void geo_build_lists_kernel(const uin
       if (listed) {
         work[2 * ((size_t)pos * kXcds + k)] = tx;
         work[2 * ((size_t)pos * kXcds + k) + 1] = ty;
+        // ... and the block's box record beside it (lrp_params.h "recs")
+        const int4 *const r = reinterpret_cast<const int4 *>(box + ((size_t)ty * (size_t)blocks_x + (size_t)tx) * 8);
+        int4 *const o = reinterpret_cast<int4 *>(recs + 8 * ((size_t)pos * kXcds + k));
+        o[0] = r[0];
+        o[1] = r[1];
       }
       base += total;
       const bool front = paired && (j & 1u) == 0;
@@ -228,6 +233,7 @@ hipError_t launch_geo_build_lists(int32_t *box, int out_w, int out_h, int in_w, 
   uint32_t *const runs = reinterpret_cast<uint32_t *>(work + 2 * geo_work_capacity(out_w, out_h));
   int32_t *const pairs = reinterpret_cast<int32_t *>(runs + 4 * geo_run_capacity(out_w, out_h));
   int32_t *const rest = pairs + 2 * geo_pair_capacity(out_w, out_h);
+  int32_t *const recs = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(header) + geo_work_recs_offset(out_w, out_h));
   hipError_t e = hipMemsetAsync(header, 0, (size_t)kGeoListHeaderWords * 4, stream);
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(work, 0xFF, geo_work_capacity(out_w, out_h) * 8, stream); // (-1, -1): nothing here
@@ -236,7 +242,7 @@ hipError_t launch_geo_build_lists(int32_t *box, int out_w, int out_h, int in_w, 
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(geo_build_lists_kernel, dim3(kXcds + 1), dim3(kListThreads), 0, stream, base + geo_class_offset(out_w, out_h),
                      geo_block_rows(out_h), box, (int)geo_block_cols(out_w), (int)geo_image_block_rows(out_h), alias_pairs, in_w, in_h, header, work, runs,
-                     pairs, rest);
+                     pairs, rest, recs);
   return hipGetLastError();
 }
 

@@ -103,6 +103,7 @@ struct KParams {
   // walks the WORK list — workgroup i renders block geo_work[i] = (column, row) of 16 x 16 blocks, or exits on a -1 —
   // instead of enumerating the frame; the corner blocks, which are not on it, are written by the fill kernel from geo_runs.
   const int32_t *geo_work;   // [geo_n_work][2]
+  const int32_t *geo_work_rec; // [geo_n_work][8]: the box records of the work list's blocks (null: loaded from the box array per block)
   const uint32_t *geo_runs;  // [geo_n_runs][4]: block row, first block column, blocks (<= kGeoRunBlocks), corner class 1-4
   uint32_t geo_n_work, geo_n_runs;
   // ... and the PAIR list: alias pairs of blocks that lie in view whole, rendered by the pair kernel (lrp_pair_kernel.h) from
@@ -144,6 +145,9 @@ struct GeoLayout {
 //   pairs   (alias geometries only: a rectilinear view into a full-turn panorama, no pitch / roll) the blocks in front of the
 //           camera that lie in view whole and whose partner behind the camera does too, XCD-interleaved like the work list;
 //   rest    the work list without the blocks of the pairs: what the window kernel walks when the pair kernel renders the pairs.
+//   recs    the box record (8 words) of every entry of the work list, at the entry's position: a listed wavefront reads its block
+//           and the block's record with two scalar loads issued together — one round trip in front of the window request instead
+//           of two (the record's address in the box array depends on the entry).
 constexpr int kGeoListHeaderWords = 16;
 constexpr int kGeoRunBlocks = 16;
 inline __host__ __device__ uint32_t geo_image_block_rows(int out_h) { return (uint32_t)(out_h + 15) / 16; }
@@ -152,6 +156,10 @@ inline __host__ __device__ size_t geo_work_capacity(int out_w, int out_h) { // e
 }
 inline __host__ __device__ size_t geo_run_capacity(int out_w, int out_h) { return (size_t)geo_image_block_rows(out_h) * geo_block_cols(out_w); }
 inline __host__ __device__ size_t geo_pair_capacity(int out_w, int out_h) { return geo_work_capacity(out_w, out_h) / 2 + kXcds; } // entries (pairs of ints)
+inline __host__ __device__ size_t geo_work_recs_offset(int out_w, int out_h) { // bytes from the list header to the records of the work list
+  return (size_t)kGeoListHeaderWords * 4 + geo_work_capacity(out_w, out_h) * 8 + geo_run_capacity(out_w, out_h) * 16 + geo_pair_capacity(out_w, out_h) * 8 +
+         geo_work_capacity(out_w, out_h) * 8;
+}
 // Element (float2) of output pixel (x, y) in the coordinate map: row-major.  (A map stored in 16 x 16 tiles — 2 KiB contiguous
 // bytes per block of the window kernel instead of 16 row segments of 128 bytes — measured the same for the window kernels
 // and 2-3 % slower for the tile kernels: profiles/r04_experiments_ab.txt.)
@@ -178,7 +186,7 @@ inline GeoLayout geo_layout(int out_w, int out_h, bool with_boxes) {
   if (with_boxes) {
     L.box_bytes = geo_lists_offset(out_w, out_h);
     L.list_bytes = (size_t)kGeoListHeaderWords * 4 + geo_work_capacity(out_w, out_h) * 8 + geo_run_capacity(out_w, out_h) * 16 +
-                   geo_pair_capacity(out_w, out_h) * 8 + geo_work_capacity(out_w, out_h) * 8;
+                   geo_pair_capacity(out_w, out_h) * 8 + geo_work_capacity(out_w, out_h) * 8 + geo_work_capacity(out_w, out_h) * 32;
   }
   return L;
 }

@@ -103,7 +103,10 @@ template <int OutLens, int InMode, int QMode, int CH, bool Frames = false, bool 
 #define LRP_WIN_MINWAVES_FRAMES 4 // the instantiations with the frame loop
 #endif
 #ifndef LRP_WIN_CAP_BIG
-#define LRP_WIN_CAP_BIG 1280 // window slots of the big-window GeoRead variant: 20 KiB per wavefront, two wavefronts per SIMD
+#define LRP_WIN_CAP_BIG 1120 // window slots of the big-window GeoRead variant (RGB / RGBA): 17.5 KiB per wavefront — nine wavefronts per CU (LDS is
+                             // allocated in 512-byte granules: 1136 slots are eight again).  Round 4's 20 KiB held more whole and half windows at eight
+                             // wavefronts; since the passes without a window fetch their taps (1027 slots) the ninth wavefront is worth more:
+                             // rect -> equirect 4096^2 RGBA 179 -> 173 us single, 163 -> 157 batched; rect -> fisheye 146 -> 140 / 130 -> 124 (1060 / 1100 / 1120: level)
 #endif
 #ifndef LRP_WIN_CAP_BIG5
 #define LRP_WIN_CAP_BIG5 1200 // ... RGBAZ: 18.75 KiB, so that with the 1.25 KiB exchange buffer of its stores eight wavefronts fit a CU's 160 KiB (1280 slots: seven; rect -> equirect RGBAZ + tonemap 330 -> 318 us single, 313 -> 300 batched)
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   // The big-window variant (GeoRead, "OutLens" kEquirect by convention; chosen by the host for a rectilinear view rendered
   // into a panorama, BASELINE configs[3]): the in-view blocks of that mapping are minified 3-5 x 1.5-3 — the window of a 16 x 4
   // PASS is ~67 x 11 texels, too wide for one DMA instruction per row and too large for 10 KiB next to three other
-  // wavefronts' — so this variant holds 20 KiB per wavefront (two wavefronts per SIMD, no register limit to speak of) and
+  // wavefronts' — so this variant holds 17.5 KiB (RGBAZ: 20 KiB) per wavefront (two wavefronts per SIMD, a third on one of them) and
   // stages the windows of single passes (and fetches the taps of the passes that have none: tap DMA below).  tools/microbench/row_gather.hip: rows of that shape arrive at 7.7 TB/s by
   // LDS-DMA with 8 wavefronts per CU, a window each in flight; per-pixel gathers of the same bytes at 4.5 TB/s in this kernel.
   constexpr bool kBigWin = GeoRead && OutLens == kEquirect;
@@ -203,6 +206,18 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
 #ifndef LRP_WIN_PASS_PIPELINE
 #define LRP_WIN_PASS_PIPELINE 1 // ... and request what pass k + 1 reads behind the taps of pass k (0: in front of pass k + 1, on the spot)
 #endif
+#ifndef LRP_DMA_ROWS_V2
+#define LRP_DMA_ROWS_V2 1 // the window-row requests of issue() in the big-window variant: see there
+#endif
+#ifndef LRP_PASS_QUICK_REJECT
+#define LRP_PASS_QUICK_REJECT 1 // big-window variant: a pass that is too wide for a window by its first row alone skips the wave-wide plan
+#endif
+#ifndef LRP_TAP_OFFSETS
+#define LRP_TAP_OFFSETS 1 // tap DMA: one write of M0 per group of four tap rows, the rows told apart by instruction offsets (0: one per instruction)
+#endif
+#ifndef LRP_TAP_DPP
+#define LRP_TAP_DPP 1 // tap DMA: the quad's pixel offsets by DPP moves (0: ds_bpermute, an LDS round trip per pass)
+#endif
 #ifndef LRP_WIN_TAPDMA
 #define LRP_WIN_TAPDMA 1 // the big-window variant: tap DMA (below) compiled in
 #endif
@@ -211,7 +226,10 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   // array (the exchange buffer is written behind the pixel's last tap read and read back before the next pass requests anything).
   constexpr bool kTapDma = kBigWin && kWinWaves == 1 && LRP_WIN_TAPDMA != 0 && LRP_WIN_ROLLED_UNSTAGED != 0;
   constexpr int kOutSlots = (CH == 5 && kTapDma) ? 80 : 0; // 320 floats
-  static_assert(!kTapDma || (CH == 5 ? (kCap + kOutSlots) * 16 >= 1024 * 20 : kCap >= 1027), "tap DMA: 16 taps x 64 pixels");
+  static_assert(!kTapDma || (CH == 5 ? (kCap + kOutSlots) * 16 >= 1024 * 20 : kCap >= 1024), "tap DMA: 16 taps x 64 pixels");
+  // how the read-back of the taps avoids LDS bank conflicts (request_taps below): groups skewed by one slot each where the buffer
+  // has the three slots to spare (conflict-free), else the quads rotated within their rows of 16 lanes (two-way)
+  constexpr bool kTapRotate = CH == 5 || kCap < 1027;
   __shared__ float4 s_win[kWinWaves][kCap + kOutSlots];
 #ifndef LRP_BIG_PASS_SLOTS
 #define LRP_BIG_PASS_SLOTS 4096
@@ -241,6 +259,11 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   // the frame that are not corner blocks, already in XCD-interleaved order with alias pairs next to each other; the corner
   // blocks are written by the fill kernel (lrp_geo_lists.hip).  One block per wavefront.
   bool listed = false;
+  // (the record beside the entry: in the big-window variant only — that is where listed launches run; in the four-wavefront
+  // instantiations of the rectilinear source the seven scalars cost 17-29 spilled SGPRs and 14 spilled VGPRs)
+  constexpr bool kListRec = kListable && kBigWin;
+  int list_rec[7] = {0, 0, 0, 0, 0, 0, 0}; // a listed block's box record (scalar)
+  bool have_list_rec = false;
   if constexpr (kListable) listed = Pk.geo_work != nullptr;
   if (listed) {
     typedef const int32_t __attribute__((address_space(4))) *ScalarI;
@@ -250,6 +273,16 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     const ScalarI e = reinterpret_cast<ScalarI>(addr);
     tx = e[0];
     ty = e[1];
+    // ... and the block's box record from beside the entry (lrp_params.h "recs"): both scalar loads are in flight together, the
+    // window is planned one round trip earlier than from the box array (whose address depends on the entry)
+    if (kListRec && Pk.geo_work_rec != nullptr) {
+      const uintptr_t rbase = reinterpret_cast<uintptr_t>(Pk.geo_work_rec);
+      const ScalarI r = reinterpret_cast<ScalarI>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rbase >> 32)) << 32 |
+                                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rbase)) + (uint64_t)blockIdx.x * 32u);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) list_rec[i] = r[i];
+      have_list_rec = true;
+    }
     if (tx < 0) { // the end of a shorter sub-list
       fill_share();
       return;
@@ -606,7 +639,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   int geo_boxv = 0;
   auto geo_fetch = [&](int g, WinBlock &b) {
     // (the extremes first: loads return in order, and the first block of a strip plans its window before anything else)
-    geo_boxv = __builtin_nontemporal_load(P.geo_box + (geo_block(g) * 8u + (uint32_t)(lane & 7)));
+    if (!(kListRec && have_list_rec)) geo_boxv = __builtin_nontemporal_load(P.geo_box + (geo_block(g) * 8u + (uint32_t)(lane & 7)));
     const vf2 *const map = reinterpret_cast<const vf2 *>(P.geo_xy);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -646,6 +679,13 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     if (cls != 0) {
       b.tier = cls << 3;
       return;
+    }
+    if constexpr (kListRec) {
+      if (have_list_rec) { // (a listed launch renders one block per wavefront: this is its record)
+        const int flags = list_rec[6];
+        if ((flags & 4) != 0) plan_window(b, list_rec[0], list_rec[1], list_rec[2], list_rec[3], list_rec[4], list_rec[5], (flags & 1) != 0, (flags & 2) != 0);
+        return;
+      }
     }
     const int flags = __builtin_amdgcn_readlane(geo_boxv, 6);
     if ((flags & 4) != 0)
@@ -734,34 +774,73 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
         const uint32_t lds_step = (uint32_t)(b.spitch() * 16); // dwordx3 too writes one 16-byte slot per lane
         const uint32_t lane_bytes = (uint32_t)(b.x_lo + chunk * 64 + lane) * (4u * CH);
         const int n_rows = kSplit ? b.rows_of(half) : b.bh;
-        const char *row = reinterpret_cast<const char *>(frame) + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(kSplit ? b.first_row_of(half) : b.y_lo) * src.row_bytes)); // wave-uniform
-        for (int r = 0; r < n_rows; ++r) {
-          if constexpr (CH == 4)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         :
-                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(row)
-                         : "memory", "m0");
-          else if constexpr (CH == 5) {
-            // colour into the 16-byte slots of the row, depth into the row of the float plane behind the colour plane
-            // (an instruction offset would move the LDS address as well as the global one: the fifth float's 16 bytes
-            // go into the scalar base)
-            const uint32_t lds_d = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win +
-                                   (uint32_t)(b.pitch * n_rows) * 16u + (uint32_t)(r * b.pitch + chunk * 64) * 4u;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         :
-                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(row)
-                         : "memory", "m0");
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
-                         :
-                         : "s"(__builtin_amdgcn_readfirstlane(lds_d)), "v"(lane_bytes), "s"(row + 16)
-                         : "memory", "m0");
-          } else
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %2"
-                         :
-                         : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(row)
-                         : "memory", "m0");
-          lds += lds_step;
-          row += src.row_bytes;
+        if constexpr (kBigWin && LRP_DMA_ROWS_V2 != 0) {
+          // Per window row: M0, the request, the next row's LDS address and ONE vector add that moves the lanes' byte offsets to the
+          // next source row — the scalar base is the frame's for every row.  Four rows per loop iteration: -1 % on the listed launches
+          // of the big-window variant, nothing in the four-wavefront kernels (which keep the loop below).  (There: a 64-bit scalar
+          // row pointer advanced by two adds, a counter, a compare and a branch per row — 8 scalar instructions per request, a fifth
+          // of the kernel's.  The scalar add in place of the s_nop behind the write of M0 — a read-write scalar operand of the asm
+          // statement — does not survive register allocation in the RGBAZ kernels: "illegal VGPR to SGPR copy".)
+          const char *const base = reinterpret_cast<const char *>(frame);
+          [[maybe_unused]] const char *const base_d = base + 16;
+          uint32_t voff = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(kSplit ? b.first_row_of(half) : b.y_lo) * src.row_bytes)) + lane_bytes;
+          uint32_t lds_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds);
+          const uint32_t lds_step_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_step);
+          [[maybe_unused]] uint32_t ldsd_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win +
+                                                                                       (uint32_t)(b.pitch * n_rows) * 16u + (uint32_t)(chunk * 64) * 4u));
+          [[maybe_unused]] const uint32_t ldsd_step = (uint32_t)__builtin_amdgcn_readfirstlane(b.pitch * 4);
+          auto request_row = [&]() {
+            if constexpr (CH == 4)
+              asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(__builtin_amdgcn_readfirstlane((int)lds_s)), "v"(voff), "s"(base) : "memory", "m0");
+            else if constexpr (CH == 5) {
+              // colour into the 16-byte slots of the row, depth into the row of the float plane behind the colour plane (the fifth
+              // float's 16 bytes go into the scalar base)
+              asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(__builtin_amdgcn_readfirstlane((int)lds_s)), "v"(voff), "s"(base) : "memory", "m0");
+              asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(__builtin_amdgcn_readfirstlane((int)ldsd_s)), "v"(voff), "s"(base_d) : "memory", "m0");
+              ldsd_s += ldsd_step;
+            } else
+              asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %2" : : "s"(__builtin_amdgcn_readfirstlane((int)lds_s)), "v"(voff), "s"(base) : "memory", "m0");
+            lds_s += lds_step_s;
+            voff += src.row_bytes;
+          };
+          int r = 0;
+          for (; r + 4 <= n_rows; r += 4) {
+            request_row();
+            request_row();
+            request_row();
+            request_row();
+          }
+          for (; r < n_rows; ++r) request_row();
+        } else {
+          const char *row = reinterpret_cast<const char *>(frame) + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(kSplit ? b.first_row_of(half) : b.y_lo) * src.row_bytes)); // wave-uniform
+          for (int r = 0; r < n_rows; ++r) {
+            if constexpr (CH == 4)
+              asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                           :
+                           : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(row)
+                           : "memory", "m0");
+            else if constexpr (CH == 5) {
+              // colour into the 16-byte slots of the row, depth into the row of the float plane behind the colour plane
+              // (an instruction offset would move the LDS address as well as the global one: the fifth float's 16 bytes
+              // go into the scalar base)
+              const uint32_t lds_d = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win +
+                                     (uint32_t)(b.pitch * n_rows) * 16u + (uint32_t)(r * b.pitch + chunk * 64) * 4u;
+              asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                           :
+                           : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(row)
+                           : "memory", "m0");
+              asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
+                           :
+                           : "s"(__builtin_amdgcn_readfirstlane(lds_d)), "v"(lane_bytes), "s"(row + 16)
+                           : "memory", "m0");
+            } else
+              asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %2"
+                           :
+                           : "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(lane_bytes), "s"(row)
+                           : "memory", "m0");
+            lds += lds_step;
+            row += src.row_bytes;
+          }
         }
       }
     }
@@ -1009,7 +1088,17 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   };
   // window of one pass (or of two passes that read the same source rows) from the wave-wide extremes of its coordinates;
   // false: too wide or too large for the buffer
+  // A pass spans more than kMaxPassCols texels for certain when two of its pixels lie that far apart: the first and the last
+  // pixel of its first row, two v_readlane instead of the wave-wide reductions (a quarter of the in-view passes of BASELINE
+  // configs[3] end here and fetch their taps).  With a < b: int(b) - int(a) > b - a - 1, so b - a >= kMaxPassCols - 3 means a
+  // window of int(b) - int(a) + 4 > kMaxPassCols columns.  (NaN compares false: the full plan decides.)
+  auto pass_too_wide = [&](float psx) -> bool {
+    const float xa = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(psx), 0));
+    const float xb = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(psx), LRP_WIN_LANEMAP != 0 ? 27 : kBlkW - 1));
+    return LRP_PASS_QUICK_REJECT != 0 && __builtin_fabsf(xb - xa) >= (float)(kMaxPassCols - 3);
+  };
   auto plan_pass_window = [&](WinBlock &w, int lo_x, int hi_x, int lo_y, int hi_y) -> bool {
+    if (kBigWin && pass_too_wide(u2f((uint32_t)lo_x))) return false;
     int d0 = 0, d1 = 0;
     wave_box(lo_x, hi_x, lo_y, hi_y, d0, d1); // (interior: the coordinates are >= 1, their bits order like integers)
     clear_block(w);
@@ -1048,6 +1137,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   };
   const uint32_t pass_lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)win0);
   auto plan_pass = [&](PassWin &w, float psx, float psy) -> bool { // (interior: the coordinates are >= 1, their bits order like integers)
+    if (pass_too_wide(psx)) return false;
     int lo_x = (int)f2u(psx), hi_x = lo_x, lo_y = (int)f2u(psy), hi_y = lo_y, d0 = 0, d1 = 0;
     wave_box(lo_x, hi_x, lo_y, hi_y, d0, d1);
     w.x_lo = __builtin_amdgcn_readfirstlane((int)u2f((uint32_t)lo_x)) - 1;
@@ -1085,13 +1175,56 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     const int j = lane & 3;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      // the lane whose pixel this lane helps to fetch in group t
-      const int from = CH == 5 ? ((lane & 48) | ((((lane >> 2) - t) & 3) << 2) | t) : ((lane & ~3) | t);
+      // the offset of the pixel this lane helps to fetch in group t: pixel t of this lane's quad (quad_perm broadcast), RGBAZ: of
+      // the quad t positions further down its row of 16 lanes (row_ror: lane i takes lane i - 4 t)
+#if LRP_TAP_DPP
+      int got;
+      if (t == 0) got = __builtin_amdgcn_mov_dpp((int)v0, 0x00, 0xF, 0xF, false);
+      else if (t == 1) got = __builtin_amdgcn_mov_dpp((int)v0, 0x55, 0xF, 0xF, false);
+      else if (t == 2) got = __builtin_amdgcn_mov_dpp((int)v0, 0xAA, 0xF, 0xF, false);
+      else got = __builtin_amdgcn_mov_dpp((int)v0, 0xFF, 0xF, 0xF, false);
+      if constexpr (kTapRotate) {
+        if (t == 1) got = __builtin_amdgcn_mov_dpp(got, 0x120 + 4, 0xF, 0xF, false);
+        else if (t == 2) got = __builtin_amdgcn_mov_dpp(got, 0x120 + 8, 0xF, 0xF, false);
+        else if (t == 3) got = __builtin_amdgcn_mov_dpp(got, 0x120 + 12, 0xF, 0xF, false);
+      }
+      const uint32_t vt = (uint32_t)got + (uint32_t)j * T;
+#else
+      const int from = kTapRotate ? ((lane & 48) | ((((lane >> 2) - t) & 3) << 2) | t) : ((lane & ~3) | t);
       const uint32_t vt = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)v0) + (uint32_t)j * T;
+#endif
+#if LRP_TAP_OFFSETS
+      // the four tap rows of the group with ONE write of M0: the instruction offset moves the LDS address AND the global one, so
+      // row r (LDS: 1024 r bytes further, depth plane: 256 r) takes a scalar base that many bytes lower
+      {
+        const uint32_t o0 = vt, o1 = vt + src.row_bytes, o2 = vt + 2u * src.row_bytes, o3 = vt + 3u * src.row_bytes;
+        const uint32_t lds = pass_lds0 + (uint32_t)((4 * t * 64 + (kTapRotate ? 0 : t)) * 16);
+        if constexpr (CH == 3)
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %5\n\tglobal_load_lds_dwordx3 %2, %6 offset:1024\n\t"
+                       "global_load_lds_dwordx3 %3, %7 offset:2048\n\tglobal_load_lds_dwordx3 %4, %8 offset:3072"
+                       :
+                       : "s"(lds), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base), "s"(base - 1024), "s"(base - 2048), "s"(base - 3072)
+                       : "memory", "m0");
+        else
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\tglobal_load_lds_dwordx4 %2, %6 offset:1024\n\t"
+                       "global_load_lds_dwordx4 %3, %7 offset:2048\n\tglobal_load_lds_dwordx4 %4, %8 offset:3072"
+                       :
+                       : "s"(lds), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base), "s"(base - 1024), "s"(base - 2048), "s"(base - 3072)
+                       : "memory", "m0");
+        if constexpr (CH == 5) {
+          const uint32_t lds_d = pass_lds0 + 1024u * 16u + (uint32_t)(4 * t * 64 * 4);
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %5\n\tglobal_load_lds_dword %2, %6 offset:256\n\t"
+                       "global_load_lds_dword %3, %7 offset:512\n\tglobal_load_lds_dword %4, %8 offset:768"
+                       :
+                       : "s"(lds_d), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base + 16), "s"(base + 16 - 256), "s"(base + 16 - 512), "s"(base + 16 - 768)
+                       : "memory", "m0");
+        }
+      }
+#else
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const uint32_t off = vt + (uint32_t)r * src.row_bytes;
-        const uint32_t lds = pass_lds0 + (uint32_t)(((4 * t + r) * 64 + (CH == 5 ? 0 : t)) * 16);
+        const uint32_t lds = pass_lds0 + (uint32_t)(((4 * t + r) * 64 + (kTapRotate ? 0 : t)) * 16);
         if constexpr (CH == 3)
           asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %2" : : "s"(lds), "v"(off), "s"(base) : "memory", "m0");
         else
@@ -1101,6 +1234,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
           asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(lds_d), "v"(off), "s"(base + 16) : "memory", "m0");
         }
       }
+#endif
     }
   };
   // plans pass `k` (coordinates psx, psy) and requests what it will read: 1 its own window `w`, 2 its taps, 0 nothing (it gathers)
@@ -1199,7 +1333,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
               request_taps(psx, psy);
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the taps (and every older store)
               const int j = lane & 3;
-              const int slot0 = CH == 5 ? (256 * j + (lane & 48) + ((((lane >> 2) + j) & 3) << 2)) : (257 * j + (lane & ~3));
+              const int slot0 = kTapRotate ? (256 * j + (lane & 48) + ((((lane >> 2) + j) & 3) << 2)) : (257 * j + (lane & ~3));
               s = win_tier_raw<CH>(win0 + slot0, 64, reinterpret_cast<const float *>(win0 + 1024) + slot0, psx - __builtin_truncf(psx), psy - __builtin_truncf(psy), [&]() {
                 if (last_pass) next_window(); // behind the last reads of the taps
               });
@@ -1241,7 +1375,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
               s = win_tier_raw<CH>(win0 + slot0, w.pitch, reinterpret_cast<const float *>(win0 + w.pitch * w.bh) + slot0, psx - tx_, psy - ty_, after_reads);
             } else { // (the taps: a window of constant pitch — every row offset is an immediate of the read)
               const int j = lane & 3;
-              const int slot0 = CH == 5 ? (256 * j + (lane & 48) + ((((lane >> 2) + j) & 3) << 2)) : (257 * j + (lane & ~3));
+              const int slot0 = kTapRotate ? (256 * j + (lane & 48) + ((((lane >> 2) + j) & 3) << 2)) : (257 * j + (lane & ~3));
               s = win_tier_raw<CH>(win0 + slot0, 64, reinterpret_cast<const float *>(win0 + 1024) + slot0, psx - tx_, psy - ty_, after_reads);
             }
           } else {

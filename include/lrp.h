@@ -125,6 +125,7 @@ int lrp_debug_kernel(int choice);
  * wavefront of the window kernel), "geo_fill_stream" (1: that fill kernel on a side stream), "geo_pairs" (1: the pair kernel — alias pairs of in-view blocks, a rectilinear view
  * and its copy behind the camera in a full panorama, two wavefronts per staged window — in a listed launch; default 0: not faster), "multi_merge" (1: lrp_reproject_multi_device merges the outputs whose
  * geometry-cache entries exist into one launch; default 0: a launch per output, measured level), "merged_launches", "big_launches" (counters), "context_streams" (0: an lrp_context keeps all its kernels on one compute stream instead of alternating two),
+ * "geo_census" (0: no census of a new entry's windows), "geo_list_recs" (0: listed wavefronts read their block's record from the box array),
  * "win_tapdma" (0: passes of the big-window variant whose window fits no buffer gather per lane instead of fetching their taps quad by quad through LDS-DMA),
  * "listed_launches" (a counter: launches rendered by block class so far; 0 resets).  Sets the value for subsequent calls of all threads
  * and returns the previous one; a value outside the switch's range only queries; an unknown name returns -1.  The

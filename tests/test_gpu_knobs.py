@@ -60,6 +60,7 @@ SETTINGS = {
     "multi_merge1": {"geo_cache": 1, "multi_merge": 1},  # (lrp_reproject_multi_device: the outputs whose entries exist in ONE launch)
     "win_tapdma0": {"geo_cache": 1, "win_tapdma": 0},  # (the big-window variant: passes whose window fits no buffer gather per lane)
     "geo_lists2_tapdma0": {"geo_cache": 1, "geo_lists": 2, "win_tapdma": 0},
+    "geo_lists2_recs0": {"geo_cache": 1, "geo_lists": 2, "geo_list_recs": 0},  # (a listed wavefront loads its block's record from the box array)
     "win_ss0": {"geo_cache": 0, "win_ss": 0},  # (bicubic with num_samples == 2 through the tile kernel)
 }
 FRAMES = ["config1_4k_eqd_rect_bc", "config3_4k_rgbaz_rect_eqr_bc_post", "4k_eqr_rect_bc_rot", "config4_8k_rgb_face4"]
@@ -94,7 +95,7 @@ class _DeviceSynth:
 
 def test_switch_names_and_ranges(lrp):
     for name in ("kernel", "xsep", "quad", "mirror_modes", "win_edge", "win_split", "batch_frames", "multi_fork", "geo_cache", "geo_strip", "geo_big",
-                 "geo_lists", "geo_fill_fused", "geo_fill_stream", "geo_pairs", "multi_merge", "context_streams", "win_ss", "win_tapdma"):
+                 "geo_lists", "geo_fill_fused", "geo_fill_stream", "geo_pairs", "multi_merge", "context_streams", "win_ss", "win_tapdma", "geo_list_recs", "geo_census"):
         now = lrp.debug_set(name, -1)
         assert lrp.debug_set(name, now) == now  # setting the current value returns it
         assert lrp.debug_set(name, 10 ** 6) == now and lrp.debug_set(name, -1) == now  # out of range: a query
