@@ -108,13 +108,43 @@ template <int OutLens, int InMode, int QMode, int CH, bool Frames = false, bool 
                              // wavefronts; since the passes without a window fetch their taps (1027 slots) the ninth wavefront is worth more:
                              // rect -> equirect 4096^2 RGBA 179 -> 173 us single, 163 -> 157 batched; rect -> fisheye 146 -> 140 / 130 -> 124 (1060 / 1100 / 1120: level)
 #endif
+#ifndef LRP_WIN_ROLLED_UNSTAGED
+#define LRP_WIN_ROLLED_UNSTAGED 1 // the big-window variant: blocks with nothing staged run their passes in one rolled loop (below)
+#endif
+#ifndef LRP_WIN_PASS_PIPELINE
+#define LRP_WIN_PASS_PIPELINE 1 // ... and request what pass k + 1 reads behind the taps of pass k (0: in front of pass k + 1, on the spot)
+#endif
+#ifndef LRP_DMA_ROWS_V2
+#define LRP_DMA_ROWS_V2 1 // the window-row requests of issue() in the big-window variant: see there
+#endif
+#ifndef LRP_PASS_QUICK_REJECT
+#define LRP_PASS_QUICK_REJECT 1 // big-window variant: a pass that is too wide for a window by its first row alone skips the wave-wide plan
+#endif
+#ifndef LRP_TAP_OFFSETS
+#define LRP_TAP_OFFSETS 1 // tap DMA: one write of M0 per group of four tap rows, the rows told apart by instruction offsets (0: one per instruction)
+#endif
+#ifndef LRP_TAP_DPP
+#define LRP_TAP_DPP 1 // tap DMA: the quad's pixel offsets by DPP moves (0: ds_bpermute, an LDS round trip per pass)
+#endif
+#ifndef LRP_WIN_TAPDMA
+#define LRP_WIN_TAPDMA 1 // the big-window variant: tap DMA (below) compiled in
+#endif
+#ifndef LRP_TAP_SPLIT5
+#define LRP_TAP_SPLIT5 0 // 1: RGBAZ tap DMA in two steps — the colour taps, then (behind their read-back, under the colour arithmetic) the depths into the
+                         // same 16 KiB — so that buffer + exchange buffer are 17.5 KiB (nine wavefronts per CU) and the passes can be requested ahead.
+                         // Measured 8 % SLOWER (rect -> equirect RGBAZ + tonemap 264 -> 285 us batched, pole face 133 -> 142): nine wavefronts
+                         // need <= 168 VGPRs (178 at eight: spills), the windows shrink to 1040 slots, the code grows to 97 KB.  Off.
+#endif
+#ifndef LRP_WIN_CAP_BIG5S
+#define LRP_WIN_CAP_BIG5S 1040 // ... its window slots then: 16.25 KiB + the 1.25 KiB exchange buffer = 17.5 KiB
+#endif
 #ifndef LRP_WIN_CAP_BIG5
 #define LRP_WIN_CAP_BIG5 1200 // ... RGBAZ: 18.75 KiB, so that with the 1.25 KiB exchange buffer of its stores eight wavefronts fit a CU's 160 KiB (1280 slots: seven; rect -> equirect RGBAZ + tonemap 330 -> 318 us single, 313 -> 300 batched)
 #endif
 #ifndef LRP_WIN_MINWAVES_BIG
 #define LRP_WIN_MINWAVES_BIG 2
 #endif
-__global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LRP_WIN_MINWAVES_BIG : CH == 5 ? LRP_WIN_MINWAVES5 : (QMode == 4 ? LRP_WIN_MINWAVES_RAYS : (Frames ? LRP_WIN_MINWAVES_FRAMES : (QMode >= 2 ? LRP_WIN_MINWAVES_AXIS : LRP_WIN_MINWAVES)))) void reproject_bicubic_win_kernel(const KParams Pk) {
+__global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((CH == 5 && LRP_TAP_SPLIT5 != 0) ? 3 : LRP_WIN_MINWAVES_BIG) : CH == 5 ? LRP_WIN_MINWAVES5 : (QMode == 4 ? LRP_WIN_MINWAVES_RAYS : (Frames ? LRP_WIN_MINWAVES_FRAMES : (QMode >= 2 ? LRP_WIN_MINWAVES_AXIS : LRP_WIN_MINWAVES)))) void reproject_bicubic_win_kernel(const KParams Pk) {
   constexpr bool Quad = QMode != 0;
   constexpr bool MirX = QMode == 1 || QMode == 3 || QMode == 4, MirY = QMode == 1 || QMode == 2 || QMode == 4;
   constexpr bool kSharedRays = QMode == 4; // only the ray through the output lens is shared: per-image coordinates are stored like a plain block's
@@ -135,7 +165,8 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   // stages the windows of single passes (and fetches the taps of the passes that have none: tap DMA below).  tools/microbench/row_gather.hip: rows of that shape arrive at 7.7 TB/s by
   // LDS-DMA with 8 wavefronts per CU, a window each in flight; per-pixel gathers of the same bytes at 4.5 TB/s in this kernel.
   constexpr bool kBigWin = GeoRead && OutLens == kEquirect;
-  constexpr int kCap = kBigWin ? (CH == 5 ? LRP_WIN_CAP_BIG5 : LRP_WIN_CAP_BIG) : kWinCap; // 16-byte slots of this instantiation's window buffer
+  constexpr bool kTapSplit5 = kBigWin && CH == 5 && kWinWaves == 1 && LRP_WIN_TAPDMA != 0 && LRP_WIN_ROLLED_UNSTAGED != 0 && LRP_TAP_SPLIT5 != 0;
+  constexpr int kCap = kBigWin ? (CH == 5 ? (kTapSplit5 ? LRP_WIN_CAP_BIG5S : LRP_WIN_CAP_BIG5) : LRP_WIN_CAP_BIG) : kWinCap; // 16-byte slots of this instantiation's window buffer
 #ifndef LRP_BIG_PASSCOLS
 #define LRP_BIG_PASSCOLS 64 // (128 — two DMA instructions per row for the wider ones — measured 1 % slower once such passes can fetch their taps instead)
 #endif
@@ -200,33 +231,12 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   // fisheye-target kernels the extra code cost 2.5 % (equirect -> fisheye single launches 247 -> 253 us).
   constexpr bool kPassWin = (kSplit || (GeoRead && OutLens == kEquirect)) && LRP_WIN_PASSWIN != 0 && (OutLens == kRect || GeoRead || (InMode == kInRect && CH == 5));
   constexpr int kPlanes = 3;
-#ifndef LRP_WIN_ROLLED_UNSTAGED
-#define LRP_WIN_ROLLED_UNSTAGED 1 // the big-window variant: blocks with nothing staged run their passes in one rolled loop (below)
-#endif
-#ifndef LRP_WIN_PASS_PIPELINE
-#define LRP_WIN_PASS_PIPELINE 1 // ... and request what pass k + 1 reads behind the taps of pass k (0: in front of pass k + 1, on the spot)
-#endif
-#ifndef LRP_DMA_ROWS_V2
-#define LRP_DMA_ROWS_V2 1 // the window-row requests of issue() in the big-window variant: see there
-#endif
-#ifndef LRP_PASS_QUICK_REJECT
-#define LRP_PASS_QUICK_REJECT 1 // big-window variant: a pass that is too wide for a window by its first row alone skips the wave-wide plan
-#endif
-#ifndef LRP_TAP_OFFSETS
-#define LRP_TAP_OFFSETS 1 // tap DMA: one write of M0 per group of four tap rows, the rows told apart by instruction offsets (0: one per instruction)
-#endif
-#ifndef LRP_TAP_DPP
-#define LRP_TAP_DPP 1 // tap DMA: the quad's pixel offsets by DPP moves (0: ds_bpermute, an LDS round trip per pass)
-#endif
-#ifndef LRP_WIN_TAPDMA
-#define LRP_WIN_TAPDMA 1 // the big-window variant: tap DMA (below) compiled in
-#endif
   // Tap DMA (big-window variant; request_taps below) needs 1024 slots for the colour taps of a pass — and, RGBAZ, 1024 floats for their
   // depths behind them: exactly the 18.75 KiB window + the 1.25 KiB exchange buffer of the stores, which therefore lie in ONE
   // array (the exchange buffer is written behind the pixel's last tap read and read back before the next pass requests anything).
   constexpr bool kTapDma = kBigWin && kWinWaves == 1 && LRP_WIN_TAPDMA != 0 && LRP_WIN_ROLLED_UNSTAGED != 0;
   constexpr int kOutSlots = (CH == 5 && kTapDma) ? 80 : 0; // 320 floats
-  static_assert(!kTapDma || (CH == 5 ? (kCap + kOutSlots) * 16 >= 1024 * 20 : kCap >= 1024), "tap DMA: 16 taps x 64 pixels");
+  static_assert(!kTapDma || ((CH == 5 && !kTapSplit5) ? (kCap + kOutSlots) * 16 >= 1024 * 20 : kCap >= 1024), "tap DMA: 16 taps x 64 pixels");
   // how the read-back of the taps avoids LDS bank conflicts (request_taps below): groups skewed by one slot each where the buffer
   // has the three slots to spare (conflict-free), else the quads rotated within their rows of 16 lanes (two-way)
   constexpr bool kTapRotate = CH == 5 || kCap < 1027;
@@ -1167,7 +1177,8 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
         }
       }
   };
-  auto request_taps = [&](float psx, float psy) {
+  // (`which`: 1 the colour taps, 2 the depths, 3 both; the depths land `depth_at` bytes into the buffer)
+  auto request_taps = [&](float psx, float psy, int which = 3, uint32_t depth_at = 1024u * 16u) {
     const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
     constexpr uint32_t T = 4u * CH;
     const uint32_t v0 = __umul24((uint32_t)((int)ty_ - 1), src.row_bytes) + (uint32_t)((int)tx_ - 1) * T; // tap (0, 0) of this lane's pixel
@@ -1199,7 +1210,9 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
       {
         const uint32_t o0 = vt, o1 = vt + src.row_bytes, o2 = vt + 2u * src.row_bytes, o3 = vt + 3u * src.row_bytes;
         const uint32_t lds = pass_lds0 + (uint32_t)((4 * t * 64 + (kTapRotate ? 0 : t)) * 16);
-        if constexpr (CH == 3)
+        if (CH == 5 && (which & 1) == 0) {
+          // (the depths only)
+        } else if constexpr (CH == 3)
           asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %5\n\tglobal_load_lds_dwordx3 %2, %6 offset:1024\n\t"
                        "global_load_lds_dwordx3 %3, %7 offset:2048\n\tglobal_load_lds_dwordx3 %4, %8 offset:3072"
                        :
@@ -1211,8 +1224,8 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
                        :
                        : "s"(lds), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base), "s"(base - 1024), "s"(base - 2048), "s"(base - 3072)
                        : "memory", "m0");
-        if constexpr (CH == 5) {
-          const uint32_t lds_d = pass_lds0 + 1024u * 16u + (uint32_t)(4 * t * 64 * 4);
+        if (CH == 5 && (which & 2) != 0) {
+          const uint32_t lds_d = pass_lds0 + depth_at + (uint32_t)(4 * t * 64 * 4);
           asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %5\n\tglobal_load_lds_dword %2, %6 offset:256\n\t"
                        "global_load_lds_dword %3, %7 offset:512\n\tglobal_load_lds_dword %4, %8 offset:768"
                        :
@@ -1230,7 +1243,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
         else
           asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds), "v"(off), "s"(base) : "memory", "m0");
         if constexpr (CH == 5) {
-          const uint32_t lds_d = pass_lds0 + 1024u * 16u + (uint32_t)((4 * t + r) * 64 * 4);
+          const uint32_t lds_d = pass_lds0 + depth_at + (uint32_t)((4 * t + r) * 64 * 4); // (this path: both planes at once only)
           asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(lds_d), "v"(off), "s"(base + 16) : "memory", "m0");
         }
       }
@@ -1247,7 +1260,10 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
       request_pass(w);
       return 1;
     }
-    request_taps(psx, psy);
+    if constexpr (kTapSplit5)
+      request_taps(psx, psy, 1); // (the colour taps; the depths follow behind their read-back: below)
+    else
+      request_taps(psx, psy);
     return 2;
   };
 #pragma unroll 1
@@ -1315,7 +1331,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
         auto pass_y = [&](int k) { return k == 0 ? y0 : k == 1 ? y1 : k == 2 ? y2 : y3; };
         // (RGBAZ: on the spot — its taps fill the buffer to the last byte, the exchange buffer of the stores in its tail included,
         // and can only be requested once the previous pass has left; with the request in two places its kernel is 3 % slower)
-        constexpr bool kPipeline = LRP_WIN_PASS_PIPELINE != 0 && kOutSlots == 0;
+        constexpr bool kPipeline = LRP_WIN_PASS_PIPELINE != 0 && (kOutSlots == 0 || kTapSplit5);
         PassWin w;
         int kind = 0;
         bool behind_store = true; // what this pass reads was requested behind the previous pass's store: nothing younger in flight
@@ -1376,7 +1392,32 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
             } else { // (the taps: a window of constant pitch — every row offset is an immediate of the read)
               const int j = lane & 3;
               const int slot0 = kTapRotate ? (256 * j + (lane & 48) + ((((lane >> 2) + j) & 3) << 2)) : (257 * j + (lane & ~3));
-              s = win_tier_raw<CH>(win0 + slot0, 64, reinterpret_cast<const float *>(win0 + 1024) + slot0, psx - tx_, psy - ty_, after_reads);
+              if constexpr (kTapSplit5) {
+                // RGBAZ in two steps: the 16 colour taps into registers, the depths requested into the slots they left — their round
+                // trip runs under the five colour cubics —, then the depth taps and their cubics (win_tier_raw's operations, in its order)
+                const float fx = psx - tx_, fy = psy - ty_, hfx = 0.5f * fx, hfy = 0.5f * fy;
+                const float4 *const t0 = win0 + slot0, *const t1 = t0 + 64, *const t2 = t1 + 64, *const t3 = t2 + 64;
+                Rgba q[4][4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  q[c][0] = as_rgba(t0[c]);
+                  q[c][1] = as_rgba(t1[c]);
+                  q[c][2] = as_rgba(t2[c]);
+                  q[c][3] = as_rgba(t3[c]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the colour taps are in registers: their slots may be overwritten
+                asm volatile("" : "+v"(q[0][0].lo), "+v"(q[3][3].hi)); // (... and the reads stay in front of the request)
+                request_taps(psx, psy, 2, 0u);
+                const Rgba k0 = cubic4(q[0][0], q[0][1], q[0][2], q[0][3], fy, hfy);
+                const Rgba k1 = cubic4(q[1][0], q[1][1], q[1][2], q[1][3], fy, hfy);
+                const Rgba k2 = cubic4(q[2][0], q[2][1], q[2][2], q[2][3], fy, hfy);
+                const Rgba k3 = cubic4(q[3][0], q[3][1], q[3][2], q[3][3], fy, hfy);
+                s = cubic4(k0, k1, k2, k3, fx, hfx);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the depths
+                s.e = win_depth_sample(reinterpret_cast<const float *>(win0) + slot0, 64, fx, fy, hfx, hfy, after_reads);
+              } else {
+                s = win_tier_raw<CH>(win0 + slot0, 64, reinterpret_cast<const float *>(win0 + 1024) + slot0, psx - tx_, psy - ty_, after_reads);
+              }
             }
           } else {
             after_reads(); // nothing of this pass reads the buffer
