@@ -108,6 +108,12 @@ template <int OutLens, int InMode, int QMode, int CH, bool Frames = false, bool 
                              // wavefronts; since the passes without a window fetch their taps (1027 slots) the ninth wavefront is worth more:
                              // rect -> equirect 4096^2 RGBA 179 -> 173 us single, 163 -> 157 batched; rect -> fisheye 146 -> 140 / 130 -> 124 (1060 / 1100 / 1120: level)
 #endif
+#ifndef LRP_BIG_NO_COEF
+#define LRP_BIG_NO_COEF 1 // (rect -> equirect RGBAZ + tonemap 258 -> 252.5 us batched, RGBA 158.4 -> 156.4, rect -> fisheye and the pole face -0.5 %)
+#endif
+#ifndef LRP_BIG_ROLL_STAGED
+#define LRP_BIG_ROLL_STAGED 1
+#endif
 #ifndef LRP_WIN_ROLLED_UNSTAGED
 #define LRP_WIN_ROLLED_UNSTAGED 1 // the big-window variant: blocks with nothing staged run their passes in one rolled loop (below)
 #endif
@@ -231,6 +237,8 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
   // fisheye-target kernels the extra code cost 2.5 % (equirect -> fisheye single launches 247 -> 253 us).
   constexpr bool kPassWin = (kSplit || (GeoRead && OutLens == kEquirect)) && LRP_WIN_PASSWIN != 0 && (OutLens == kRect || GeoRead || (InMode == kInRect && CH == 5));
   constexpr int kPlanes = 3;
+  // (LRP_BIG_NO_COEF: the big-window variant without the coefficient tier — its blocks are minified, the planes rarely fit)
+  constexpr bool kCoefHere = kWinCoef && !(kBigWin && LRP_BIG_NO_COEF != 0);
   // Tap DMA (big-window variant; request_taps below) needs 1024 slots for the colour taps of a pass — and, RGBAZ, 1024 floats for their
   // depths behind them: exactly the 18.75 KiB window + the 1.25 KiB exchange buffer of the stores, which therefore lie in ONE
   // array (the exchange buffer is written behind the pixel's last tap read and read back before the next pass requests anything).
@@ -955,7 +963,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
     // while this block's coefficient planes are still being read the next raw window must stay in front of them
     // (the same block's window in the next frame always does: planes sit behind the raw window)
     // (likewise the plane of vertical cubics of a block beyond the first / last source row: edge() 1, 2)
-    const bool planes_live = (kWinCoef && cur.coef()) || (kEdge && cur.edge() != 0 && cur.edge() < 3);
+    const bool planes_live = (kCoefHere && cur.coef()) || (kEdge && cur.edge() != 0 && cur.edge() < 3);
     dma_early = has_next() && (!planes_live || f_loop + 1 < n_frames || raw_slots(nxt) <= cur.c_base);
     if (dma_early) issue_next();
   };
@@ -1298,7 +1306,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
 #else
     const int tier = cur.tier;
 #endif
-    const bool t_coef = kWinCoef && (tier & 2) != 0, t_staged = (tier & 1) != 0, t_whole = (tier & 4) != 0;
+    const bool t_coef = kCoefHere && (tier & 2) != 0, t_staged = (tier & 1) != 0, t_whole = (tier & 4) != 0;
     const int t_edge = kEdge ? ((tier >> 6) & 7) : 0;
     const bool t_split = kSplit && (tier & 512) != 0; // the window holds passes 0-1; that of passes 2-3 is fetched behind pass 1's taps // 1, 2: beyond the first / last source row; 3, 4: column
 #if defined(LRP_TIER_STATS)
@@ -1441,19 +1449,28 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
       }
     }
     if (t_edge == 1 || t_edge == 2) edge_plane(cur);
-#pragma unroll
+#pragma unroll(kBigWin && CH == 5 && LRP_BIG_ROLL_STAGED == 2 ? 1 : 2)
     for (int h = 0; h < 2; ++h) {
 #if !defined(LRP_SKIP_PLANES) // timing experiment (wrong results): the coefficient phase removed
       if (t_coef && (h == 0 || !t_whole)) precompute(cur, h);
 #endif
-#pragma unroll
+      // (the RGBAZ big-window variant keeps the two passes of a half rolled — its code shrinks 82 -> 77 KB: rect -> equirect RGBAZ +
+      // tonemap 262 -> 255 us batched; RGB / RGBA lose 0.5-1.5 % that way and stay unrolled: LRP_BIG_ROLL_STAGED)
+      float hx0 = cur.sx[2 * h], hx1 = cur.sx[2 * h + 1], hy0 = cur.sy[2 * h], hy1 = cur.sy[2 * h + 1];
+      if constexpr (kBigWin && CH == 5 && LRP_BIG_ROLL_STAGED == 2) { // (both loops rolled: h is not a constant either)
+        float a0 = cur.sx[0], a1 = cur.sx[1], a2 = cur.sx[2], a3 = cur.sx[3], b0 = cur.sy[0], b1 = cur.sy[1], b2 = cur.sy[2], b3 = cur.sy[3];
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+        hx0 = h == 0 ? a0 : a2, hx1 = h == 0 ? a1 : a3, hy0 = h == 0 ? b0 : b2, hy1 = h == 0 ? b1 : b3;
+      }
+      if constexpr (kBigWin && CH == 5 && LRP_BIG_ROLL_STAGED != 0) asm volatile("" : "+v"(hx0), "+v"(hx1), "+v"(hy0), "+v"(hy1)); // (selected, not indexed: no scratch)
+#pragma unroll(kBigWin && CH == 5 && LRP_BIG_ROLL_STAGED != 0 ? 1 : 2)
       for (int kk = 0; kk < 2; ++kk) {
         const int k = 2 * h + kk;
         if (Quad && !kSharedRays && k == 3 && last_frame && g + 1 < G) coords(g + 1, nxt); // only its box is kept
         if constexpr (GeoRead)
           if (k == 3 && g + 1 < G && last_frame) geo_plan(nxt, geo_class(g + 1));
         const bool last_pass = k == 3;
-        float psx = cur.sx[k], psy = cur.sy[k];
+        float psx = kk == 0 ? hx0 : hx1, psy = kk == 0 ? hy0 : hy1;
         if constexpr (Quad && !kSharedRays) quad_xy(image_of(g), k, psx, psy); // re-derived (2-4 instructions) instead of held in registers
         // (where the coordinates of a mirror image are a plain selection of stored values the compiler would otherwise
         // hoist everything derived from them — truncations, weights, window addresses of all four passes and both
