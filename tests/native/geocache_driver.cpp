@@ -164,7 +164,7 @@ static lrp::GeoUse fill(const lrp::GeoKey &k, hipStream_t s, bool boxes, bool li
   lrp::geo_acquire(k, boxes, s, &u);
   if (u.mode == 1 || u.mode == 3) {
     if (lists && u.host_counts) {
-      const uint32_t counts[6] = {800, 12, 40, 1000, 0, 800};
+      const uint32_t counts[8] = {800, 12, 40, 1000, 0, 800, 123, 456}; // (... 6, 7: the census of the entry's windows)
       std::memcpy(u.host_counts, counts, sizeof(counts)); // (what the device-side copy would deliver)
       u.lists_enqueued = true;
     }
@@ -191,6 +191,7 @@ static int scenario_fill_read_lists() {
   fake::waits.clear();
   lrp::geo_acquire(k, true, S(1), &r);
   CHECK(r.mode == 2 && r.lists && r.n_work == 800 && r.n_runs == 12 && r.n_corner_blocks == 40 && r.n_blocks == 1000 && r.n_rest == 800);
+  CHECK(r.n_wide == 123 && r.n_inview == 456);
   CHECK(fake::waits.empty()); // ready parts need no event
   lrp::geo_launched(&r, S(1), true);
   // a nearest / bilinear launch does not ask for the records
@@ -201,6 +202,32 @@ static int scenario_fill_read_lists() {
   lrp::geo_stats(&st);
   CHECK(st.entries == 1 && st.fills == 1 && st.hits == 3 && st.evictions == 0);
   CHECK(fake::device_syncs == 0);
+  return 0;
+}
+
+// The regions of an entry (lrp_params.h): map, box records + class bytes, list header, work list, runs, pairs, rest list, work
+// records — disjoint, inside the entry, aligned as their readers need (256 bytes for the records and the header, 16 for the
+// 32-byte work records the list builder writes as two 16-byte vectors), for sizes around every rounding boundary.
+static int scenario_layout() {
+  const int sizes[][2] = {{1, 1}, {15, 17}, {16, 16}, {17, 15}, {72, 67}, {127, 129}, {128, 128}, {640, 480}, {2048, 2048}, {4096, 4096}, {8192, 4096}, {33, 4097}};
+  for (const auto &wh : sizes) {
+    const int w = wh[0], h = wh[1];
+    const lrp::GeoLayout L = lrp::geo_layout(w, h, true);
+    CHECK(L.xy_bytes % 256 == 0 && L.xy_bytes >= (size_t)w * h * 8);
+    const size_t blocks = (size_t)lrp::geo_block_cols(w) * lrp::geo_block_rows(h);
+    CHECK(lrp::geo_class_offset(w, h) == blocks * 32);
+    CHECK(L.box_bytes == lrp::geo_lists_offset(w, h) && L.box_bytes % 256 == 0 && L.box_bytes >= blocks * 33);
+    const size_t cap = lrp::geo_work_capacity(w, h), runs = lrp::geo_run_capacity(w, h), pairs = lrp::geo_pair_capacity(w, h);
+    CHECK(cap % lrp::kXcds == 0 && cap >= (size_t)lrp::geo_block_cols(w) * lrp::geo_image_block_rows(h));
+    CHECK(runs >= (size_t)lrp::geo_block_cols(w) * lrp::geo_image_block_rows(h) / lrp::kGeoRunBlocks);
+    const size_t recs = lrp::geo_work_recs_offset(w, h);
+    CHECK(recs == (size_t)lrp::kGeoListHeaderWords * 4 + cap * 8 + runs * 16 + pairs * 8 + cap * 8);
+    CHECK(recs % 16 == 0);                // (int4 stores of the list builder, dwordx8 scalar loads of the kernel)
+    CHECK(L.list_bytes == recs + cap * 32); // the records are the last region
+    CHECK(L.bytes() == L.xy_bytes + L.box_bytes + L.list_bytes);
+  }
+  const lrp::GeoLayout no_boxes = lrp::geo_layout(640, 480, false);
+  CHECK(no_boxes.box_bytes == 0 && no_boxes.list_bytes == 0);
   return 0;
 }
 
@@ -348,6 +375,7 @@ int main(int argc, char **argv) {
   int rc = 2;
   if (name == "fill_read_lists") rc = scenario_fill_read_lists();
   if (name == "map_then_boxes") rc = scenario_map_then_boxes();
+  if (name == "layout") rc = scenario_layout();
   if (name == "eviction") rc = scenario_eviction_without_device_sync();
   if (name == "devices") rc = scenario_devices_are_independent();
   if (name == "default_cap") rc = scenario_default_cap_and_release();
