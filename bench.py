@@ -214,10 +214,12 @@ def cpu_baseline(pkg, wl, seconds_target):
         "kind": "port",
         "single_thread_value": rows_one * size / dt_one / 1e6,
         "cpu_model": cpu_model(),
-        "sample": f"one image per thread like the reference's -j pool (src/main.cpp:538-544): {cores} threads = usable CPUs "
-                  f"(affinity {len(os.sched_getaffinity(0))}, cgroup quota honoured), each rendering {rows / size:.2f} frames "
-                  f"of its own {size}x{size}x{c} image ({dt_all:.1f} s wall); single thread: {rows_one / size:.2f} frames of one image "
-                  f"({dt_one:.1f} s)",
+        "sample": f"{cores} threads (usable CPUs) x {rows / size:.2f} frames of {size}x{size}x{c}, one image per thread as the "
+                  f"reference's -j pool ({dt_all:.1f} s); 1 thread: {rows_one / size:.2f} frames ({dt_one:.1f} s)",
+        "sample_detail": f"one image per thread like the reference's -j pool (src/main.cpp:538-544): {cores} threads = usable CPUs "
+                         f"(affinity {len(os.sched_getaffinity(0))}, cgroup quota honoured), each rendering {rows / size:.2f} frames "
+                         f"of its own {size}x{size}x{c} image ({dt_all:.1f} s wall); single thread: {rows_one / size:.2f} frames of one "
+                         f"image ({dt_one:.1f} s)",
     }
 
 
@@ -275,8 +277,9 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the frames of a step round-robin over (--per-frame-launches only)")
     ap.add_argument("--workload", default="fisheye_to_rect_bicubic", choices=sorted(WORKLOADS))
-    ap.add_argument("--secondary", default=DEFAULT_SECONDARY,
-                    help="comma-separated workloads measured (kernel timing only) in the same process; '' = none")
+    ap.add_argument("--secondary", default=None,
+                    help="comma-separated workloads measured (kernel timing only) in the same process; '' = none "
+                         "(default: the seven of DEFAULT_SECONDARY at N = 1, none at N > 1)")
     ap.add_argument("--size", type=int, default=0, help="override the frame size (tests; 0 = the workload's 4096)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the barrier / max-time reduction for --gpus > 1 (nccl = RCCL; "
@@ -288,6 +291,16 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-staged", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg (tools/staged_bench)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--detail-file", default="bench_detail.json",
+                    help="rank 0 writes the full result here (notes, traffic detail, two-stream / uncached single launches, per-rank "
+                         "times, staged rates); stdout carries the compact line only.  '' = do not write")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="--gpus 1 through the N > 1 code path: started under torch.distributed.run with one rank, process group "
+                         "initialised (nccl = RCCL), barriers and the device-side MAX reduction run on a world-size-1 communicator — "
+                         "the one RCCL launch a one-GPU box admits (tests/test_bench_multi_rank.py)")
+    ap.add_argument("--full-legs", action="store_true",
+                    help="N > 1: measure the single-launch / two-stream / uncached legs and the secondary workloads on rank 0 as at "
+                         "N = 1 (default for N > 1: the timed region only, so that the other ranks are released at once)")
     return ap.parse_args()
 
 
@@ -326,7 +339,7 @@ def resident_frames(torch, pkg, wl, size, n, dev, first_seed=0x5EED0000):
     return srcs, dsts
 
 
-def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_ms=None):
+def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_ms=None, single_legs=True):
     """Roofline figures of one workload's dominant kernel on resident frames: 16-frame launches and
     single-frame launches, both with HIP events on the launch stream, cycling over the resident frames.
     `dsts[k]` is the list of outputs of source k (one; six for the cubemap, where a "frame" is one
@@ -368,15 +381,8 @@ def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_
             batched(i)
         torch.cuda.synchronize()
         b_avg, b_min = time_launches(torch, stream, batched, 32)
-    # single-frame launches — the call the reference's worker makes once per file (src/main.cpp:597): with the geometry
-    # cache (the first launch of the geometry fills it, the timed ones read it) and with every launch computing its coordinates
-    for i in range(16):
-        single(i)
-    torch.cuda.synchronize()
-    s_avg, s_min = time_launches(torch, stream, single, 64)
-    # ... and the same single launches dealt alternately to TWO streams (what lrp_context does with consecutive images: the tail
-    # of one launch overlaps the head of the next): wall time per launch between a fork and a join on `stream`
-    side = torch.cuda.Stream(device=stream.device)
+    launch_bytes = (size * size + out_size * out_size) * c * 4
+    frame_bytes = launch_bytes * (len(faces) if faces else 1)
 
     def single_on(i, st):
         if faces:
@@ -384,45 +390,66 @@ def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_
         else:
             pkg.reproject(im_in[i % n_res], im_out[i % n_res][0], ns, wl["interp"], rot, post=post, stream=st)
 
-    def two_stream_us(reps=64):
-        best = None
-        for _ in range(3):
-            e0, e1, ej = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event()
-            e0.record(stream)
-            side.wait_event(e0)
-            for i in range(reps):
-                single_on(i, side if i & 1 else stream)
-            ej.record(side)
-            stream.wait_event(ej)
-            e1.record(stream)
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / reps
-            best = us if best is None else min(best, us)
-        return best
-
-    one_stream_wall_us = None
-    for i in range(8):
-        single_on(i, side if i & 1 else stream)
-    torch.cuda.synchronize()
-    two_us = two_stream_us()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for i in range(64):
-        single_on(i, stream)
-    e1.record(stream)
-    torch.cuda.synchronize()
-    one_stream_wall_us = e0.elapsed_time(e1) * 1e3 / 64
-    prev_geo = pkg.debug_set("geo_cache", 0)
-    try:  # (the switch is process-wide: whatever happens in here, the launches after it run the default again)
-        for i in range(8):
+    def single_launch_figures():
+        """Single-frame launches — the call the reference's worker makes once per file (src/main.cpp:597): with the geometry
+        cache (the first launch of the geometry fills it, the timed ones read it), dealt alternately to two streams (what
+        lrp_context does with consecutive images: the tail of one launch overlaps the head of the next; wall time per launch
+        between a fork and a join on `stream`), on one stream measured the same way, and with every launch computing its own
+        coordinates (lrp_debug_set geo_cache 0)."""
+        for i in range(16):
             single(i)
         torch.cuda.synchronize()
-        u_avg, _u_min = time_launches(torch, stream, single, 32)
-    finally:
-        pkg.debug_set("geo_cache", prev_geo)
+        s_avg, s_min = time_launches(torch, stream, single, 64)
+        side = torch.cuda.Stream(device=stream.device)
+
+        def two_stream_us(reps=64):
+            best = None
+            for _ in range(3):
+                e0, e1, ej = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event()
+                e0.record(stream)
+                side.wait_event(e0)
+                for i in range(reps):
+                    single_on(i, side if i & 1 else stream)
+                ej.record(side)
+                stream.wait_event(ej)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / reps
+                best = us if best is None else min(best, us)
+            return best
+
+        for i in range(8):
+            single_on(i, side if i & 1 else stream)
+        torch.cuda.synchronize()
+        two_us = two_stream_us()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for i in range(64):
+            single_on(i, stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        one_stream_wall_us = e0.elapsed_time(e1) * 1e3 / 64
+        prev_geo = pkg.debug_set("geo_cache", 0)
+        try:  # (the switch is process-wide: whatever happens in here, the launches after it run the default again)
+            for i in range(8):
+                single(i)
+            torch.cuda.synchronize()
+            u_avg, _u_min = time_launches(torch, stream, single, 32)
+        finally:
+            pkg.debug_set("geo_cache", prev_geo)
+        return {
+            "single_launch_us": s_avg * 1e3,
+            "single_launch_us_min": s_min * 1e3,
+            "single_launch_frac": frame_bytes / (s_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "single_launch_us_two_streams": two_us,
+            "single_launch_frac_two_streams": frame_bytes / (two_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "single_launch_us_one_stream_wall": one_stream_wall_us,
+            "single_launch_us_uncached": u_avg * 1e3,
+            "single_launch_frac_uncached": frame_bytes / (u_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        }
+
+    singles = single_launch_figures() if single_legs else {}
     # SURVEY §8d: (inW*inH + outW*outH)*C*4 per launch that reads the source; a cubemap is six such launches
-    launch_bytes = (size * size + out_size * out_size) * c * 4
-    frame_bytes = launch_bytes * (len(faces) if faces else 1)
     read_bytes = size * size * c * 4 * (len(faces) if faces else 1)
     algo = frame_bytes * nb
     achieved = algo / (b_avg * 1e-3) / 1e9
@@ -440,8 +467,10 @@ def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_
         # the bytes the PMC counters saw cross the HBM interface / time / peak: what the memory system actually sustains
         # (below frac whenever the view does not look at the whole source)
         "frac_measured_hbm": (hbm_bytes / (b_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if hbm_bytes else None,
+        # PMC bytes of one launch as timed here (rocprofv3 FETCH_SIZE / WRITE_SIZE passes over that launch shape; null when the
+        # traffic file was measured on other kernel sources)
         "traffic": hbm_bytes or None,
-        "traffic_detail": {"batched_launch": traffic_b, "single_launch": traffic_s},
+        "traffic_detail": {"batched_launch": traffic_b, "single_launch": traffic_s, "file": TRAFFIC_FILE},
         "kernel": "six launches of reproject_bicubic_win_kernel (LDS window) over one resident source" if faces else KERNEL_NAMES[wl["interp"]],
         "workload": name,
         "kernel_ms_avg": b_avg,
@@ -451,29 +480,14 @@ def kernel_figures(torch, pkg, wl, size, srcs, dsts, stream, name, timed_region_
         "frames_per_launch": nb,
         "us_per_frame": b_avg * 1e3 / nb,
         "algorithmic_bytes_per_launch": algo,
-        "single_launch_us": s_avg * 1e3,
-        "single_launch_us_min": s_min * 1e3,
-        "single_launch_frac": frame_bytes / (s_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "single_launch_us_two_streams": two_us,
-        "single_launch_frac_two_streams": frame_bytes / (two_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-        "single_launch_us_one_stream_wall": one_stream_wall_us,
-        "single_launch_two_streams_note": "64 single launches dealt alternately to two streams (lrp_context alternates its compute streams the same "
-                                          "way), wall time per launch between a fork and a join; ..._one_stream_wall: the same 64 launches on one stream, "
-                                          "measured the same way (no event between the launches)",
-        "single_launch_us_uncached": u_avg * 1e3,
-        "single_launch_frac_uncached": frame_bytes / (u_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "single_launch_note": "one frame per launch, what reproject::reproject() makes per file: coordinates from the geometry cache "
-                              "(default) / computed in every launch (lrp_debug_set geo_cache 0)",
-        "traffic_note": f"PMC bytes of one {nb}-frame launch as timed here (rocprofv3 FETCH_SIZE / WRITE_SIZE passes over that launch "
-                        f"shape; single-frame launches in traffic_detail); null when {TRAFFIC_FILE} was measured on other kernel sources",
+        **singles,
     }
     if faces:
         # the source read ONCE + the six faces written: what a cubemap has to move (SURVEY 8d's figure counts the whole source per face)
         once = size * size * c * 4 + len(faces) * out_size * out_size * c * 4
         out["frac_source_once"] = once / (b_avg * 1e-3) / 1e9 / HBM_PEAK_GBS
-        out["note"] = ("a frame is one cubemap: six 2048^2 faces from one resident 8192^2 RGB source; `frac` counts the whole source once per "
-                       "face launch as SURVEY 8d prescribes (it exceeds 1: a 90-degree face looks at a sixth of the source); "
-                       "frac_source_once = (source once + six faces) / time / peak is the honest roofline fraction")
+        # (`frac` counts the whole source once per face launch as SURVEY 8d prescribes and exceeds 1 — a 90-degree face looks at a sixth
+        # of the source; frac_source_once is the honest fraction and the one the compact line carries for this workload)
     return out
 
 
@@ -490,9 +504,57 @@ def golden_batch_digest(workload, total_images):
     return hashlib.sha256(",".join(sums[:total_images]).encode()).hexdigest()
 
 
+# ---- the line the driver reads --------------------------------------------------------------------------------------
+# bench.py's LAST stdout line is ONE compact JSON object (the contract keys + the roofline and cpu_baseline objects + one
+# {frac, us_per_frame} pair per secondary workload); everything else that is measured — notes, traffic detail, two-stream and
+# uncached figures, per-rank times, the staged rates — goes to the detail file (--detail-file, default bench_detail.json).
+# Round 5's single line had grown to 24.7 KB and the driver could no longer read it.
+COMPACT_LIMIT = 4000
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "frac_read_only", "frac_measured_hbm", "traffic", "kernel", "kernel_ms_avg",
+                 "frames_per_launch", "algorithmic_bytes_per_launch", "single_launch_us", "single_launch_frac",
+                 "single_launch_us_two_streams", "single_launch_frac_two_streams")
+CPU_KEYS = ("value", "unit", "cores", "kind", "single_thread_value", "cpu_model", "sample")
+TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline", "cpu_baseline", "outputs_match_golden", "secondary", "detail_file")
+
+
+def _short(v, digits=6):
+    """Floats to `digits` significant digits (the line is a report, the detail file keeps every bit)."""
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None  # (never a NaN / Infinity token on the driver's line)
+        return float(f"{v:.{digits}g}")
+    return v
+
+
+def compact_line(detail, detail_file=None):
+    """The driver's line from the full result: a pure function (tests/test_tools.py feeds it a canned result)."""
+    cfg = detail.get("config") or {}
+    out = {k: _short(detail.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                                "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = {k: cfg[k] for k in ("workload", "images_per_step", "images_per_gpu_per_step", "frames_per_launch", "parallelism")
+                     if k in cfg}
+    roof = detail.get("roofline") or {}
+    out["roofline"] = {k: _short(roof.get(k)) for k in ROOFLINE_KEYS if k in roof}
+    cpu = detail.get("cpu_baseline")
+    if cpu:
+        out["cpu_baseline"] = {k: _short(cpu.get(k)) for k in CPU_KEYS if k in cpu}
+        out["cpu_baseline"]["sample"] = str(cpu.get("sample", ""))[:200]
+    out["outputs_match_golden"] = detail.get("outputs_match_golden")
+    out["secondary"] = {name: {"frac": _short(r.get("frac_source_once", r.get("frac")), 4), "us_per_frame": _short(r.get("us_per_frame"), 4)}
+                        for name, r in (detail.get("secondary") or {}).items()}
+    if detail_file:
+        out["detail_file"] = detail_file
+    line = json.dumps(out, separators=(",", ":"))
+    assert len(line) <= COMPACT_LIMIT, f"bench.py: the driver's line grew to {len(line)} bytes (limit {COMPACT_LIMIT})"
+    return line
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.force_dist and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))  # (one rank under the launcher; nothing has touched the GPU yet)
     if args.gpus != world:
         if "WORLD_SIZE" in os.environ or args.gpus < 1:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with python -m "
@@ -511,7 +573,7 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -612,7 +674,7 @@ def main():
     if dist is not None:
         per_rank = [None] * world
         dist.all_gather_object(per_rank, (elapsed_rank, busy_rank))
-    elapsed = sharding.max_over_ranks(elapsed_rank, dist, dev if args.dist_backend == "nccl" else None)
+    elapsed = sharding.max_over_ranks(elapsed_rank, dist, dev if args.dist_backend == "nccl" else None, always=args.force_dist)
     # full 16-frame launches of the timed region (a shard's last launch may hold fewer frames)
     timed_ms = [a.elapsed_time(b) for per_step in events for (a, b), g in zip(per_step, groups) if g._n == FRAMES_PER_LAUNCH]
 
@@ -632,12 +694,17 @@ def main():
                 json.dump({"images": total_images, "n_gpus": world, "checksums": [f"{v:016x}" for v in flat]}, f)
 
     bad_pixels = False
+    # N > 1: rank 0 reports the timed region only and the other ranks are released at once (the single-launch legs and the
+    # secondary workloads are N = 1 measurements: ~15 s during which seven GPUs would sit in a barrier); --full-legs overrides.
+    full_legs = world == 1 or args.full_legs
+    if args.secondary is None:
+        args.secondary = DEFAULT_SECONDARY if full_legs else ""
     if rank == 0:
         res = min(n_res, 64)
         roof = kernel_figures(torch, pkg, wl, size, srcs[:res], [[d] for d in dsts[:res]], streams[0], args.workload,
-                              timed_region_ms=timed_ms if len(timed_ms) >= 4 else None)
-        roof["note"] = ("the un-fused IEEE arithmetic of the reference makes this kernel VALU-bound, not HBM-bound "
-                        "(DESIGN.md section 5); frac is algorithmic bytes / kernel time / 8 TB/s as the contract asks")
+                              timed_region_ms=timed_ms if len(timed_ms) >= 4 else None, single_legs=full_legs)
+        # (the un-fused IEEE arithmetic of the reference makes this kernel VALU-bound, not HBM-bound — DESIGN.md section 5;
+        # frac is algorithmic bytes / kernel time / 8 TB/s as the contract asks)
         secondary = {}
         for name in [n for n in args.secondary.split(",") if n and n != args.workload]:
             w2 = WORKLOADS[name]
@@ -667,6 +734,7 @@ def main():
             "per_rank_device_busy_s": [b for _e, b in per_rank],
             "rank_skew_s": max(e for e, _b in per_rank) - min(e for e, _b in per_rank),
             "settle_seconds": args.settle_seconds,
+            "dist": (f"{args.dist_backend} process group, world size {world}" + (" (--force-dist)" if args.force_dist else "")) if dist is not None else None,
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -694,7 +762,15 @@ def main():
             out["staged"] = staged_rates()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, wl, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        detail_file = None
+        if args.detail_file:
+            try:
+                with open(os.path.join(ROOT, args.detail_file) if not os.path.isabs(args.detail_file) else args.detail_file, "w") as f:
+                    json.dump(out, f, indent=1)
+                detail_file = args.detail_file
+            except OSError as e:  # (a read-only checkout: the compact line is still the result)
+                print(f"bench.py: could not write {args.detail_file}: {e}", file=sys.stderr, flush=True)
+        print(compact_line(out, detail_file), flush=True)  # the LAST stdout line: what the driver reads
         if digest and golden and digest != golden:
             print("bench.py: the rendered batch differs from the committed oracle checksums (tests/golden/fullframe_golden.json): "
                   "the number above was measured on WRONG pixels", file=sys.stderr, flush=True)

@@ -20,9 +20,10 @@ def stream_of(local_index, n_streams):
     return local_index % n_streams
 
 
-def max_over_ranks(seconds, dist=None, device=None):
-    """Whole-job time = slowest rank (bench.py contract)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+def max_over_ranks(seconds, dist=None, device=None, always=False):
+    """Whole-job time = slowest rank (bench.py contract).  `always`: run the reduction on a world-size-1 group too
+    (bench.py --force-dist: the one RCCL collective a one-GPU box can execute)."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not always):
         return seconds
     import torch
 

@@ -20,18 +20,39 @@ BENCH = os.path.join(ROOT, "bench.py")
 SIZE, BATCH = 512, 24
 
 
-def run_bench(n, tmp_path, extra=()):
+def check_driver_line(stdout, n):
+    """What the driver does with bench.py's output: the LAST stdout line is one compact JSON object with the contract keys
+    (round 5's had grown to 24.7 KB and was recorded as `parsed: null`)."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    last = stdout.rstrip("\n").splitlines()[-1]
+    assert last.startswith("{") and len(last) < bench.COMPACT_LIMIT, len(last)
+    rec = json.loads(last)
+    assert set(bench.TOP_KEYS) - {"cpu_baseline", "detail_file"} <= set(rec) <= set(bench.TOP_KEYS), sorted(rec)
+    assert rec["n_gpus"] == n and rec["unit"] == "Mpix/s" and rec["value"] > 0 and rec["ms_per_step"] > 0
+    assert rec["roofline"]["bound"] == "hbm" and rec["roofline"]["peak"] == 8000.0 and 0 < rec["roofline"]["frac"]
+    assert ("single_launch_us" in rec["roofline"]) == (n == 1)  # N > 1: the timed region only, the other ranks are released at once
+    return rec
+
+
+def run_bench(n, tmp_path, extra=(), backend="gloo"):
+    """-> (the detail record bench.py wrote, the per-image checksums); the compact line is checked on the way."""
     out = tmp_path / f"sums_{n}.json"
+    detail = tmp_path / f"detail_{n}.json"
     args = ["--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", str(BATCH), "--size", str(SIZE),
-            "--no-cpu-baseline", "--secondary", "", "--settle-seconds", "0", "--dist-backend", "gloo", "--checksums-file", str(out), *extra]
+            "--no-cpu-baseline", "--secondary", "", "--settle-seconds", "0", "--dist-backend", backend, "--checksums-file", str(out),
+            "--detail-file", str(detail), *extra]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     # N > 1: bench.py starts torch.distributed.run itself (as a child, before touching the GPU)
     r = subprocess.run([sys.executable, BENCH, *args], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    return json.loads(line), json.load(open(out))
+    line = check_driver_line(r.stdout, n)
+    rec = json.load(open(detail))
+    assert line["value"] == pytest.approx(rec["value"], rel=1e-5) and line["detail_file"] == str(detail)
+    return rec, json.load(open(out))
 
 
 @pytest.mark.gpu
@@ -53,9 +74,10 @@ def test_one_rank_and_two_ranks_render_identical_images(lrp, oracle, torch_cuda,
         src = oracle.synth_frame(SIZE, SIZE, 4, 0x5EED0000 + i)
         want = oracle.reproject(lin, src, lout, SIZE, SIZE, 1, wl["interp"], None)
         assert f"{lrp.checksum_host(want):016x}" == sums2["checksums"][i], f"image {i}"
+    assert one["roofline"]["single_launch_us"] > 0
+    assert one["roofline"]["single_launch_us_uncached"] > 0 and one["roofline"]["single_launch_frac_uncached"] > 0
+    assert "single_launch_us" not in two["roofline"] and two["secondary"] == {}
     for rec in (one, two):
-        assert rec["roofline"]["frac"] > 0 and rec["roofline"]["single_launch_us"] > 0
-        assert rec["roofline"]["single_launch_us_uncached"] > 0 and rec["roofline"]["single_launch_frac_uncached"] > 0
         assert 0 < rec["roofline"]["frac_read_only"] < rec["roofline"]["frac"]
         # per-rank times (what explains a bad scaling line): one entry per rank, the whole-job time is the slowest rank's
         n = rec["n_gpus"]
@@ -128,16 +150,22 @@ def test_two_ranks_over_rccl_on_two_gpus(torch_cuda, tmp_path):
     if torch_cuda.cuda.device_count() < 2:
         pytest.skip("one GPU visible: two RCCL ranks need two")
     one, sums1 = run_bench(1, tmp_path)
-    out = tmp_path / "sums_nccl.json"
-    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", str(BATCH), "--size", str(SIZE), "--no-cpu-baseline",
-            "--secondary", "", "--settle-seconds", "0", "--dist-backend", "nccl", "--checksums-file", str(out)]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
-    r = subprocess.run([sys.executable, BENCH, *args], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    two = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert two["n_gpus"] == 2 and json.load(open(out))["checksums"] == sums1["checksums"]
+    two, sums2 = run_bench(2, tmp_path, backend="nccl")
+    assert two["n_gpus"] == 2 and sums2["checksums"] == sums1["checksums"]
+
+
+@pytest.mark.gpu
+def test_one_rank_through_the_rccl_path(lrp, torch_cuda, tmp_path):
+    """The N > 1 code path on real RCCL with the one world size a one-GPU box admits: `--force-dist` starts
+    ONE rank under torch.distributed.run (as a child, before anything touches the GPU), `init_process_group("nccl",
+    device_id=...)`, every barrier, both `all_gather_object`s and the device-side float64 `all_reduce(MAX)` of
+    sharding.max_over_ranks execute on a world-size-1 RCCL communicator; the images are the ones a plain run renders."""
+    plain, sums_plain = run_bench(1, tmp_path)
+    forced, sums_forced = run_bench(1, tmp_path, extra=("--force-dist",), backend="nccl")
+    assert plain["dist"] is None and forced["dist"] == "nccl process group, world size 1 (--force-dist)"
+    assert sums_forced["checksums"] == sums_plain["checksums"] and forced["outputs_digest"] == plain["outputs_digest"]
+    assert len(forced["per_rank_elapsed_s"]) == 1 and forced["per_rank_elapsed_s"][0] == pytest.approx(forced["timed_region_s"], abs=1e-6)
+    assert forced["roofline"]["single_launch_us"] > 0  # (N = 1: rank 0 still measures the single-launch legs)
 
 
 @pytest.mark.gpu

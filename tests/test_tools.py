@@ -7,6 +7,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -61,3 +63,51 @@ def test_roofline_table_is_generated_from_the_bench_line(tmp_path):
     cells = [c.strip() for c in head.strip("|").split("|")]
     assert cells[1] == "537" and float(cells[3]) == round(rec["roofline"]["frac"], 3) and float(cells[2]) == round(rec["roofline"]["us_per_frame"], 1)
     assert sum(1 for ln in out.splitlines() if ln.startswith("| ") and ":" in ln.split("|")[1]) == 1 + len(rec["secondary"])
+
+
+def test_the_drivers_bench_line_is_compact_and_complete():
+    """bench.py's LAST stdout line is what the driver parses (BENCH_rNN.json): one JSON object with the contract keys, the
+    roofline and cpu_baseline objects and one {frac, us_per_frame} pair per secondary workload — and SHORT.  Round 5's line was
+    24.7 KB (seven secondaries x two traffic blocks x four prose notes) and the driver recorded `parsed: null`.  Built here from
+    that very result (profiles/r05_bench.json is a full detail record)."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    detail = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+    assert len(json.dumps(detail)) > 20000  # (the canned result is the one that broke the driver)
+    line = bench.compact_line(detail, "bench_detail.json")
+    assert "\n" not in line and len(line) < bench.COMPACT_LIMIT < 6000
+    rec = json.loads(line)
+    assert set(rec) == set(bench.TOP_KEYS)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        want = detail[k]
+        assert rec[k] == (pytest.approx(want, rel=1e-5) if isinstance(want, float) else want), k
+    assert rec["config"]["workload"] == detail["config"]["workload"] and "model" not in rec["config"]
+    roof = rec["roofline"]
+    assert set(roof) == set(bench.ROOFLINE_KEYS)
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], rel=1e-4)
+    assert roof["achieved"] == pytest.approx(roof["algorithmic_bytes_per_launch"] / (roof["kernel_ms_avg"] * 1e-3) / 1e9, rel=1e-4)
+    assert roof["traffic"] == pytest.approx(detail["roofline"]["traffic"], rel=1e-5)
+    cpu = rec["cpu_baseline"]
+    assert set(cpu) == set(bench.CPU_KEYS) and cpu["kind"] == "port" and cpu["cores"] == 16 and len(cpu["sample"]) <= 200
+    assert set(rec["secondary"]) == set(detail["secondary"])
+    for name, r in rec["secondary"].items():
+        assert set(r) == {"frac", "us_per_frame"} and 0 < r["frac"] < 1, name  # (the cubemap's entry is frac_source_once, below 1)
+    assert rec["outputs_match_golden"] is True and rec["detail_file"] == "bench_detail.json"
+    assert "NaN" not in line and "Infinity" not in line
+
+    # an N > 1 line: no cpu_baseline, no secondary, no single-launch legs — still every contract key
+    multi = {k: v for k, v in detail.items() if k not in ("cpu_baseline", "staged")}
+    multi["n_gpus"], multi["secondary"] = 8, {}
+    multi["roofline"] = {k: v for k, v in detail["roofline"].items() if not k.startswith("single_launch")}
+    rec8 = json.loads(bench.compact_line(multi))
+    assert set(rec8) == set(bench.TOP_KEYS) - {"cpu_baseline", "detail_file"} and rec8["secondary"] == {}
+    assert "single_launch_us" not in rec8["roofline"] and rec8["roofline"]["frac"] == roof["frac"]
+
+    # non-finite figures never reach the line as NaN / Infinity tokens, and an oversized line is refused, not printed
+    broken = dict(detail, value=float("nan"))
+    assert json.loads(bench.compact_line(broken))["value"] is None
+    fat = dict(detail, secondary={f"workload_{i}_{'x' * 40}": {"frac": 0.5, "us_per_frame": 100.0} for i in range(60)})
+    with pytest.raises(AssertionError):
+        bench.compact_line(fat)

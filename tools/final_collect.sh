@@ -1,10 +1,11 @@
 #!/usr/bin/env bash
-# Copies the summaries of gpurun_out/final (tools/final_measure.sh) into profiles/ under this round's names.  usage: final_collect.sh [round: r05]
+# Copies the summaries of gpurun_out/final (tools/final_measure.sh) into profiles/ under this round's names.  usage: final_collect.sh [round: r06]
 set -euo pipefail
 R="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd "$R"
-f=gpurun_out/final; r=${1:-r05}
+f=gpurun_out/final; r=${1:-r06}
 cp gpurun_out/traffic_${r}.json profiles/traffic_${r}.json # (written on the GPU box; only gpurun_out/ travels back)
-cp $f/bench.json profiles/${r}_bench.json
+cp $f/bench.json profiles/${r}_bench.json            # the detail file
+cp $f/bench_line.json profiles/${r}_bench_line.json  # the compact line (what BENCH_rNN.json parses)
 cat "$(ls -t $f/prof_bench/*/*kernel_stats.csv | head -1)" > profiles/${r}_bench_kernel_stats.csv # (the newest: gpurun merges the passes of a round into one directory)
 cp $f/kernel_trace_by_launch_shape.txt profiles/${r}_bench_kernel_trace_by_launch_shape.txt
 cp $f/roofline.md profiles/${r}_roofline.md

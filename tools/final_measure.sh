@@ -1,14 +1,15 @@
 #!/usr/bin/env bash
-# ONE pass over everything DESIGN.md quotes; run on an MI355X box from the repo root.  usage: final_measure.sh [round: r05]
+# ONE pass over everything DESIGN.md quotes; run on an MI355X box from the repo root.  usage: final_measure.sh [round: r06]
 # Writes gpurun_out/final/* (copy what is to be judged into profiles/ with tools/final_collect.sh <round>).
 set -uo pipefail
 R="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; cd "$R"
-round="${1:-r05}"
+round="${1:-r06}"
 out=gpurun_out/final; rm -rf $out gpurun_out/traffic; mkdir -p $out
 (timeout 2400 python -m pytest tests -m gpu -q > $out/gpu_tests.log 2>&1; echo "exit $?" >> $out/gpu_tests.log); tail -3 $out/gpu_tests.log
 # the PMC traffic first: bench.py reports roofline.traffic only from a file stamped with the sources it runs
 bash tools/collect_traffic.sh $round > $out/traffic.log 2>&1; tail -2 $out/traffic.log; cp gpurun_out/traffic_$round.json profiles/traffic_$round.json
-(timeout 1200 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?")
+# bench.json = the detail file (everything measured); bench_line.json = the compact line the driver reads (stdout)
+(timeout 1200 python bench.py --detail-file $out/bench.json > $out/bench_line.json 2> $out/bench.err; echo "bench rc=$?"; tail -c 4200 $out/bench_line.json)
 ALL="eqd_rect_bc eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch eqr_rect_bc_gen rect_rect_bc eqd_eqd_bc eqr_eqr_bc_rot eqr_eqd_bc_rot rect_eqd_bc rect_eqr_bc eqr_eqd_bl_rot eqr_rect_bl eqr_rect_nn eqr_rect_bl_rot eqr_rect_nn_rot"
 BC="eqd_rect_bc eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch eqr_rect_bc_gen rect_rect_bc eqr_eqd_bc_rot rect_eqr_bc"
 timeout 300 ./tools/kbench --sum --reps 32 --distinct 16 $ALL > $out/kbench_rgba_single.log 2>&1
@@ -49,7 +50,7 @@ timeout 300 ./tools/staged_bench > $out/staged.log 2>&1
 (echo "# RGBA"; python3 tools/fov_sweep.py 4 2>&1 | grep focal; echo "# RGBAZ + tonemap"; python3 tools/fov_sweep.py 5 post 2>&1 | grep focal) > $out/fov_sweep.log
 timeout 100 tools/microbench/hbm_stream > $out/hbm_stream.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof_bench -- python3 $R/bench.py --no-cpu-baseline --no-staged > $R/$out/prof_bench.log 2>&1; echo "rocprof rc=$?"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof_bench -- python3 $R/bench.py --no-cpu-baseline --no-staged --detail-file "" > $R/$out/prof_bench.log 2>&1; echo "rocprof rc=$?"
 cat $R/$out/prof_bench/*/*kernel_stats.csv | cut -c1-200
 python3 $R/tools/kernel_trace_summary.py $(ls -t $R/$out/prof_bench/*/*kernel_trace.csv | head -1) | tee $R/$out/kernel_trace_by_launch_shape.txt
 i=0
@@ -67,4 +68,4 @@ python3 $R/tools/pmc_summary.py $R/$out/sq > $R/$out/sq_counters.txt
 cd $R
 (timeout 1800 python3 tools/policy_check.py 0.05 2>&1 | grep -v amdgpu.ids > $out/policy_check.txt; echo "policy_check rc=$?" >> $out/policy_check.txt)
 python3 tools/roofline_table.py $out/bench.json $out/kernel_trace_by_launch_shape.txt > $out/roofline.md
-cat $out/bench.json
+cat $out/bench_line.json

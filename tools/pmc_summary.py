@@ -16,6 +16,7 @@ for arg in sys.argv[1:]:
         for k, cs in agg.items():
             if "synth" in k or "build_tables" in k:
                 continue
-            print(arg, "|", k)
+            # the pass (its directory under the argument), never an absolute path of the box
+            print(os.path.relpath(os.path.dirname(f), arg).split(os.sep)[0], "|", k)
             for c, v in sorted(cs.items()):
                 print(f"    {c:34s} {sum(v)/len(v):16.1f}  (n={len(v)})")
