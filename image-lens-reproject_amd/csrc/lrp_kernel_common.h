@@ -27,18 +27,6 @@
 
 namespace lrp {
 
-#ifndef LRP_VERT_STEPS
-#define LRP_VERT_STEPS 1 // coefficient tier: the vertical evaluations interleaved step by step (0: chain by chain, the compiler's order)
-#endif
-#ifndef LRP_OPT_POST
-#define LRP_OPT_POST 1
-#endif
-#ifndef LRP_OPT_TIER
-#define LRP_OPT_TIER 1
-#endif
-#ifndef LRP_WIN_ALIAS_PAIRS
-#define LRP_WIN_ALIAS_PAIRS 1 // rectilinear -> panorama: the view and its copy behind the camera rendered side by side
-#endif
 constexpr int kT2W = 64;         // tile width: one output column per lane
 // Output rows per wavefront of the tile kernel, per sampler (measured at the settled
 // clock, 4K frames: bilinear and bicubic hold 4 / 16 taps per pixel in registers and run
@@ -176,38 +164,7 @@ __device__ __forceinline__ void bicubic_indices(float sx, float sy, int w, int h
 // plus a single (c2 for RGB, c4 for RGBAZ); every interpolation step is one packed
 // instruction per pair (v_pk_mul_f32 / v_pk_add_f32 round each half exactly like
 // the scalar instruction) plus a scalar one for the odd channel, weights broadcast.
-#ifndef LRP_NO_PACKED
-#define LRP_NO_PACKED 0
-#endif
-#if LRP_NO_PACKED
-// Channel pairs as two independent floats: every operation is a plain VOP2 / VOP3 instruction (build with
-// -fno-slp-vectorize so that the compiler does not fuse them back into v_pk_*_f32).  On gfx950 a wavefront
-// whose VALU stream contains packed-f32 instructions issues ALL its VALU instructions at ~4 cycles; a stream
-// without them issues plain, SGPR-operand, convert and compare instructions at ~2.2 (tools/microbench/valu_runs.hip).
-struct f2 {
-  float x, y;
-};
-__device__ __forceinline__ f2 operator+(const f2 a, const f2 b) { return f2{a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ f2 operator-(const f2 a, const f2 b) { return f2{a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ f2 operator*(const f2 a, const f2 b) { return f2{a.x * b.x, a.y * b.y}; }
-__device__ __forceinline__ f2 operator+(const f2 a, const float b) { return f2{a.x + b, a.y + b}; }
-__device__ __forceinline__ f2 operator-(const f2 a, const float b) { return f2{a.x - b, a.y - b}; }
-__device__ __forceinline__ f2 operator*(const f2 a, const float b) { return f2{a.x * b, a.y * b}; }
-__device__ __forceinline__ f2 operator+(const float a, const f2 b) { return f2{a + b.x, a + b.y}; }
-__device__ __forceinline__ f2 operator*(const float a, const f2 b) { return f2{a * b.x, a * b.y}; }
-__device__ __forceinline__ f2 &operator+=(f2 &a, const f2 b) {
-  a.x += b.x;
-  a.y += b.y;
-  return a;
-}
-__device__ __forceinline__ f2 &operator+=(f2 &a, const float b) {
-  a.x += b;
-  a.y += b;
-  return a;
-}
-#else
 typedef float f2 __attribute__((ext_vector_type(2)));
-#endif
 template <int CH> struct Px {
   f2 lo; // channels 0, 1
   f2 hi; // channels 2, 3 (CH >= 4)
@@ -226,17 +183,7 @@ template <int CH> __device__ __forceinline__ void px_add(Px<CH> &a, const Px<CH>
 // cubicInterpolate (src/reproject.cpp:92-98), same association order as catmull_rom().
 __device__ __forceinline__ f2 catmull_rom2(const f2 a, const f2 b, const f2 c, const f2 d, float t, float half_t) {
   const f2 inner = ((3.0f * (b - c)) + d) - a;
-#if defined(LRP_FUSED_EXACT_PRODUCTS) && !LRP_NO_PACKED
-  // Timing experiment (tools/ablate_units.sh; NOT the reference's bits for texels of 2^126 and more): 2 a and 4 c are exact
-  // products unless they overflow, so fma(2, a, -(5 b)) and fma(4, c, x) round like the separate multiply + add — 15 instead of
-  // 17 operations.  Guarding it needs a magnitude test of every texel, which costs what it saves.
-  const f2 m5b = 5.0f * b;
-  const f2 x0 = __builtin_elementwise_fma(f2{2.0f, 2.0f}, a, -m5b);
-  const f2 x1 = __builtin_elementwise_fma(f2{4.0f, 4.0f}, c, x0);
-  const f2 mid = (x1 - d) + t * inner;
-#else
   const f2 mid = ((((2.0f * a) - (5.0f * b)) + (4.0f * c)) - d) + t * inner;
-#endif
   const f2 outer = (c - a) + t * mid;
   return b + half_t * outer;
 }
@@ -653,23 +600,8 @@ __device__ __forceinline__ Px<CH> sample_direct(const KParams &P, const SrcView 
       const float tx_ = __builtin_truncf(sx), ty_ = __builtin_truncf(sy);
       const float fx = sx - tx_, fy = sy - ty_;
       uint32_t v0 = __umul24((uint32_t)((int)ty_ - 1), row_bytes) + (uint32_t)((int)tx_ - 1) * T;
-#if defined(LRP_ABLATE_L2ROWS) // timing experiment (wrong results): the taps of every pixel come from the first 64 source rows (cache-resident), same access pattern within a row
-      v0 = __umul24((uint32_t)(((int)ty_ - 1) & 63), row_bytes) + (uint32_t)((int)tx_ - 1) * T;
-#endif
-#if defined(LRP_ABLATE_ONETAP) // timing experiment (wrong results): one tap load per pixel, the arithmetic of all five cubics
-      {
-        const Px<CH> acc = texel_at<CH>(rsrc, v0, 0u);
-        const float hfx_ = 0.5f * fx, hfy_ = 0.5f * fy;
-        const Px<CH> k0 = cubic_px<CH>(acc, acc, acc, acc, fy, hfy_);
-        Px<CH> k1 = k0, k2 = k0, k3 = k0;
-        k1.lo += fx; k2.lo += fy; k3.lo += hfx_;
-        s = cubic_px<CH>(cubic_px<CH>(k0, k1, k2, k3, fy, hfy_), cubic_px<CH>(k1, k2, k3, k0, fy, hfy_),
-                         cubic_px<CH>(k2, k3, k0, k1, fy, hfy_), cubic_px<CH>(k3, k0, k1, k2, fy, hfy_), fx, hfx_);
-      }
-#else
       s = bicubic_taps<CH, true, LowReg>(rsrc, v0, v0 + T, v0 + 2u * T, v0 + 3u * T, 0u, row_bytes, 2u * row_bytes,
                                  3u * row_bytes, fx, fy);
-#endif
     } else {
       int xs[4], ys[4];
       bicubic_indices<Loop>(sx, sy, in_w, in_h, xs, ys);
@@ -760,9 +692,7 @@ __device__ __forceinline__ void finish_px(const KParams &P, const Px<CH> &a, flo
   // (the flag is made opaque where it is tested: hoisted out of the pass loops as a lane mask, its negation for the
   // branch comes back as a v_cndmask + v_cmp pair in front of every store; as a scalar integer it is an s_cmp)
   int has_post = P.has_post;
-#if LRP_OPT_POST
   asm volatile("" : "+s"(has_post));
-#endif
   if (has_post != 0) {
     c[0] = tonemap(c[0], P.exposure, P.reinhard);
     c[1] = tonemap(c[1], P.exposure, P.reinhard);

@@ -87,8 +87,8 @@ struct KParams {
   int32_t quad;                     // 1: mirrored pixels / blocks (mapping symmetric about both image axes); 2: mirrored rays (tile kernels, equidistant target)
   int32_t frames_per_wave;          // window kernel, batched launch: consecutive frames one wavefront renders its strip for (blockIdx.y = group of frames)
   int32_t win_mode;                 // window kernel: 0 plain blocks, 1 blocks mirrored in both axes (== quad 1), 2 rows only (pan), 3 columns only (pitch), 4 shared rays (equidistant target, any rotation)
-  int32_t win_edge;    // window kernel: blocks beyond one side of the source stage one source row / column (LRP_WIN_EDGE=0: per-pixel gathers)
-  int32_t win_split;   // window kernel: blocks whose window exceeds the buffer stage the windows of their two halves one after the other (LRP_WIN_SPLIT=0: per-pixel gathers)
+  int32_t win_edge;    // window kernel: blocks beyond one side of the source stage one source row / column (0: per-pixel gathers)
+  int32_t win_split;   // window kernel: blocks whose window exceeds the buffer stage the windows of their two halves one after the other (0: per-pixel gathers)
   int32_t win_tapdma;  // window kernel: a pass whose window fits no buffer fetches its taps quad by quad through LDS-DMA (lrp_win_kernel.h tap_dma; 0: per-pixel gathers)
   // Geometry cache (lrp_geocache.h): what a single launch would re-derive from the geometry alone — the source
   // coordinates of every output pixel and, for the window kernel, the window extremes of every 16 x 16 block — kept in

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(kT2Threads, (Frames || GeoRead) ? LRP_TILE_MINWAVES
   if (!xcd_tile(P.tiles_x, P.tiles_y, tx, ty)) return; // whole workgroup
   // Alias pairs (see the window kernel): a rectilinear view rendered into a panorama appears a second time behind
   // the camera, from the same source texels; consecutive workgroups of an XCD take the two tiles that read them.
-  if constexpr (LRP_WIN_ALIAS_PAIRS != 0 && (OutLens == kEquirect || GeoRead) && InMode == kInRect) {
+  if constexpr ((OutLens == kEquirect || GeoRead) && InMode == kInRect) {
     if (P.alias_pairs == 0) {
       // (a partial panorama has no second copy: raster order keeps neighbouring tiles together, 1-3 % faster there)
     } else if (P.quad == 1) { // quadrant tiles: columns from both ends inwards (tile t shares its texels with tile tiles_x-1-t)

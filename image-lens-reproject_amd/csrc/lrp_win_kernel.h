@@ -108,49 +108,13 @@ template <int OutLens, int InMode, int QMode, int CH, bool Frames = false, bool 
                              // wavefronts; since the passes without a window fetch their taps (1027 slots) the ninth wavefront is worth more:
                              // rect -> equirect 4096^2 RGBA 179 -> 173 us single, 163 -> 157 batched; rect -> fisheye 146 -> 140 / 130 -> 124 (1060 / 1100 / 1120: level)
 #endif
-#ifndef LRP_BIG_NO_COEF
-#define LRP_BIG_NO_COEF 1 // (rect -> equirect RGBAZ + tonemap 258 -> 252.5 us batched, RGBA 158.4 -> 156.4, rect -> fisheye and the pole face -0.5 %)
-#endif
-#ifndef LRP_BIG_ROLL_STAGED
-#define LRP_BIG_ROLL_STAGED 1
-#endif
-#ifndef LRP_WIN_ROLLED_UNSTAGED
-#define LRP_WIN_ROLLED_UNSTAGED 1 // the big-window variant: blocks with nothing staged run their passes in one rolled loop (below)
-#endif
-#ifndef LRP_WIN_PASS_PIPELINE
-#define LRP_WIN_PASS_PIPELINE 1 // ... and request what pass k + 1 reads behind the taps of pass k (0: in front of pass k + 1, on the spot)
-#endif
-#ifndef LRP_DMA_ROWS_V2
-#define LRP_DMA_ROWS_V2 1 // the window-row requests of issue() in the big-window variant: see there
-#endif
-#ifndef LRP_PASS_QUICK_REJECT
-#define LRP_PASS_QUICK_REJECT 1 // big-window variant: a pass that is too wide for a window by its first row alone skips the wave-wide plan
-#endif
-#ifndef LRP_TAP_OFFSETS
-#define LRP_TAP_OFFSETS 1 // tap DMA: one write of M0 per group of four tap rows, the rows told apart by instruction offsets (0: one per instruction)
-#endif
-#ifndef LRP_TAP_DPP
-#define LRP_TAP_DPP 1 // tap DMA: the quad's pixel offsets by DPP moves (0: ds_bpermute, an LDS round trip per pass)
-#endif
-#ifndef LRP_WIN_TAPDMA
-#define LRP_WIN_TAPDMA 1 // the big-window variant: tap DMA (below) compiled in
-#endif
-#ifndef LRP_TAP_SPLIT5
-#define LRP_TAP_SPLIT5 0 // 1: RGBAZ tap DMA in two steps — the colour taps, then (behind their read-back, under the colour arithmetic) the depths into the
-                         // same 16 KiB — so that buffer + exchange buffer are 17.5 KiB (nine wavefronts per CU) and the passes can be requested ahead.
-                         // Measured 8 % SLOWER (rect -> equirect RGBAZ + tonemap 264 -> 285 us batched, pole face 133 -> 142): nine wavefronts
-                         // need <= 168 VGPRs (178 at eight: spills), the windows shrink to 1040 slots, the code grows to 97 KB.  Off.
-#endif
-#ifndef LRP_WIN_CAP_BIG5S
-#define LRP_WIN_CAP_BIG5S 1040 // ... its window slots then: 16.25 KiB + the 1.25 KiB exchange buffer = 17.5 KiB
-#endif
 #ifndef LRP_WIN_CAP_BIG5
 #define LRP_WIN_CAP_BIG5 1200 // ... RGBAZ: 18.75 KiB, so that with the 1.25 KiB exchange buffer of its stores eight wavefronts fit a CU's 160 KiB (1280 slots: seven; rect -> equirect RGBAZ + tonemap 330 -> 318 us single, 313 -> 300 batched)
 #endif
 #ifndef LRP_WIN_MINWAVES_BIG
 #define LRP_WIN_MINWAVES_BIG 2
 #endif
-__global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((CH == 5 && LRP_TAP_SPLIT5 != 0) ? 3 : LRP_WIN_MINWAVES_BIG) : CH == 5 ? LRP_WIN_MINWAVES5 : (QMode == 4 ? LRP_WIN_MINWAVES_RAYS : (Frames ? LRP_WIN_MINWAVES_FRAMES : (QMode >= 2 ? LRP_WIN_MINWAVES_AXIS : LRP_WIN_MINWAVES)))) void reproject_bicubic_win_kernel(const KParams Pk) {
+__global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LRP_WIN_MINWAVES_BIG : CH == 5 ? LRP_WIN_MINWAVES5 : (QMode == 4 ? LRP_WIN_MINWAVES_RAYS : (Frames ? LRP_WIN_MINWAVES_FRAMES : (QMode >= 2 ? LRP_WIN_MINWAVES_AXIS : LRP_WIN_MINWAVES)))) void reproject_bicubic_win_kernel(const KParams Pk) {
   constexpr bool Quad = QMode != 0;
   constexpr bool MirX = QMode == 1 || QMode == 3 || QMode == 4, MirY = QMode == 1 || QMode == 2 || QMode == 4;
   constexpr bool kSharedRays = QMode == 4; // only the ray through the output lens is shared: per-image coordinates are stored like a plain block's
@@ -171,8 +135,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
   // stages the windows of single passes (and fetches the taps of the passes that have none: tap DMA below).  tools/microbench/row_gather.hip: rows of that shape arrive at 7.7 TB/s by
   // LDS-DMA with 8 wavefronts per CU, a window each in flight; per-pixel gathers of the same bytes at 4.5 TB/s in this kernel.
   constexpr bool kBigWin = GeoRead && OutLens == kEquirect;
-  constexpr bool kTapSplit5 = kBigWin && CH == 5 && kWinWaves == 1 && LRP_WIN_TAPDMA != 0 && LRP_WIN_ROLLED_UNSTAGED != 0 && LRP_TAP_SPLIT5 != 0;
-  constexpr int kCap = kBigWin ? (CH == 5 ? (kTapSplit5 ? LRP_WIN_CAP_BIG5S : LRP_WIN_CAP_BIG5) : LRP_WIN_CAP_BIG) : kWinCap; // 16-byte slots of this instantiation's window buffer
+  constexpr int kCap = kBigWin ? (CH == 5 ? LRP_WIN_CAP_BIG5 : LRP_WIN_CAP_BIG) : kWinCap; // 16-byte slots of this instantiation's window buffer
 #ifndef LRP_BIG_PASSCOLS
 #define LRP_BIG_PASSCOLS 64 // (128 — two DMA instructions per row for the wider ones — measured 1 % slower once such passes can fetch their taps instead)
 #endif
@@ -217,7 +180,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
   // Edge blocks (WinBlockT::edge) are compiled for the rectilinear source only: a narrow view inside a wider target is
   // where whole blocks lie beyond one side of the source; in the other instantiations the extra code costs 2-3 % (measured:
   // fisheye -> rectilinear 100 -> 102.5 us, fisheye -> fisheye 141.5 -> 146) and such blocks take the per-pixel gathers.
-  constexpr bool kEdge = LRP_WIN_EDGE != 0 && InMode == kInRect;
+  constexpr bool kEdge = InMode == kInRect;
   // Split blocks (WinBlockT::split) are compiled into the single-launch instantiations only: in the kernels with the frame
   // loop the extra code costs 2-7 % on mappings that have no such block (measured: equirect -> rect 91 -> 98 us, rect ->
   // equirect 212 -> 227), and what needs them — the 2048^2 faces of an 8192^2 panorama — arrives as single launches.
@@ -225,26 +188,24 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
   // the rectilinear-source kernels lost 6 % to the extra code: rect -> equirect 210 -> 223 us).
   // (... and for the RGBAZ kernels of a rectilinear source: their per-pixel path is 20 gathers a pixel, and the pass windows
   // below pay there — rect -> equirect RGBAZ 300 -> 288 us, BASELINE configs[3] — while RGBA / RGB lose 4-6 %.)
-#ifndef LRP_BIG_SPLIT4
-#define LRP_BIG_SPLIT4 1 // the big-window RGBA variant stages half blocks too, like the RGBAZ one (rect -> equirect 4096^2: 210 -> 203 us single, 191 -> 184 batched)
-#endif
 #ifndef LRP_BIG_MAXCOLS
 #define LRP_BIG_MAXCOLS 64 // widest block / half-block window of the big-window variant (pass windows: LRP_BIG_PASSCOLS)
 #endif
-  constexpr bool kSplit = LRP_WIN_SPLIT != 0 && !Frames && (InMode == kInEquirect || InMode == kInEquirectLoop || (InMode == kInRect && CH == 5) || (kBigWin && LRP_BIG_SPLIT4 != 0));
+  // (the big-window variant stages half blocks for every channel count: rect -> equirect 4096^2 RGBA 210 -> 203 us single, 191 -> 184 batched)
+  constexpr bool kSplit = !Frames && (InMode == kInEquirect || InMode == kInEquirectLoop || (InMode == kInRect && CH == 5) || kBigWin);
   constexpr int kMaxStagedCols = kBigWin ? LRP_BIG_MAXCOLS : 64;
   // Pass windows (below) for rectilinear targets only — perspective views and cubemap faces out of a panorama; in the
   // fisheye-target kernels the extra code cost 2.5 % (equirect -> fisheye single launches 247 -> 253 us).
-  constexpr bool kPassWin = (kSplit || (GeoRead && OutLens == kEquirect)) && LRP_WIN_PASSWIN != 0 && (OutLens == kRect || GeoRead || (InMode == kInRect && CH == 5));
-  constexpr int kPlanes = 3;
-  // (LRP_BIG_NO_COEF: the big-window variant without the coefficient tier — its blocks are minified, the planes rarely fit)
-  constexpr bool kCoefHere = kWinCoef && !(kBigWin && LRP_BIG_NO_COEF != 0);
+  constexpr bool kPassWin = (kSplit || (GeoRead && OutLens == kEquirect)) && (OutLens == kRect || GeoRead || (InMode == kInRect && CH == 5));
+  // (the big-window variant has no coefficient tier — its blocks are minified, the planes rarely fit: rect -> equirect RGBAZ + tonemap
+  // 258 -> 252.5 us batched, RGBA 158.4 -> 156.4)
+  constexpr bool kCoefHere = !kBigWin;
   // Tap DMA (big-window variant; request_taps below) needs 1024 slots for the colour taps of a pass — and, RGBAZ, 1024 floats for their
   // depths behind them: exactly the 18.75 KiB window + the 1.25 KiB exchange buffer of the stores, which therefore lie in ONE
   // array (the exchange buffer is written behind the pixel's last tap read and read back before the next pass requests anything).
-  constexpr bool kTapDma = kBigWin && kWinWaves == 1 && LRP_WIN_TAPDMA != 0 && LRP_WIN_ROLLED_UNSTAGED != 0;
+  constexpr bool kTapDma = kBigWin && kWinWaves == 1;
   constexpr int kOutSlots = (CH == 5 && kTapDma) ? 80 : 0; // 320 floats
-  static_assert(!kTapDma || ((CH == 5 && !kTapSplit5) ? (kCap + kOutSlots) * 16 >= 1024 * 20 : kCap >= 1024), "tap DMA: 16 taps x 64 pixels");
+  static_assert(!kTapDma || (CH == 5 ? (kCap + kOutSlots) * 16 >= 1024 * 20 : kCap >= 1024), "tap DMA: 16 taps x 64 pixels");
   // how the read-back of the taps avoids LDS bank conflicts (request_taps below): groups skewed by one slot each where the buffer
   // has the three slots to spare (conflict-free), else the quads rotated within their rows of 16 lanes (two-way)
   constexpr bool kTapRotate = CH == 5 || kCap < 1027;
@@ -309,7 +270,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
 #if defined(LRP_WAVE_STAMPS)
   const unsigned long long stamp_start = wall_clock64();
 #endif
-  // Alias pairs (LRP_WIN_ALIAS_PAIRS; mirrored strips of rectilinear -> equirectangular).  The reference has no
+  // Alias pairs (mirrored strips of rectilinear -> equirectangular).  The reference has no
   // hemisphere test: the ray of panorama pixel (x + W/2, H-1-y) is the ray of (x, y) with x and z negated, and a
   // rectilinear projection divides by z — both pixels land on (nearly: different roundings) the same source
   // texel, the view is rendered a second time behind the camera.  In quadrant terms the strip of tile column
@@ -321,7 +282,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
   // Plain strips (the tables of a panorama are not mirror images bit for bit, so this is the kernel that runs):
   // the strip of tile (t, r) and the strip of tile (t + tiles_x/2, tiles_y-1-r) are the pair, the second one
   // walks its blocks bottom-up.
-  constexpr bool kAliasPairs = LRP_WIN_ALIAS_PAIRS != 0 && (OutLens == kEquirect || GeoRead) && InMode == kInRect && kWinWaves == 1;
+  constexpr bool kAliasPairs = (OutLens == kEquirect || GeoRead) && InMode == kInRect && kWinWaves == 1;
   int g_flip = 0;        // mirrored strips: the mirror image rendered by loop iteration g is g ^ g_flip
   bool g_reverse = false; // plain strips: iteration g renders block G-1-g
   if (kAliasPairs && P.alias_pairs != 0 && !listed) {
@@ -484,7 +445,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
   // long way, precise test included.
   int plan = 0;
   uint32_t plan_exact = 0;
-  constexpr bool kStripPlan = Quad && !kSharedRays && LRP_WIN_STRIP_PLAN != 0;
+  constexpr bool kStripPlan = Quad && !kSharedRays;
   auto plan_strip = [&]() {
     Extremes e0, e1; // unmirrored (image 0) and mirrored in every mirrored axis (an axis that is not mirrored has one range: e1's equals e0's)
 #pragma unroll
@@ -585,9 +546,9 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
     // column's share of the source lens — is loop-invariant, gets hoisted out of the block loop and then spilled to scratch
     // for the whole kernel: 80-100 MB of scratch traffic per 4K frame.  Opaque here, those few multiplies run per block.)
     ColTerms col_g = col;
-    if constexpr (!Quad && LRP_OPAQUE_COL != 0) asm volatile("" : "+v"(col_g.a), "+v"(col_g.b), "+v"(col_g.nx), "+v"(col_g.nz), "+v"(col_g.sx));
+    if constexpr (!Quad) asm volatile("" : "+v"(col_g.a), "+v"(col_g.b), "+v"(col_g.nx), "+v"(col_g.nz), "+v"(col_g.sx));
     ColTerms col_s = col_m; // SS: sub-samples 2, 3 (ssx == 1)
-    if constexpr (SS && LRP_OPAQUE_COL != 0) asm volatile("" : "+v"(col_s.a), "+v"(col_s.b), "+v"(col_s.nx), "+v"(col_s.nz), "+v"(col_s.sx));
+    if constexpr (SS) asm volatile("" : "+v"(col_s.a), "+v"(col_s.b), "+v"(col_s.nx), "+v"(col_s.nz), "+v"(col_s.sx));
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int yk = pixel_row(g, k);
@@ -673,10 +634,9 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
   // anything is requested for it and skips geo_fetch: in a strip of corner blocks nothing stands between the stores
   // (a 4096^2 frame of corner blocks, every block waiting for its successor's record and coordinates: RGBA 100 -> 79 us,
   // RGBAZ + tonemap 167 -> 144 us).
-#ifndef LRP_GEO_CLASSES
-#define LRP_GEO_CLASSES 2 // 0: never; 1: every GeoRead instantiation of a source with corners (10 more spilled SGPRs at four wavefronts per SIMD: rect -> fisheye single launches 164 -> 171 us); 2: the big-window variant only
-#endif
-  constexpr bool kGeoClasses = GeoRead && !Loop && LRP_WIN_CORNER != 0 && (LRP_GEO_CLASSES == 1 || (LRP_GEO_CLASSES == 2 && kBigWin));
+  // (the big-window variant only: in every GeoRead instantiation of a source with corners the word costs 10 more spilled SGPRs at four
+  // wavefronts per SIMD — rect -> fisheye single launches 164 -> 171 us)
+  constexpr bool kGeoClasses = GeoRead && !Loop && kBigWin;
   uint32_t strip_classes = 0;
   if constexpr (kGeoClasses) {
     if (Gs <= 4 && (Gs & (Gs - 1)) == 0 && !listed) { // (a listed block is not a corner block)
@@ -792,7 +752,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
         const uint32_t lds_step = (uint32_t)(b.spitch() * 16); // dwordx3 too writes one 16-byte slot per lane
         const uint32_t lane_bytes = (uint32_t)(b.x_lo + chunk * 64 + lane) * (4u * CH);
         const int n_rows = kSplit ? b.rows_of(half) : b.bh;
-        if constexpr (kBigWin && LRP_DMA_ROWS_V2 != 0) {
+        if constexpr (kBigWin) {
           // Per window row: M0, the request, the next row's LDS address and ONE vector add that moves the lanes' byte offsets to the
           // next source row — the scalar base is the frame's for every row.  Four rows per loop iteration: -1 % on the listed launches
           // of the big-window variant, nothing in the four-wavefront kernels (which keep the loop below).  (There: a 64-bit scalar
@@ -1018,9 +978,6 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
     }
     const Px<CH> a = accumulate(s);
     const PassOut o = pass_out(g, k);
-#if defined(LRP_NO_STORE) // timing experiment: almost no output traffic
-    if (a.lo.x == 12345.678f) store_px<CH, true>(P, (uint32_t)o.yo * (uint32_t)P.out_w + (uint32_t)o.xo, a);
-#else
     if constexpr (CH == 5) {
      if constexpr (decltype(as_runs)::value) {
       // a pass that lies in the image whole (wave-uniform) leaves as four runs of 16 pixels (store_rgbaz_run).
@@ -1037,7 +994,6 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
      }
     }
     store_px<CH, true>(P, (uint32_t)o.yo * (uint32_t)P.out_w + (uint32_t)o.xo, a);
-#endif
   };
   // A corner block: every pixel is the one value `s`.  Finished (normalize, tonemap) once, stored four times; an RGBAZ pass that
   // lies in the image whole leaves as 80 sixteen-byte chunks of the repeating five-float pattern straight from registers (no
@@ -1074,9 +1030,6 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
     for (int k = 0; k < 4; ++k) {
       if (k == 3) before_last();
       const PassOut o = pass_out(g, k);
-#if defined(LRP_NO_STORE)
-      if (c[0] == 12345.678f) store_texel_nt<CH>(P.dst + (size_t)((uint32_t)o.yo * (uint32_t)P.out_w + (uint32_t)o.xo) * CH, c);
-#else
       if constexpr (CH == 5) {
         if (o.whole) { // (a constant run reads the same mirrored or not)
           float *const row0 = P.dst + (size_t)o.first * 5;
@@ -1087,7 +1040,6 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
         }
       }
       store_texel_nt<CH>(P.dst + (size_t)((uint32_t)o.yo * (uint32_t)P.out_w + (uint32_t)o.xo) * CH, c);
-#endif
     }
   };
   // Pass windows (kernels with split blocks): a block whose two half windows do not fit either (a pole face of a
@@ -1112,8 +1064,8 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
   // window of int(b) - int(a) + 4 > kMaxPassCols columns.  (NaN compares false: the full plan decides.)
   auto pass_too_wide = [&](float psx) -> bool {
     const float xa = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(psx), 0));
-    const float xb = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(psx), LRP_WIN_LANEMAP != 0 ? 27 : kBlkW - 1));
-    return LRP_PASS_QUICK_REJECT != 0 && __builtin_fabsf(xb - xa) >= (float)(kMaxPassCols - 3);
+    const float xb = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(psx), kBlkW - 1));
+    return __builtin_fabsf(xb - xa) >= (float)(kMaxPassCols - 3);
   };
   auto plan_pass_window = [&](WinBlock &w, int lo_x, int hi_x, int lo_y, int hi_y) -> bool {
     if (kBigWin && pass_too_wide(u2f((uint32_t)lo_x))) return false;
@@ -1185,8 +1137,9 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
         }
       }
   };
-  // (`which`: 1 the colour taps, 2 the depths, 3 both; the depths land `depth_at` bytes into the buffer)
-  auto request_taps = [&](float psx, float psy, int which = 3, uint32_t depth_at = 1024u * 16u) {
+  // (RGBAZ: the depths land behind the 1024 colour slots)
+  auto request_taps = [&](float psx, float psy) {
+    constexpr uint32_t depth_at = 1024u * 16u;
     const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
     constexpr uint32_t T = 4u * CH;
     const uint32_t v0 = __umul24((uint32_t)((int)ty_ - 1), src.row_bytes) + (uint32_t)((int)tx_ - 1) * T; // tap (0, 0) of this lane's pixel
@@ -1196,7 +1149,6 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
     for (int t = 0; t < 4; ++t) {
       // the offset of the pixel this lane helps to fetch in group t: pixel t of this lane's quad (quad_perm broadcast), RGBAZ: of
       // the quad t positions further down its row of 16 lanes (row_ror: lane i takes lane i - 4 t)
-#if LRP_TAP_DPP
       int got;
       if (t == 0) got = __builtin_amdgcn_mov_dpp((int)v0, 0x00, 0xF, 0xF, false);
       else if (t == 1) got = __builtin_amdgcn_mov_dpp((int)v0, 0x55, 0xF, 0xF, false);
@@ -1208,19 +1160,12 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
         else if (t == 3) got = __builtin_amdgcn_mov_dpp(got, 0x120 + 12, 0xF, 0xF, false);
       }
       const uint32_t vt = (uint32_t)got + (uint32_t)j * T;
-#else
-      const int from = kTapRotate ? ((lane & 48) | ((((lane >> 2) - t) & 3) << 2) | t) : ((lane & ~3) | t);
-      const uint32_t vt = (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)v0) + (uint32_t)j * T;
-#endif
-#if LRP_TAP_OFFSETS
       // the four tap rows of the group with ONE write of M0: the instruction offset moves the LDS address AND the global one, so
       // row r (LDS: 1024 r bytes further, depth plane: 256 r) takes a scalar base that many bytes lower
       {
         const uint32_t o0 = vt, o1 = vt + src.row_bytes, o2 = vt + 2u * src.row_bytes, o3 = vt + 3u * src.row_bytes;
         const uint32_t lds = pass_lds0 + (uint32_t)((4 * t * 64 + (kTapRotate ? 0 : t)) * 16);
-        if (CH == 5 && (which & 1) == 0) {
-          // (the depths only)
-        } else if constexpr (CH == 3)
+        if constexpr (CH == 3)
           asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %5\n\tglobal_load_lds_dwordx3 %2, %6 offset:1024\n\t"
                        "global_load_lds_dwordx3 %3, %7 offset:2048\n\tglobal_load_lds_dwordx3 %4, %8 offset:3072"
                        :
@@ -1232,7 +1177,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
                        :
                        : "s"(lds), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base), "s"(base - 1024), "s"(base - 2048), "s"(base - 3072)
                        : "memory", "m0");
-        if (CH == 5 && (which & 2) != 0) {
+        if constexpr (CH == 5) {
           const uint32_t lds_d = pass_lds0 + depth_at + (uint32_t)(4 * t * 64 * 4);
           asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %5\n\tglobal_load_lds_dword %2, %6 offset:256\n\t"
                        "global_load_lds_dword %3, %7 offset:512\n\tglobal_load_lds_dword %4, %8 offset:768"
@@ -1241,21 +1186,6 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
                        : "memory", "m0");
         }
       }
-#else
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const uint32_t off = vt + (uint32_t)r * src.row_bytes;
-        const uint32_t lds = pass_lds0 + (uint32_t)(((4 * t + r) * 64 + (kTapRotate ? 0 : t)) * 16);
-        if constexpr (CH == 3)
-          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %2" : : "s"(lds), "v"(off), "s"(base) : "memory", "m0");
-        else
-          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds), "v"(off), "s"(base) : "memory", "m0");
-        if constexpr (CH == 5) {
-          const uint32_t lds_d = pass_lds0 + depth_at + (uint32_t)((4 * t + r) * 64 * 4); // (this path: both planes at once only)
-          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" : : "s"(lds_d), "v"(off), "s"(base + 16) : "memory", "m0");
-        }
-      }
-#endif
     }
   };
   // plans pass `k` (coordinates psx, psy) and requests what it will read: 1 its own window `w`, 2 its taps, 0 nothing (it gathers)
@@ -1268,10 +1198,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
       request_pass(w);
       return 1;
     }
-    if constexpr (kTapSplit5)
-      request_taps(psx, psy, 1); // (the colour taps; the depths follow behind their read-back: below)
-    else
-      request_taps(psx, psy);
+    request_taps(psx, psy);
     return 2;
   };
 #pragma unroll 1
@@ -1288,24 +1215,18 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
     f_loop = f;
     if (n_frames > 1 || g == 0) set_frame(f);
     const bool last_frame = f + 1 == n_frames; // the next step is the next block
-#if !defined(LRP_NO_DMA_WAIT) // timing experiment (wrong results): how much of the frame is exposed DMA / store latency
     // (a launch that writes the geometry cache has the stores of coords(g + 1) in flight as well: it waits for everything)
     if ((g == 0 && f == 0) || !dma_early || geo_write)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the window was the last thing requested
     else
       asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); // window g has landed; block g-1's last store may be in flight
-#endif
     if constexpr (GeoRead)
       if (g + 1 < G && f == 0 && geo_class(g + 1) == 0) geo_fetch(g + 1, nxt);
     const float4 *const win = win0;
     // The tier of this block in a scalar register for the branches below: carried through the block loop inside `cur` it
     // ends up in a VGPR (the kernel is at the SGPR limit), and every test of it then costs a v_and + v_cmp and the
     // branch condition is re-materialised through v_cndmask / v_cmp at each use — seven VALU instructions per pass.
-#if LRP_OPT_TIER
     const int tier = __builtin_amdgcn_readfirstlane(cur.tier);
-#else
-    const int tier = cur.tier;
-#endif
     const bool t_coef = kCoefHere && (tier & 2) != 0, t_staged = (tier & 1) != 0, t_whole = (tier & 4) != 0;
     const int t_edge = kEdge ? ((tier >> 6) & 7) : 0;
     const bool t_split = kSplit && (tier & 512) != 0; // the window holds passes 0-1; that of passes 2-3 is fetched behind pass 1's taps // 1, 2: beyond the first / last source row; 3, 4: column
@@ -1328,7 +1249,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
     // decided pass by pass — runs them in ONE rolled loop: the three paths exist once instead of four times (the unrolled passes
     // below then hold the staged tiers only), 27 KB less code and the registers of the staged tiers are not shared with the
     // gathers' 80 tap registers.
-    constexpr bool kRolledUnstaged = kBigWin && LRP_WIN_ROLLED_UNSTAGED != 0;
+    constexpr bool kRolledUnstaged = kBigWin;
     if constexpr (kRolledUnstaged) {
       if (!t_staged && !t_coef && t_edge == 0) {
         // (k is wave-uniform but not a constant: the coordinates are selected, not indexed — no scratch)
@@ -1339,7 +1260,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
         auto pass_y = [&](int k) { return k == 0 ? y0 : k == 1 ? y1 : k == 2 ? y2 : y3; };
         // (RGBAZ: on the spot — its taps fill the buffer to the last byte, the exchange buffer of the stores in its tail included,
         // and can only be requested once the previous pass has left; with the request in two places its kernel is 3 % slower)
-        constexpr bool kPipeline = LRP_WIN_PASS_PIPELINE != 0 && (kOutSlots == 0 || kTapSplit5);
+        constexpr bool kPipeline = kOutSlots == 0;
         PassWin w;
         int kind = 0;
         bool behind_store = true; // what this pass reads was requested behind the previous pass's store: nothing younger in flight
@@ -1400,32 +1321,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
             } else { // (the taps: a window of constant pitch — every row offset is an immediate of the read)
               const int j = lane & 3;
               const int slot0 = kTapRotate ? (256 * j + (lane & 48) + ((((lane >> 2) + j) & 3) << 2)) : (257 * j + (lane & ~3));
-              if constexpr (kTapSplit5) {
-                // RGBAZ in two steps: the 16 colour taps into registers, the depths requested into the slots they left — their round
-                // trip runs under the five colour cubics —, then the depth taps and their cubics (win_tier_raw's operations, in its order)
-                const float fx = psx - tx_, fy = psy - ty_, hfx = 0.5f * fx, hfy = 0.5f * fy;
-                const float4 *const t0 = win0 + slot0, *const t1 = t0 + 64, *const t2 = t1 + 64, *const t3 = t2 + 64;
-                Rgba q[4][4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                  q[c][0] = as_rgba(t0[c]);
-                  q[c][1] = as_rgba(t1[c]);
-                  q[c][2] = as_rgba(t2[c]);
-                  q[c][3] = as_rgba(t3[c]);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the colour taps are in registers: their slots may be overwritten
-                asm volatile("" : "+v"(q[0][0].lo), "+v"(q[3][3].hi)); // (... and the reads stay in front of the request)
-                request_taps(psx, psy, 2, 0u);
-                const Rgba k0 = cubic4(q[0][0], q[0][1], q[0][2], q[0][3], fy, hfy);
-                const Rgba k1 = cubic4(q[1][0], q[1][1], q[1][2], q[1][3], fy, hfy);
-                const Rgba k2 = cubic4(q[2][0], q[2][1], q[2][2], q[2][3], fy, hfy);
-                const Rgba k3 = cubic4(q[3][0], q[3][1], q[3][2], q[3][3], fy, hfy);
-                s = cubic4(k0, k1, k2, k3, fx, hfx);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the depths
-                s.e = win_depth_sample(reinterpret_cast<const float *>(win0) + slot0, 64, fx, fy, hfx, hfy, after_reads);
-              } else {
-                s = win_tier_raw<CH>(win0 + slot0, 64, reinterpret_cast<const float *>(win0 + 1024) + slot0, psx - tx_, psy - ty_, after_reads);
-              }
+              s = win_tier_raw<CH>(win0 + slot0, 64, reinterpret_cast<const float *>(win0 + 1024) + slot0, psx - tx_, psy - ty_, after_reads);
             }
           } else {
             after_reads(); // nothing of this pass reads the buffer
@@ -1449,21 +1345,14 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? ((
       }
     }
     if (t_edge == 1 || t_edge == 2) edge_plane(cur);
-#pragma unroll(kBigWin && CH == 5 && LRP_BIG_ROLL_STAGED == 2 ? 1 : 2)
+#pragma unroll 2
     for (int h = 0; h < 2; ++h) {
-#if !defined(LRP_SKIP_PLANES) // timing experiment (wrong results): the coefficient phase removed
       if (t_coef && (h == 0 || !t_whole)) precompute(cur, h);
-#endif
       // (the RGBAZ big-window variant keeps the two passes of a half rolled — its code shrinks 82 -> 77 KB: rect -> equirect RGBAZ +
-      // tonemap 262 -> 255 us batched; RGB / RGBA lose 0.5-1.5 % that way and stay unrolled: LRP_BIG_ROLL_STAGED)
+      // tonemap 262 -> 255 us batched; RGB / RGBA lose 0.5-1.5 % that way and stay unrolled)
       float hx0 = cur.sx[2 * h], hx1 = cur.sx[2 * h + 1], hy0 = cur.sy[2 * h], hy1 = cur.sy[2 * h + 1];
-      if constexpr (kBigWin && CH == 5 && LRP_BIG_ROLL_STAGED == 2) { // (both loops rolled: h is not a constant either)
-        float a0 = cur.sx[0], a1 = cur.sx[1], a2 = cur.sx[2], a3 = cur.sx[3], b0 = cur.sy[0], b1 = cur.sy[1], b2 = cur.sy[2], b3 = cur.sy[3];
-        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
-        hx0 = h == 0 ? a0 : a2, hx1 = h == 0 ? a1 : a3, hy0 = h == 0 ? b0 : b2, hy1 = h == 0 ? b1 : b3;
-      }
-      if constexpr (kBigWin && CH == 5 && LRP_BIG_ROLL_STAGED != 0) asm volatile("" : "+v"(hx0), "+v"(hx1), "+v"(hy0), "+v"(hy1)); // (selected, not indexed: no scratch)
-#pragma unroll(kBigWin && CH == 5 && LRP_BIG_ROLL_STAGED != 0 ? 1 : 2)
+      if constexpr (kBigWin && CH == 5) asm volatile("" : "+v"(hx0), "+v"(hx1), "+v"(hy0), "+v"(hy1)); // (selected, not indexed: no scratch)
+#pragma unroll(kBigWin && CH == 5 ? 1 : 2)
       for (int kk = 0; kk < 2; ++kk) {
         const int k = 2 * h + kk;
         if (Quad && !kSharedRays && k == 3 && last_frame && g + 1 < G) coords(g + 1, nxt); // only its box is kept

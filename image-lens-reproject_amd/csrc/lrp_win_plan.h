@@ -15,22 +15,16 @@ namespace lrp {
 #ifndef LRP_WIN_STRIP
 #define LRP_WIN_STRIP 2
 #endif
-#ifndef LRP_WIN_COEF
-#define LRP_WIN_COEF 1
-#endif
 static_assert(LRP_WIN_STRIP <= kGeoStripRows, "geometry-cache entries hold block rows in multiples of kGeoStripRows (lrp_params.h)");
-constexpr bool kWinCoef = LRP_WIN_COEF != 0; // coefficient tier (below)
+constexpr bool kWinCoef = true; // coefficient tier (below)
 constexpr int kWinCap = LRP_WIN_CAP; // float4 texels per window buffer: 10 KiB per wavefront, 40 KiB per workgroup -> 4 workgroups / CU
 #ifndef LRP_WIN_BLOCK_W
 #define LRP_WIN_BLOCK_W 16
 #endif
-#ifndef LRP_WIN_WAVES
-#define LRP_WIN_WAVES 1
-#endif
 // Wavefronts per workgroup of the window kernel.  Its wavefronts share nothing (the window is
 // wave-private), so a workgroup is ONE wavefront: each of the 16 wave slots of a CU is refilled
 // the moment its wavefront retires instead of when the slowest of four does.
-constexpr int kWinWaves = LRP_WIN_WAVES;
+constexpr int kWinWaves = 1;
 constexpr int kWinThreads = 64 * kWinWaves;
 constexpr int kBlkW = LRP_WIN_BLOCK_W;  // output block per wavefront: kBlkW x kBlkH = 256 pixels,
 constexpr int kBlkH = 256 / kBlkW;      // 4 passes of kBlkW columns x (64 / kBlkW) rows
@@ -45,38 +39,10 @@ constexpr int kPassRows = 64 / kBlkW;
 // every group.  Measured twice — round 2, and round 3 with the frames of a batch sharing the coordinate math (LDS array
 // 80 % busy with conflicts): bank-conflict cycles 151 M -> 90 M per 16-frame launch, LDS active cycles -12 %, frame time
 // unchanged (101.7 vs 101.2 us).  Off by default.
-#ifndef LRP_WIN_LANEMAP
-#define LRP_WIN_LANEMAP 0
-#endif
 __device__ __forceinline__ void win_lane_pixel(int lane, int &prow, int &pcol) {
-  static_assert(LRP_WIN_BLOCK_W == 16 || LRP_WIN_LANEMAP == 0, "the group lane map is written for 16-column passes");
-  if constexpr (LRP_WIN_LANEMAP != 0) {
-    const int m = lane & 31, seg = m >> 2;
-    prow = ((lane >> 5) << 1) | ((0x96 >> seg) & 1);
-    pcol = ((m >> 3) << 2) | (m & 3);
-  } else {
-    prow = lane / kBlkW;
-    pcol = lane & (kBlkW - 1);
-  }
+  prow = lane / kBlkW;
+  pcol = lane & (kBlkW - 1);
 }
-#ifndef LRP_WIN_CORNER
-#define LRP_WIN_CORNER 1 // blocks wholly beyond one corner of the source: one evaluation per block (0: per pixel)
-#endif
-#ifndef LRP_WIN_SPLIT
-#define LRP_WIN_SPLIT 1 // blocks whose window exceeds the buffer but whose two half-block windows fit stage those one after the other (0: per-pixel gathers)
-#endif
-#ifndef LRP_WIN_PASSWIN
-#define LRP_WIN_PASSWIN 1 // (with LRP_WIN_SPLIT) blocks whose half windows do not fit either try the window of each 16 x 4 pass
-#endif
-#ifndef LRP_OPAQUE_COL
-#define LRP_OPAQUE_COL 1 // plain blocks: the column terms are opaque to loop-invariant code motion (see coords())
-#endif
-#ifndef LRP_WIN_EDGE
-#define LRP_WIN_EDGE 1 // blocks wholly beyond one SIDE of the source (and inside it along the other axis): one source row / column staged (0: per-pixel gathers)
-#endif
-#ifndef LRP_WIN_STRIP_PLAN
-#define LRP_WIN_STRIP_PLAN 1 // mirrored strips: one reduction for the windows of all four mirror blocks (0: one per block)
-#endif
 
 
 // Source coordinates and window of one 16 x 16 block (4 pixels per lane).  Fat: the per-half plane offsets are
@@ -237,7 +203,7 @@ __device__ __forceinline__ void win_plan_block(WinBlockT<Quad> &block, const KPa
     // (the extremes are wave-uniform values in vector registers; what is derived from them and kept is made scalar)
     const int sx_side = __builtin_amdgcn_readfirstlane(side(w_lo_x, w_hi_x, L.beyond_x_bits));
     const int sy_side = __builtin_amdgcn_readfirstlane(side(w_lo_y, w_hi_y, L.beyond_y_bits));
-    if (LRP_WIN_CORNER != 0 && sx_side != 0 && sy_side != 0) b.tier = (1 + (sx_side - 1) + 2 * (sy_side - 1)) << 3;
+    if (sx_side != 0 && sy_side != 0) b.tier = (1 + (sx_side - 1) + 2 * (sy_side - 1)) << 3;
     // ... beyond one SIDE only (a rectilinear view inside a panorama: the rows above and below the view and the
     // columns left and right of it, another 37 % of the blocks): the same reasoning along one axis — all four tap
     // rows (columns) are the first or the last source row (column), the weight of that axis is 0 or 1 — and the

@@ -72,7 +72,6 @@ __device__ __forceinline__ Rgba win_tier_coef(const float4 *tb, const float4 *ci
   // the only reads of the raw window: the second tap row
   const Rgba b0 = as_rgba(tb[0]), b1 = as_rgba(tb[1]), b2 = as_rgba(tb[2]), b3 = as_rgba(tb[3]);
   if constexpr (CH != 5) after_reads();
-#if LRP_VERT_STEPS
   // The four vertical evaluations step by step across the eight channel-pair chains instead of chain by chain: a step's
   // eight instructions are independent and the next step's operands are eight instructions old, so a wavefront never waits
   // on its own previous instruction (chain by chain, the compiler's order, every other instruction depends on its
@@ -120,20 +119,6 @@ __device__ __forceinline__ Rgba win_tier_coef(const float4 *tb, const float4 *ci
   }
   __builtin_amdgcn_sched_barrier(0);
   const Rgba k0 = kk[0], k1 = kk[1], k2 = kk[2], k3 = kk[3];
-#else
-  auto vert = [&](int j, const Rgba bj) {
-#if defined(LRP_SKIP_TAP_READS) // timing experiment (wrong results): no LDS reads of the planes
-    const Rgba inner{f2{fx, fy} * (float)j, f2{hfx, fy}, 0.0f}, m0{f2{fy, fx} + (float)j, f2{fx, hfy}, 0.0f}, cma{f2{hfx, hfy}, f2{fy, fx} - (float)j, 0.0f};
-#else
-    const Rgba inner = as_rgba(ci[j]), m0 = as_rgba(cm[j]), cma = as_rgba(cc[j]);
-#endif
-    Rgba r = px_zero<4>();
-    r.lo = bj.lo + hfy * (cma.lo + fy * (m0.lo + fy * inner.lo));
-    r.hi = bj.hi + hfy * (cma.hi + fy * (m0.hi + fy * inner.hi));
-    return r;
-  };
-  const Rgba k0 = vert(0, b0), k1 = vert(1, b1), k2 = vert(2, b2), k3 = vert(3, b3);
-#endif
   Rgba s = cubic4(k0, k1, k2, k3, fx, hfx);
   if constexpr (CH == 5) s.e = win_depth_sample(depth, pitch, fx, fy, hfx, hfy, after_reads);
   return s;
