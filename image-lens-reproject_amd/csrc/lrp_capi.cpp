@@ -32,9 +32,8 @@ hipError_t launch_tile_nearest(const KParams &P, int out_idx, int in_mode, hipSt
 hipError_t launch_tile_bilinear(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
 hipError_t launch_tile_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
 hipError_t launch_win_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // (P.geo_mode == 2: the GeoRead kernels)
-hipError_t launch_geo_build_lists(int32_t *box, int out_w, int out_h, int in_w, int in_h, int alias_pairs, hipStream_t stream); // lrp_geo_lists.hip
+hipError_t launch_geo_build_lists(int32_t *box, int out_w, int out_h, int alias_pairs, hipStream_t stream); // lrp_geo_lists.hip
 hipError_t launch_geo_census(int32_t *box, int out_w, int out_h, int in_w, int in_h, bool clear_header, hipStream_t stream); // lrp_geo_lists.hip
-hipError_t launch_pair_kernel(const KParams &P, hipStream_t stream); // lrp_tile_pair.hip
 hipError_t launch_corner_fill(const KParams &P, hipStream_t stream);
 hipError_t launch_post_process(float *data, uint32_t n_pixels, int channels, float exposure, float reinhard,
                                hipStream_t stream);
@@ -180,14 +179,12 @@ lrp::KParams make_params(const lrp_image *in, const lrp_image *out, int num_samp
 }
 
 // Kernel selection and the A/B switches of the sharing / staging paths.  All of them live in one table of atomics that
-// lrp_debug_set() reads and writes; the environment (LRP_KERNEL=pixel|tile|window-raw, LRP_XSEP, LRP_QUAD,
-// LRP_MIRROR_MODES, LRP_WIN_EDGE, LRP_WIN_SPLIT, LRP_BATCH_FRAMES, LRP_MULTI_FORK, LRP_GEO_CACHE) only supplies the
-// initial values, once, when the library is loaded — nothing on a launch path calls getenv.
+// lrp_debug_set() reads and writes (tests, tools/policy_check.py); the library reads no environment variable.
 //   kernel: 0 = pixel kernel, 1 = tile kernel everywhere, 2 (default) = tile kernel with the LDS-window kernel for
 //   bicubic, 3 = the same without its shared-coefficient tier and without any work sharing.  All HIP; there is no CPU path.
-enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobGeoBig, kKnobGeoLists, kKnobGeoFillStream, kKnobGeoFillFused, kKnobGeoPairs, kKnobMultiMerge, kKnobContextStreams, kKnobWinTapDma, kKnobGeoCensus, kKnobGeoListRecs, kKnobWinSS, kKnobListedLaunches, kKnobMergedLaunches, kKnobPairLaunches, kKnobBigLaunches, kKnobCount };
+enum DebugKnob : int { kKnobKernel = 0, kKnobXsep, kKnobQuad, kKnobMirrorModes, kKnobWinEdge, kKnobWinSplit, kKnobBatchFrames, kKnobMultiFork, kKnobGeoCache, kKnobGeoStrip, kKnobGeoBig, kKnobGeoLists, kKnobGeoFillStream, kKnobGeoFillFused, kKnobContextStreams, kKnobWinTapDma, kKnobGeoCensus, kKnobGeoListRecs, kKnobWinSS, kKnobListedLaunches, kKnobBigLaunches, kKnobCount };
 struct KnobSpec {
-  const char *name, *env;
+  const char *name;
   int lo, hi, initial;
 };
 constexpr int kMaxSideStreams = 5;
@@ -199,44 +196,31 @@ constexpr unsigned kListedCornerPercent = 30;
 constexpr unsigned kBigWidePercent = 30; // in-view blocks no 10 KiB window stages, per cent: from there on the big-window variant renders a panorama source
 constexpr unsigned kMinWavesForFusedFill = 2048; // wavefronts a listed window launch must have to carry the corner runs itself
 const KnobSpec kKnobs[kKnobCount] = {
-    {"kernel", "LRP_KERNEL", 0, 3, 2},
-    {"xsep", "LRP_XSEP", 0, 1, 1},                  // column-separable source x tables
-    {"quad", "LRP_QUAD", 0, 1, 1},                  // mirrored pixels / blocks (every mirror mode)
-    {"mirror_modes", "LRP_MIRROR_MODES", 0, 1, 1},  // window kernel: pan / pitch / shared-ray mirror modes
-    {"win_edge", "LRP_WIN_EDGE", 0, 1, 1},          // window kernel: blocks beyond one side of the source stage one row / column
-    {"win_split", "LRP_WIN_SPLIT", 0, 1, 1},        // window kernel: split blocks and pass windows
-    {"batch_frames", "LRP_BATCH_FRAMES", 0, lrp::kMaxBatch, 0}, // frames per wavefront of a batched launch (0: automatic)
-    {"multi_fork", "LRP_MULTI_FORK", 0, kMaxSideStreams, 1},    // side streams of lrp_reproject_multi_device
-    {"geo_cache", "LRP_GEO_CACHE", 0, 1, 1},        // geometry cache used by single launches (0: every launch computes)
-    {"geo_strip", "LRP_GEO_STRIP", 0, lrp::kGeoStripRows, 0}, // blocks per wavefront of a launch that reads the geometry cache (0: automatic)
-    {"geo_big", "LRP_GEO_BIG", 0, 2, 1},            // big-window variant of the kernels that read the geometry cache (a rectilinear view rendered into a panorama); 0: the four-wavefront instantiation
-    {"geo_lists", "LRP_GEO_LISTS", 0, 2, 1},        // rendering by block class from the lists of a geometry-cache entry (corner runs by the fill kernel / a share per wavefront, the window kernel over the work list): 0 never, 1 where at least 30 % of the blocks are corner blocks, 2 whenever the lists are known
-    {"geo_fill_stream", "LRP_GEO_FILL_STREAM", 0, 1, 0}, // the fill kernel of a listed launch: 0 in front of the window kernel on the caller's stream, 1 beside it on a side stream of the device
-    {"geo_fill_fused", "LRP_GEO_FILL_FUSED", 0, 1, 1}, // the corner runs of a listed launch as a share per wavefront of the window kernel (0: always the fill kernel)
-    {"geo_pairs", "LRP_GEO_PAIRS", 0, 1, 0},        // listed launches: 1 = alias pairs of in-view blocks by the pair kernel, two wavefronts per window (default 0: measured level for RGBAZ and 12-17 % slower for RGB / RGBA on BASELINE configs[3], profiles/r05_experiments_ab.txt item 8)
-    {"multi_merge", "LRP_MULTI_MERGE", 0, 1, 0},     // lrp_reproject_multi_device: 1 = the outputs whose geometry-cache entries exist in ONE launch; default 0, a launch per output over the caller's stream and a side stream (measured level: 360-365 against 359-363 us per 8192^2 -> six 2048^2 cubemap)
-    {"context_streams", "LRP_CONTEXT_STREAMS", 0, 1, 1}, // lrp_context: consecutive images alternate between two compute streams (0: one)
-    {"win_tapdma", "LRP_WIN_TAPDMA", 0, 1, 1},      // window kernel: passes whose window fits no buffer fetch their taps a quad of lanes per pixel row through LDS-DMA (0: a gather per lane and tap)
-    {"geo_census", "LRP_GEO_CENSUS", 0, 1, 1},      // the census of a new geometry-cache entry's windows (lrp_geo_lists.hip; what the automatic choice of the big-window variant reads); 0: not taken
-    {"geo_list_recs", "LRP_GEO_LIST_RECS", 0, 1, 1}, // listed launches: a wavefront reads its block's box record from beside its work-list entry, with the entry (0: from the box array, a second round trip)
-    {"win_ss", "LRP_WIN_SS", 0, 1, 1},              // bicubic with num_samples == 2 through the window kernel's supersampling instantiations (0: the tile kernel, as for any other num_samples > 1)
-    {"listed_launches", "LRP_LISTED_LAUNCHES_UNUSED", 0, 0, 0}, // a counter, not a switch: launches rendered by block class so far (set 0 to reset; tests, bench)
-    {"merged_launches", "LRP_MERGED_LAUNCHES_UNUSED", 0, 0, 0}, // a counter: multi-output launches so far
-    {"pair_launches", "LRP_PAIR_LAUNCHES_UNUSED", 0, 0, 0},     // a counter: launches of the pair kernel so far
-    {"big_launches", "LRP_BIG_LAUNCHES_UNUSED", 0, 0, 0},       // a counter: window launches through the big-window variant so far
+    {"kernel", 0, 3, 2},
+    {"xsep", 0, 1, 1},                  // column-separable source x tables
+    {"quad", 0, 1, 1},                  // mirrored pixels / blocks (every mirror mode)
+    {"mirror_modes", 0, 1, 1},  // window kernel: pan / pitch / shared-ray mirror modes
+    {"win_edge", 0, 1, 1},          // window kernel: blocks beyond one side of the source stage one row / column
+    {"win_split", 0, 1, 1},        // window kernel: split blocks and pass windows
+    {"batch_frames", 0, lrp::kMaxBatch, 0}, // frames per wavefront of a batched launch (0: automatic)
+    {"multi_fork", 0, kMaxSideStreams, 1},    // side streams of lrp_reproject_multi_device
+    {"geo_cache", 0, 1, 1},        // geometry cache used by single launches (0: every launch computes)
+    {"geo_strip", 0, lrp::kGeoStripRows, 0}, // blocks per wavefront of a launch that reads the geometry cache (0: automatic)
+    {"geo_big", 0, 2, 1},            // big-window variant of the kernels that read the geometry cache (a rectilinear view rendered into a panorama); 0: the four-wavefront instantiation
+    {"geo_lists", 0, 2, 1},        // rendering by block class from the lists of a geometry-cache entry (corner runs by the fill kernel / a share per wavefront, the window kernel over the work list): 0 never, 1 where at least 30 % of the blocks are corner blocks, 2 whenever the lists are known
+    {"geo_fill_stream", 0, 1, 0}, // the fill kernel of a listed launch: 0 in front of the window kernel on the caller's stream, 1 beside it on a side stream of the device
+    {"geo_fill_fused", 0, 1, 1}, // the corner runs of a listed launch as a share per wavefront of the window kernel (0: always the fill kernel)
+    {"context_streams", 0, 1, 1}, // lrp_context: consecutive images alternate between two compute streams (0: one)
+    {"win_tapdma", 0, 1, 1},      // window kernel: passes whose window fits no buffer fetch their taps a quad of lanes per pixel row through LDS-DMA (0: a gather per lane and tap)
+    {"geo_census", 0, 1, 1},      // the census of a new geometry-cache entry's windows (lrp_geo_lists.hip; what the automatic choice of the big-window variant reads); 0: not taken
+    {"geo_list_recs", 0, 1, 1}, // listed launches: a wavefront reads its block's box record from beside its work-list entry, with the entry (0: from the box array, a second round trip)
+    {"win_ss", 0, 1, 1},              // bicubic with num_samples == 2 through the window kernel's supersampling instantiations (0: the tile kernel, as for any other num_samples > 1)
+    {"listed_launches", 0, 0, 0}, // a counter, not a switch: launches rendered by block class so far (set 0 to reset; tests, bench)
+    {"big_launches", 0, 0, 0},       // a counter: window launches through the big-window variant so far
 };
 std::atomic<int> g_knobs[kKnobCount];
-const bool g_knobs_initialised = [] { // the one place that reads the environment
-  for (int k = 0; k < kKnobCount; ++k) {
-    int v = kKnobs[k].initial;
-    if (const char *e = std::getenv(kKnobs[k].env)) {
-      if (k == kKnobKernel)
-        v = std::strcmp(e, "pixel") == 0 ? 0 : std::strcmp(e, "tile") == 0 ? 1 : std::strcmp(e, "window-raw") == 0 ? 3 : 2;
-      else if (*e)
-        v = std::min(kKnobs[k].hi, std::max(kKnobs[k].lo, std::atoi(e)));
-    }
-    g_knobs[k].store(v, std::memory_order_relaxed);
-  }
+const bool g_knobs_initialised = [] {
+  for (int k = 0; k < kKnobCount; ++k) g_knobs[k].store(kKnobs[k].initial, std::memory_order_relaxed);
   return true;
 }();
 int knob(int k) { return g_knobs[k].load(std::memory_order_relaxed); }
@@ -301,18 +285,9 @@ hipError_t fill_corner_runs(const lrp::KParams &P, int device, hipStream_t strea
 // row_count > 0: only output rows [row_first, row_first + row_count) are rendered (the rows of the reference
 // loop are independent, src/reproject.cpp:284); the kernels that share work between mirrored rows need the
 // whole image and are not used for a band.
-// merge != null (lrp_reproject_multi_device): when this output would be rendered by a window launch that READS a
-// geometry-cache entry, nothing is launched: the launch is described in *merge and the caller renders several such outputs
-// of one source with ONE launch (lrp_params.h face_n).  Anything else is launched as usual and merge->ready stays false.
-struct MergeCandidate {
-  bool ready = false;
-  lrp::KParams P;
-  lrp::GeoKey key;
-  int out_idx = 0, in_mode = 0;
-};
 int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int interpolation,
                       const float *rotation, const lrp_post *post, int device, hipStream_t stream, int n_batch = 0,
-                      int row_first = 0, int row_count = 0, MergeCandidate *merge = nullptr) {
+                      int row_first = 0, int row_count = 0) {
   if (num_samples <= 0) return LRP_OK; // reference loop body never runs: output untouched
   lrp::KParams P = make_params(in, out, num_samples, rotation, post);
   const bool band = row_count > 0 && !(row_first == 0 && row_count == out->height);
@@ -336,9 +311,9 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
     bool plain = false;
     e = lrp::get_output_tables(device, out_kind, P.out_lens, out->width, out->height, num_samples, stream, lease,
                                &P.col_tab, &P.row_tab, &plain, &symmetry);
-    if (e == hipErrorOutOfMemory) { // the geometry cache holds what it holds for speed only: give it back, once
+    if (e == hipErrorOutOfMemory) { // the geometry cache of THIS GPU holds what it holds for speed only: give it back, once
       (void)hipGetLastError();
-      lrp::geo_release_all();
+      lrp::geo_release_device(device);
       e = lrp::get_output_tables(device, out_kind, P.out_lens, out->width, out->height, num_samples, stream, lease,
                                  &P.col_tab, &P.row_tab, &plain, &symmetry);
     }
@@ -444,15 +419,6 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
       key.has_rot = P.has_rot;
       key.out_lens = lrp::geo_canonical_lens(P.out_lens, out->lens.type), key.in_lens = lrp::geo_canonical_lens(P.in_lens, in->lens.type);
       if (P.has_rot) std::memcpy(key.rot, P.rot, sizeof(key.rot));
-      if (merge != nullptr && window1 && n_batch <= 0 && knob(kKnobMultiMerge) != 0 && lrp::geo_peek(key, true)) {
-        merge->ready = true;
-        merge->P = P;
-        merge->P.col_tab = merge->P.row_tab = merge->P.xsep_tab = nullptr; // (the kernels that read the cache use no table; the lease ends here)
-        merge->key = key;
-        merge->out_idx = oi;
-        merge->in_mode = im;
-        return LRP_OK;
-      }
       lrp::geo_acquire(key, window1, stream, &geo);
       if (geo.mode != 0) {
         P.geo_mode = geo.mode;
@@ -482,16 +448,8 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
           P.geo_n_work = geo.n_work;
           P.geo_n_runs = geo.n_runs;
           P.geo_work_rec = knob(kKnobGeoListRecs) != 0 ? reinterpret_cast<const int32_t *>(lists + lrp::geo_work_recs_offset(out->width, out->height)) : nullptr;
-          if (knob(kKnobGeoPairs) != 0 && geo.n_pairs != 0) { // alias pairs of in-view blocks: the pair kernel (lrp_pair_kernel.h) ...
-            P.geo_pairs = reinterpret_cast<const int32_t *>(P.geo_runs + 4 * lrp::geo_run_capacity(out->width, out->height));
-            P.geo_n_pairs = geo.n_pairs;
-            P.geo_work = P.geo_pairs + 2 * lrp::geo_pair_capacity(out->width, out->height); // ... and the window kernel over the rest
-            P.geo_n_work = geo.n_rest;
-            P.geo_work_rec = nullptr; // (the records lie beside the work list's entries, not the rest list's)
-          }
           // the corner runs: a share per wavefront of the window launch where it has enough wavefronts to spread them over,
           // else (few or no blocks to render: the frame is nearly all corners) the fill kernel at its own, full occupancy
-          // (P.geo_n_work: the wavefronts of THIS window launch — the rest list when the pair kernel takes the pairs)
           if (knob(kKnobGeoFillFused) != 0 && P.geo_n_work >= kMinWavesForFusedFill && geo.n_runs != 0) {
             // every stride-th wavefront (odd stride: all XCDs) writes at least one whole run (16 row segments)
             const unsigned long long segs = (unsigned long long)geo.n_runs * 16u;
@@ -511,11 +469,6 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
         if (P.geo_fill_per_wave == 0) {
           const hipError_t fe = fill_corner_runs(P, device, stream);
           if (fe != hipSuccess) return fe;
-        }
-        if (P.geo_n_pairs != 0) {
-          const hipError_t pe = lrp::launch_pair_kernel(P, stream);
-          if (pe != hipSuccess) return pe;
-          g_knobs[kKnobPairLaunches].fetch_add(1, std::memory_order_relaxed);
         }
       }
       if (window && P.geo_mode == 2 && P.big_windows != 0) g_knobs[kKnobBigLaunches].fetch_add(1, std::memory_order_relaxed);
@@ -555,7 +508,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
       const bool with_lists = im == lrp::kInRect && knob(kKnobGeoLists) != 0, with_census = knob(kKnobGeoCensus) != 0 && im != lrp::kInEquidistant;
       if (!with_lists && !with_census) {
         // (nothing to tell the host about this entry)
-      } else if ((!with_lists || lrp::launch_geo_build_lists(geo.box, out->width, out->height, in->width, in->height, P.alias_pairs, stream) == hipSuccess) &&
+      } else if ((!with_lists || lrp::launch_geo_build_lists(geo.box, out->width, out->height, P.alias_pairs, stream) == hipSuccess) &&
           (!with_census || lrp::launch_geo_census(geo.box, out->width, out->height, in->width, in->height, !with_lists, stream) == hipSuccess) &&
           hipMemcpyAsync(geo.host_counts, header, (size_t)lrp::kGeoListHeaderWords * 4, hipMemcpyDeviceToHost, stream) == hipSuccess)
         geo.lists_enqueued = true;
@@ -597,9 +550,10 @@ struct Buffer {
     if (bytes <= cap) return LRP_OK;
     release();
     hipError_t e = pinned_host ? hipHostMalloc(&ptr, bytes, hipHostMallocDefault) : hipMalloc(&ptr, bytes);
-    if (e == hipErrorOutOfMemory && !pinned_host) { // the geometry cache holds what it holds for speed only: give it back, once
+    if (e == hipErrorOutOfMemory && !pinned_host) { // the geometry cache of THIS GPU holds what it holds for speed only: give it back, once
       (void)hipGetLastError();
-      lrp::geo_release_all();
+      int dev = -1;
+      if (hipGetDevice(&dev) == hipSuccess) lrp::geo_release_device(dev); // (the allocation is on the calling thread's current device)
       e = hipMalloc(&ptr, bytes);
     }
     if (e != hipSuccess) {
@@ -766,52 +720,6 @@ MultiFork *multi_fork(int device) { // null if the streams / events cannot be cr
 // 0 keeps every launch on the caller's stream; default 1 — measured best, 588 -> 509 us per 8192^2 -> 6 x 2048^2 cubemap; 2-3: 522, 5: 549).
 int multi_fork_lanes() { return knob(kKnobMultiFork); }
 
-// One launch for the outputs group[0 .. n_group) of `in` (all described by enqueue_reproject as reading launches of one
-// shape).  An output whose entry has gone or changed hands in the meantime is rendered by a launch of its own.
-int enqueue_merged_outputs(const std::vector<MergeCandidate> &cand, lrp_image *outs, const int *group, int n_group, const lrp_image *in,
-                           int num_samples, int interpolation, const float *rotations, const lrp_post *post, int device, hipStream_t stream) {
-  lrp::KParams P = cand[(size_t)group[0]].P;
-  const int oi = cand[(size_t)group[0]].out_idx, im = cand[(size_t)group[0]].in_mode;
-  lrp::GeoUse uses[lrp::kMaxFaces];
-  int merged[lrp::kMaxFaces], n_merged = 0, result = LRP_OK;
-  for (int k = 0; k < n_group && result == LRP_OK; ++k) {
-    const int i = group[k];
-    lrp::GeoUse use;
-    lrp::geo_acquire(cand[(size_t)i].key, true, stream, &use);
-    if (use.mode == 2) {
-      uses[n_merged] = use;
-      merged[n_merged++] = i;
-      continue;
-    }
-    lrp::geo_launched(&use, stream, false); // (a claim this path will not honour: given up) ...
-    result = enqueue_reproject(in, &outs[i], num_samples, interpolation, rotations ? rotations + 9 * i : nullptr, post, device, stream); // ... the usual way
-  }
-  if (n_merged == 0) return result;
-  hipError_t e = hipSuccess;
-  if (result == LRP_OK) {
-    P.geo_mode = 2;
-    P.win_mode = 0;
-    P.quad = 0;
-    P.alias_pairs = 0; // (per-geometry: the faces differ in their rotations)
-    P.blocks_per_wave = knob(kKnobGeoStrip);
-    P.rgbaz_runs = (outs[merged[0]].lens.type == LRP_EQUIRECTANGULAR && in->lens.type == LRP_RECTILINEAR) ? 1 : 0;
-    P.big_windows = knob(kKnobGeoBig) == 2 ? 1 : knob(kKnobGeoBig) != 0 ? P.rgbaz_runs : 0; // (2: wherever the variant is instantiated — experiments)
-    P.face_n = n_merged;
-    for (int k = 0; k < n_merged; ++k) {
-      P.face_dst[k] = outs[merged[k]].data;
-      P.face_xy[k] = uses[k].xy;
-      P.face_box[k] = uses[k].box;
-    }
-    P.dst = P.face_dst[0];
-    P.geo_xy = P.face_xy[0];
-    P.geo_box = P.face_box[0];
-    e = lrp::launch_win_bicubic(P, oi, im, stream);
-    if (e == hipSuccess) g_knobs[kKnobMergedLaunches].fetch_add(1, std::memory_order_relaxed);
-  }
-  for (int k = 0; k < n_merged; ++k) lrp::geo_launched(&uses[k], stream, e == hipSuccess && result == LRP_OK);
-  if (e != hipSuccess && result == LRP_OK) result = hip_fail(e, "multi-output reproject kernel launch");
-  return result;
-}
 } // namespace
 
 int lrp_reproject_multi_device(const lrp_image *in, lrp_image *outs, int n_out, int num_samples,
@@ -834,61 +742,25 @@ int lrp_reproject_multi_device(const lrp_image *in, lrp_image *outs, int n_out, 
   int n_lanes = 1;
   lanes[0] = (hipStream_t)stream;
   const int want_side = std::min(multi_fork_lanes(), n_out - 1);
-  // The fork point is recorded now; the side streams are made to wait for it only when a launch is about to go to one
-  // (ensure_fork below): a call whose outputs all merge into one launch never pays for a fork and a join.
-  bool fork_recorded = false, forked = false;
+  bool forked = false;
   if (want_side > 0) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) (void)hipGetLastError();
     if (cap == hipStreamCaptureStatusNone && (fork = multi_fork(device)) != nullptr) {
       fork_lock = std::unique_lock<std::mutex>(fork->busy);
-      fork_recorded = hipEventRecord(fork->forked, (hipStream_t)stream) == hipSuccess;
-      if (!fork_recorded) {
+      bool ok = hipEventRecord(fork->forked, (hipStream_t)stream) == hipSuccess;
+      for (int k = 0; k < want_side && ok; ++k) ok = hipStreamWaitEvent(fork->side[k], fork->forked, 0) == hipSuccess;
+      if (ok) {
+        for (int k = 0; k < want_side; ++k) lanes[n_lanes++] = fork->side[k];
+        forked = true;
+      } else { // (side streams that already wait on the event just wait for the caller's earlier work: harmless)
         (void)hipGetLastError();
-        fork = nullptr;
       }
     }
   }
-  auto ensure_fork = [&]() { // true: lanes[1 ..] are usable
-    if (forked) return true;
-    if (!fork_recorded || fork == nullptr) return false;
-    bool ok = true;
-    for (int k = 0; k < want_side && ok; ++k) ok = hipStreamWaitEvent(fork->side[k], fork->forked, 0) == hipSuccess;
-    if (ok) {
-      for (int k = 0; k < want_side; ++k) lanes[n_lanes++] = fork->side[k];
-      forked = true;
-    } else { // side streams that already wait on the event just wait for the caller's earlier work: harmless
-      (void)hipGetLastError();
-      fork_recorded = false;
-    }
-    return forked;
-  };
   int result = LRP_OK;
-  // Outputs whose geometry-cache entries exist (every call of a run but the first: the faces of a cubemap keep their
-  // rotations) are not launched one by one: groups of up to kMaxFaces outputs of one shape go out as ONE launch on the
-  // caller's stream.  The others — first sightings, other samplers — are launched as before, dealt over the lanes.
-  std::vector<MergeCandidate> cand((size_t)n_out);
-  int lane_next = 0;
-  for (int i = 0; i < n_out && result == LRP_OK; ++i) {
-    if (lane_next > 0) (void)ensure_fork(); // (the first launch goes to the caller's stream)
-    result = enqueue_reproject(in, &outs[i], num_samples, interpolation, rotations ? rotations + 9 * i : nullptr, post, device,
-                               lanes[lane_next % n_lanes], 0, 0, 0, n_out > 1 ? &cand[(size_t)i] : nullptr);
-    if (!cand[(size_t)i].ready) ++lane_next;
-  }
-  std::vector<char> done((size_t)n_out, 0);
-  for (int i = 0; i < n_out && result == LRP_OK; ++i) {
-    if (!cand[(size_t)i].ready || done[(size_t)i]) continue;
-    int group[lrp::kMaxFaces], n_group = 0;
-    for (int j = i; j < n_out && n_group < lrp::kMaxFaces; ++j) {
-      const MergeCandidate &a = cand[(size_t)i], &b = cand[(size_t)j];
-      if (!b.ready || done[(size_t)j]) continue;
-      const bool same_shape = a.out_idx == b.out_idx && a.in_mode == b.in_mode && a.P.out_w == b.P.out_w && a.P.out_h == b.P.out_h &&
-                              a.P.channels == b.P.channels && std::memcmp(&a.P.out_lens, &b.P.out_lens, sizeof(a.P.out_lens)) == 0;
-      if (same_shape) group[n_group++] = j;
-    }
-    result = enqueue_merged_outputs(cand, outs, group, n_group, in, num_samples, interpolation, rotations, post, device, (hipStream_t)stream);
-    for (int k = 0; k < n_group; ++k) done[(size_t)group[k]] = 1;
-  }
+  for (int i = 0; i < n_out && result == LRP_OK; ++i)
+    result = enqueue_reproject(in, &outs[i], num_samples, interpolation, rotations ? rotations + 9 * i : nullptr, post, device, lanes[i % n_lanes]);
   if (fork != nullptr && forked) // join, whatever happened: the caller's stream continues behind the side streams
     for (int k = 0; k + 1 < n_lanes; ++k)
       if (hipEventRecord(fork->joined[k], fork->side[k]) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, fork->joined[k], 0) != hipSuccess) {

@@ -50,26 +50,19 @@ __device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t v, uint32_t *s_wa
 // front of and behind the camera.  The sub-list is that sequence with the corner blocks removed, stored at 8 * position + k.
 // Workgroup 8: the corner runs, rows of blocks top to bottom, groups of kGeoRunBlocks columns left to right.
 __global__ __launch_bounds__(kListThreads) void geo_build_lists_kernel(const uint8_t *classes, uint32_t class_rows, const int32_t *box, int blocks_x,
-                                                                       int blocks_y, int alias_pairs, int in_w, int in_h, uint32_t *header,
-                                                                       int32_t *work, uint32_t *runs, int32_t *pairs, int32_t *rest, int32_t *recs) {
+                                                                       int blocks_y, int alias_pairs, uint32_t *header,
+                                                                       int32_t *work, uint32_t *runs, int32_t *recs) {
   __shared__ uint32_t s_wave[kListWaves];
   const int k = (int)blockIdx.x;
   const bool alias = alias_pairs != 0 && (blocks_x & 1) == 0;
   if (k < kXcds) {
     const int rows_k = blocks_y > k ? (blocks_y - k + kXcds - 1) / kXcds : 0;
     const uint32_t n_items = (uint32_t)rows_k * (uint32_t)blocks_x;
-    // every tap of every pixel of the block unclamped and exact: the test of win_plan_block (lrp_win_plan.h in_x && in_y) on the
-    // block's box record — flags bit 0 / 1 exact in x / y, bit 2 planned; words 0-5 the extremes as float bits
-    const int one = (int)f2u(1.0f), x_hi = (int)f2u((float)(in_w - 2)), y_hi = (int)f2u((float)(in_h - 2));
-    auto in_view = [&](int tx, int ty) {
-      const int32_t *const r = box + ((size_t)ty * (size_t)blocks_x + (size_t)tx) * 8;
-      return (r[6] & 7) == 7 && r[0] >= one && r[1] < x_hi && min(r[2], r[4]) >= one && max(r[3], r[5]) < y_hi;
-    };
-    uint32_t base = 0, pair_base = 0, rest_base = 0;
+    uint32_t base = 0;
     for (uint32_t i0 = 0; i0 < n_items; i0 += kListThreads) {
       const uint32_t j = i0 + threadIdx.x;
       int tx = 0, ty = 0;
-      bool listed = false, whole = false;
+      bool listed = false;
       if (j < n_items) {
         const int row = (int)(j / (uint32_t)blocks_x);
         tx = (int)(j - (uint32_t)row * (uint32_t)blocks_x);
@@ -80,12 +73,7 @@ __global__ __launch_bounds__(kListThreads) void geo_build_lists_kernel(const uin
           ty = rev ? blocks_y - 1 - ty : ty;
         }
         listed = classes[(size_t)tx * class_rows + (uint32_t)ty] == 0;
-        whole = alias && listed && in_view(tx, ty);
       }
-      // items j (even: the block in front of the camera) and j + 1 (its partner) are neighbouring lanes (blocks_x is even,
-      // hence so are n_items and every i0): a pair when both lie in view whole
-      const bool partner_whole = __shfl_xor((int)whole, 1) != 0;
-      const bool paired = whole && partner_whole;
       uint32_t total;
       const uint32_t pos = base + wg_exclusive_scan(listed ? 1u : 0u, s_wave, &total);
       if (listed) {
@@ -98,28 +86,8 @@ __global__ __launch_bounds__(kListThreads) void geo_build_lists_kernel(const uin
         o[1] = r[1];
       }
       base += total;
-      const bool front = paired && (j & 1u) == 0;
-      uint32_t pair_total;
-      const uint32_t pair_pos = pair_base + wg_exclusive_scan(front ? 1u : 0u, s_wave, &pair_total);
-      if (front) {
-        pairs[2 * ((size_t)pair_pos * kXcds + k)] = tx;
-        pairs[2 * ((size_t)pair_pos * kXcds + k) + 1] = ty;
-      }
-      pair_base += pair_total;
-      const bool resting = listed && !paired;
-      uint32_t rest_total;
-      const uint32_t rest_pos = rest_base + wg_exclusive_scan(resting ? 1u : 0u, s_wave, &rest_total);
-      if (resting) {
-        rest[2 * ((size_t)rest_pos * kXcds + k)] = tx;
-        rest[2 * ((size_t)rest_pos * kXcds + k) + 1] = ty;
-      }
-      rest_base += rest_total;
     }
-    if (threadIdx.x == 0) {
-      atomicMax(&header[0], base * kXcds); // entries of the interleaved list: 8 x the longest sub-list
-      atomicMax(&header[4], pair_base * kXcds);
-      atomicMax(&header[5], rest_base * kXcds);
-    }
+    if (threadIdx.x == 0) atomicMax(&header[0], base * kXcds); // entries of the interleaved list: 8 x the longest sub-list
     return;
   }
   const int groups = (blocks_x + kGeoRunBlocks - 1) / kGeoRunBlocks;
@@ -226,23 +194,18 @@ hipError_t launch_geo_census(int32_t *box, int out_w, int out_h, int in_w, int i
 }
 
 // Behind the launch that wrote the class bytes of an entry, on its stream.  `box` = the entry's first box record.
-hipError_t launch_geo_build_lists(int32_t *box, int out_w, int out_h, int in_w, int in_h, int alias_pairs, hipStream_t stream) {
+hipError_t launch_geo_build_lists(int32_t *box, int out_w, int out_h, int alias_pairs, hipStream_t stream) {
   uint8_t *const base = reinterpret_cast<uint8_t *>(box);
   uint32_t *const header = reinterpret_cast<uint32_t *>(base + geo_lists_offset(out_w, out_h));
   int32_t *const work = reinterpret_cast<int32_t *>(header + kGeoListHeaderWords);
   uint32_t *const runs = reinterpret_cast<uint32_t *>(work + 2 * geo_work_capacity(out_w, out_h));
-  int32_t *const pairs = reinterpret_cast<int32_t *>(runs + 4 * geo_run_capacity(out_w, out_h));
-  int32_t *const rest = pairs + 2 * geo_pair_capacity(out_w, out_h);
   int32_t *const recs = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(header) + geo_work_recs_offset(out_w, out_h));
   hipError_t e = hipMemsetAsync(header, 0, (size_t)kGeoListHeaderWords * 4, stream);
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(work, 0xFF, geo_work_capacity(out_w, out_h) * 8, stream); // (-1, -1): nothing here
   if (e != hipSuccess) return e;
-  e = hipMemsetAsync(pairs, 0xFF, (geo_pair_capacity(out_w, out_h) + geo_work_capacity(out_w, out_h)) * 8, stream); // (pairs, rest)
-  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(geo_build_lists_kernel, dim3(kXcds + 1), dim3(kListThreads), 0, stream, base + geo_class_offset(out_w, out_h),
-                     geo_block_rows(out_h), box, (int)geo_block_cols(out_w), (int)geo_image_block_rows(out_h), alias_pairs, in_w, in_h, header, work, runs,
-                     pairs, rest, recs);
+                     geo_block_rows(out_h), box, (int)geo_block_cols(out_w), (int)geo_image_block_rows(out_h), alias_pairs, header, work, runs, recs);
   return hipGetLastError();
 }
 

@@ -17,9 +17,12 @@
 // entry leaves a MARK — an event recorded behind it on its stream, one per (entry, stream), re-recorded by the next launch
 // of that stream.  An evicted buffer keeps its marks: the stream of the next writer that takes the buffer over waits for
 // them on the device (hipStreamWaitEvent), whatever streams they were recorded on, and a buffer nobody takes over is
-// returned to the driver only after its marks have completed — by the thread that makes room for a new geometry, outside
-// the lock (hipFree synchronises the device by itself).  Nothing on the launch path synchronises a device, and no
-// decision depends on the identity of a stream handle.
+// returned to the driver only after its marks have completed — by the thread that makes room for a NEW geometry, outside
+// the lock.  That hipFree is the one call of a launch path that may stall the other streams of its GPU (the runtime
+// synchronises the device for it), and it only happens when a new geometry arrives while the cache is over its cap AND no
+// retired buffer fits: geometries of one size rotating through a full cache take buffers over and never free; hits never
+// free.  Nothing else on the launch path synchronises a device, and no decision depends on the identity of a stream handle.
+// Retired buffers count towards geo_stats().bytes until they have gone back to the driver.
 #include "lrp_geocache.h"
 
 #include <algorithm>
@@ -266,7 +269,7 @@ void geo_acquire(const GeoKey &key, bool want_boxes, hipStream_t stream, GeoUse 
           refresh_lists(e);
           if (e.lists_known) {
             use->lists = true;
-            use->n_work = e.counts[0], use->n_runs = e.counts[1], use->n_corner_blocks = e.counts[2], use->n_blocks = e.counts[3], use->n_pairs = e.counts[4], use->n_rest = e.counts[5], use->n_wide = e.counts[6], use->n_inview = e.counts[7];
+            use->n_work = e.counts[0], use->n_runs = e.counts[1], use->n_corner_blocks = e.counts[2], use->n_blocks = e.counts[3], use->n_wide = e.counts[6], use->n_inview = e.counts[7];
           }
         }
       }
@@ -397,6 +400,17 @@ void geo_launched(GeoUse *use, hipStream_t stream, bool ok) {
     for (Mark &m : e->marks)
       if (m.stream == stream) mark = &m;
     if (!mark) {
+      // a new stream: the marks of streams whose launches have completed order nothing any more — dropped here, so that an entry
+      // used from short-lived streams (a context per job) does not collect an event per stream that ever touched it
+      for (size_t i = 0; i < e->marks.size();) {
+        if (hipEventQuery(e->marks[i].event) == hipSuccess) {
+          (void)hipEventDestroy(e->marks[i].event);
+          e->marks.erase(e->marks.begin() + (long)i);
+        } else {
+          (void)hipGetLastError(); // (hipErrorNotReady is not an error)
+          ++i;
+        }
+      }
       hipEvent_t ev = nullptr;
       if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
         e->marks.push_back(Mark{stream, ev});
@@ -442,8 +456,22 @@ void geo_launched(GeoUse *use, hipStream_t stream, bool ok) {
     // stream is drained by hand before the pin goes
     (void)hipStreamSynchronize(stream);
     (void)hipGetLastError();
-    std::lock_guard<std::mutex> lock(d.mutex);
-    e->pins--;
+    Retired orphan;
+    bool have_orphan = false;
+    {
+      std::lock_guard<std::mutex> lock(d.mutex);
+      e->pins--;
+      // ... and an entry whose writing launch failed as well has no valid map and nobody who would write one (geo_acquire
+      // bypasses a found entry whose map is unusable): it goes now — the stream has drained, nothing is in flight on it
+      if (e->pins == 0 && e->map.state == kNone)
+        for (size_t i = 0; i < d.entries.size(); ++i)
+          if (d.entries[i].get() == e) {
+            orphan = retire_entry(d, i);
+            have_orphan = true;
+            break;
+          }
+    }
+    if (have_orphan) free_retired(orphan, true);
   }
 }
 
@@ -459,7 +487,7 @@ void geo_stats(GeoStats *out) {
   for (DeviceCache &d : g_devices) {
     std::lock_guard<std::mutex> lock(d.mutex);
     out->entries += d.entries.size();
-    out->bytes += live_bytes(d);
+    out->bytes += live_bytes(d) + retired_bytes(d);
     out->fills += d.stats.fills;
     out->hits += d.stats.hits;
     out->bypasses += d.stats.bypasses;
@@ -470,30 +498,49 @@ void geo_stats(GeoStats *out) {
   else if (out->max_bytes == 0) out->max_bytes = kDefaultCapCeiling;
 }
 
+namespace {
+// Retires every unpinned entry of `dev` and returns its buffers to the driver behind their events.  The calling thread's
+// current device must be `dev` when anything is freed.
+void release_device(int dev, bool forget_sightings) {
+  DeviceCache &d = g_devices[dev];
+  std::vector<Retired> gone;
+  {
+    std::lock_guard<std::mutex> lock(d.mutex);
+    for (size_t i = 0; i < d.entries.size();) {
+      const Entry &e = *d.entries[i];
+      if (e.pins == 0 && e.map.state != kClaimed && e.box.state != kClaimed)
+        gone.push_back(retire_entry(d, i));
+      else
+        ++i;
+    }
+    for (Retired &r : d.retired) gone.push_back(std::move(r));
+    d.retired.clear();
+    if (forget_sightings) {
+      d.sightings.clear();
+      d.useless_evictions = 0;
+    }
+  }
+  for (Retired &r : gone) free_retired(r, true);
+}
+bool device_holds_anything(int dev) {
+  DeviceCache &d = g_devices[dev];
+  std::lock_guard<std::mutex> lock(d.mutex);
+  return !d.entries.empty() || !d.retired.empty() || !d.sightings.empty();
+}
+} // namespace
+
+void geo_release_device(int device) {
+  if (cache_of(device)) release_device(device, false); // (out of memory is no reason to forget what has been seen)
+}
+
 void geo_release_all() {
   int cur = 0;
   const bool have_cur = hipGetDevice(&cur) == hipSuccess;
   if (!have_cur) (void)hipGetLastError();
   for (int dev = 0; dev < kMaxDevices; ++dev) {
-    DeviceCache &d = g_devices[dev];
-    std::vector<Retired> gone;
-    {
-      std::lock_guard<std::mutex> lock(d.mutex);
-      for (size_t i = 0; i < d.entries.size();) {
-        const Entry &e = *d.entries[i];
-        if (e.pins == 0 && e.map.state != kClaimed && e.box.state != kClaimed)
-          gone.push_back(retire_entry(d, i));
-        else
-          ++i;
-      }
-      for (Retired &r : d.retired) gone.push_back(std::move(r));
-      d.retired.clear();
-      d.sightings.clear();
-      d.useless_evictions = 0;
-    }
-    if (gone.empty()) continue;
+    if (!device_holds_anything(dev)) continue;
     if (have_cur && cur != dev) (void)hipSetDevice(dev);
-    for (Retired &r : gone) free_retired(r, true);
+    release_device(dev, true);
     if (have_cur && cur != dev) (void)hipSetDevice(cur);
   }
 }

@@ -11,7 +11,8 @@
 //
 // Bounded (bytes per device, least recently used entries go first), opt-out through the C ABI
 // (lrp_geometry_cache_configure), freed by lrp_release_cached_tables.  State is per device: a launch
-// thread of one GPU never takes a lock, waits for an event or synchronises on behalf of another GPU.
+// thread of one GPU never takes a lock, waits for an event or synchronises on behalf of another GPU
+// (out of memory included: geo_release_device).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -49,7 +50,7 @@ struct GeoUse {
   uint32_t *host_counts = nullptr;
   bool lists_enqueued = false;
   bool lists = false;
-  uint32_t n_work = 0, n_runs = 0, n_corner_blocks = 0, n_blocks = 0, n_pairs = 0, n_rest = 0;
+  uint32_t n_work = 0, n_runs = 0, n_corner_blocks = 0, n_blocks = 0;
   uint32_t n_wide = 0, n_inview = 0; // the census of the entry (lrp_geo_lists.hip geo_census): blocks in view whole / those of them no 10 KiB window stages
 };
 
@@ -58,8 +59,8 @@ struct GeoUse {
 // per-block extremes too).  A reader on another stream than the entry's writer is made to wait for the writer
 // (hipStreamWaitEvent).  Never fails: any problem (no memory, a capturing stream, the cache switched off) is mode 0.
 void geo_acquire(const GeoKey &key, bool want_boxes, hipStream_t stream, GeoUse *use);
-// True: the entry of `key` exists and a geo_acquire now would read it (mode 2) — for callers that only want the cache when
-// it is there (lrp_reproject_multi_device merges the outputs whose entries are) and must not claim what they will not write.
+// True: the entry of `key` exists and a geo_acquire now would read it (mode 2).  An observer: it claims nothing and marks nothing
+// (the host tests of the cache, tests/native/geocache_driver.cpp, look at the cache through it; no launch path calls it).
 bool geo_peek(const GeoKey &key, bool want_boxes);
 // After the launch has been enqueued (ok) or has failed to: publishes a written entry, marks the stream, unpins.
 void geo_launched(GeoUse *use, hipStream_t stream, bool ok);
@@ -72,6 +73,9 @@ struct GeoStats {
 // geometry seen on that device).
 void geo_configure(long long max_bytes, int min_sightings);
 void geo_stats(GeoStats *out);
-void geo_release_all(); // waits for the launches that touched the entries (their events), frees everything unpinned
+void geo_release_all(); // every device: waits for the launches that touched the entries (their events), frees everything unpinned
+// The same for ONE device (the calling thread's current device is `device`): what a launch path of that GPU may call when it
+// runs out of memory — it neither waits for, nor frees, nor forgets anything of another GPU.
+void geo_release_device(int device);
 
 } // namespace lrp

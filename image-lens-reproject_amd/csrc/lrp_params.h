@@ -14,7 +14,6 @@ enum : int { kRect = 0, kEquidistant = 1, kEquirect = 4 };
 // (reference LoopHorizontally, src/reproject.cpp:386-394).
 enum : int { kInRect = 0, kInEquidistant = 1, kInEquirect = 2, kInEquirectLoop = 3 };
 constexpr int kMaxBatch = 16; // frames of one geometry rendered by one launch (blockIdx.y = frame)
-constexpr int kMaxFaces = 8;  // outputs of one source rendered by one launch (interleaved workgroup by workgroup; a cubemap has six)
 constexpr int kXcds = 8; // XCDs (private L2s) of an MI355X; blockIdx % 8 labels the blocks that share one
 // XCD-aware tile numbering.  The dispatcher deals workgroup i to XCD i % 8.  The rows of tiles are cut
 // into bands of kXcdBand rows and the bands dealt round-robin to the XCDs: XCD k walks bands k, k + 8,
@@ -106,18 +105,6 @@ struct KParams {
   const int32_t *geo_work_rec; // [geo_n_work][8]: the box records of the work list's blocks (null: loaded from the box array per block)
   const uint32_t *geo_runs;  // [geo_n_runs][4]: block row, first block column, blocks (<= kGeoRunBlocks), corner class 1-4
   uint32_t geo_n_work, geo_n_runs;
-  // ... and the PAIR list: alias pairs of blocks that lie in view whole, rendered by the pair kernel (lrp_pair_kernel.h) from
-  // one window per pair; geo_work then points at the REST list (the work list without them).  Entry = (column, row) of the block in front of the camera.
-  const int32_t *geo_pairs;  // [geo_n_pairs][2]
-  uint32_t geo_n_pairs;
-  // Multi-output launch (GeoRead window kernels without the frame loop; lrp_reproject_multi_device): face_n > 0 outputs of ONE
-  // source — same size, channels and lenses, each with its own rotation, i.e. its own geometry-cache entry — rendered by one
-  // launch (the outputs interleaved workgroup by workgroup): one ramp and one tail instead of face_n, and the wavefronts of cheap
-  // and of expensive faces (a cubemap's pole faces cost twice its side faces) fill each other's gaps.
-  int32_t face_n;
-  float *face_dst[kMaxFaces];
-  float *face_xy[kMaxFaces];
-  int32_t *face_box[kMaxFaces];
   uint32_t geo_fill_per_wave; // listed window launch: row segments of the corner runs a filling wavefront writes when it is done (0: the fill kernel writes them)
   uint32_t geo_fill_stride;   // ... every geo_fill_stride-th wavefront fills (odd: the filling wavefronts then fall on all XCDs): a share of a whole run or more per filling wavefront — its set-up (run record, corner texel, tonemap: two scalar round trips) is paid once per share
 };
@@ -133,7 +120,7 @@ struct GeoLayout {
   size_t bytes() const { return xy_bytes + box_bytes + list_bytes; }
 };
 // Block lists, behind the class bytes (built once per entry by geo_build_lists, lrp_geo_lists.hip, from the class bytes):
-//   header  kGeoListHeaderWords words: [0] work entries, [1] runs, [2] corner blocks, [3] blocks of the image, [4] pair entries, [5] rest entries
+//   header  kGeoListHeaderWords words: [0] work entries, [1] runs, [2] corner blocks, [3] blocks of the image, [4], [5] unused
 //           [6] blocks in view whole that no 10 KiB window stages, [7] blocks in view whole (the census, lrp_geo_lists.hip)
 //   work    pairs (block column, block row) of every block that is NOT a corner block, in the order the window kernel's
 //           launch would reach them: entry i goes to workgroup i, i.e. to XCD i % 8, and the entries of one XCD are its
@@ -142,9 +129,6 @@ struct GeoLayout {
 //   runs    maximal runs of horizontally adjacent corner blocks of one class inside an aligned group of kGeoRunBlocks
 //           block columns: (block row, first block column, blocks, class).  Every pixel of a run is the same value
 //           (the clamped corner texel, src/reproject.cpp:114-131), so a run is 16 contiguous row segments of that value.
-//   pairs   (alias geometries only: a rectilinear view into a full-turn panorama, no pitch / roll) the blocks in front of the
-//           camera that lie in view whole and whose partner behind the camera does too, XCD-interleaved like the work list;
-//   rest    the work list without the blocks of the pairs: what the window kernel walks when the pair kernel renders the pairs.
 //   recs    the box record (8 words) of every entry of the work list, at the entry's position: a listed wavefront reads its block
 //           and the block's record with two scalar loads issued together — one round trip in front of the window request instead
 //           of two (the record's address in the box array depends on the entry).
@@ -155,10 +139,8 @@ inline __host__ __device__ size_t geo_work_capacity(int out_w, int out_h) { // e
   return (size_t)kXcds * ((geo_image_block_rows(out_h) + kXcds - 1) / kXcds) * geo_block_cols(out_w);
 }
 inline __host__ __device__ size_t geo_run_capacity(int out_w, int out_h) { return (size_t)geo_image_block_rows(out_h) * geo_block_cols(out_w); }
-inline __host__ __device__ size_t geo_pair_capacity(int out_w, int out_h) { return geo_work_capacity(out_w, out_h) / 2 + kXcds; } // entries (pairs of ints)
 inline __host__ __device__ size_t geo_work_recs_offset(int out_w, int out_h) { // bytes from the list header to the records of the work list
-  return (size_t)kGeoListHeaderWords * 4 + geo_work_capacity(out_w, out_h) * 8 + geo_run_capacity(out_w, out_h) * 16 + geo_pair_capacity(out_w, out_h) * 8 +
-         geo_work_capacity(out_w, out_h) * 8;
+  return (size_t)kGeoListHeaderWords * 4 + geo_work_capacity(out_w, out_h) * 8 + geo_run_capacity(out_w, out_h) * 16;
 }
 // Element (float2) of output pixel (x, y) in the coordinate map: row-major.  (A map stored in 16 x 16 tiles — 2 KiB contiguous
 // bytes per block of the window kernel instead of 16 row segments of 128 bytes — measured the same for the window kernels
@@ -185,8 +167,7 @@ inline GeoLayout geo_layout(int out_w, int out_h, bool with_boxes) {
   L.xy_bytes = ((size_t)out_w * (size_t)out_h * 8 + 255) & ~(size_t)255; // (the records and lists behind the map start on a 256-byte boundary)
   if (with_boxes) {
     L.box_bytes = geo_lists_offset(out_w, out_h);
-    L.list_bytes = (size_t)kGeoListHeaderWords * 4 + geo_work_capacity(out_w, out_h) * 8 + geo_run_capacity(out_w, out_h) * 16 +
-                   geo_pair_capacity(out_w, out_h) * 8 + geo_work_capacity(out_w, out_h) * 8 + geo_work_capacity(out_w, out_h) * 32;
+    L.list_bytes = geo_work_recs_offset(out_w, out_h) + geo_work_capacity(out_w, out_h) * 32;
   }
   return L;
 }

@@ -150,32 +150,10 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   const int frame0 = Pk.batch_n > 0 ? (int)blockIdx.y * frames_per_wave : 0;
   const int n_frames = (Frames && Pk.batch_n > 0) ? min(frames_per_wave, Pk.batch_n - frame0) : 1;
   auto frame_src = [&](int f) { return Pk.batch_n > 0 ? Pk.batch_src[frame0 + f] : Pk.src; };
-  // A multi-output launch (lrp_params.h face_n): consecutive workgroups of an XCD take the same block of consecutive outputs —
-  // every output advances at the same pace, so the cheap and the expensive ones (a cubemap's pole faces cost twice its side
-  // faces) are mixed from the first wavefront to the last, and the launch has one tail instead of the most expensive output's.
-  int face = 0;
-  uint32_t workgroup = blockIdx.x;
-  if constexpr (GeoRead && !Frames) {
-    if (Pk.face_n > 0) {
-      const uint32_t in_xcd = blockIdx.x / kXcds;
-      face = (int)(in_xcd % (uint32_t)Pk.face_n);
-      workgroup = in_xcd / (uint32_t)Pk.face_n * kXcds + blockIdx.x % kXcds;
-    }
-  }
-  auto frame_dst = [&](int f) {
-    if constexpr (GeoRead && !Frames)
-      if (Pk.face_n > 0) return Pk.face_dst[face];
-    return Pk.batch_n > 0 ? Pk.batch_dst[frame0 + f] : Pk.dst;
-  };
+  auto frame_dst = [&](int f) { return Pk.batch_n > 0 ? Pk.batch_dst[frame0 + f] : Pk.dst; };
   KParams P = Pk; // src / dst: the frame being rendered (set_frame below)
   P.src = frame_src(0);
   P.dst = frame_dst(0);
-  if constexpr (GeoRead && !Frames) {
-    if (Pk.face_n > 0) { // a multi-output launch: this workgroup's output (frame_dst) and its geometry (lrp_params.h)
-      P.geo_xy = Pk.face_xy[face];
-      P.geo_box = Pk.face_box[face];
-    }
-  }
   constexpr bool Loop = (InMode == kInEquirectLoop);
   // Edge blocks (WinBlockT::edge) are compiled for the rectilinear source only: a narrow view inside a wider target is
   // where whole blocks lie beyond one side of the source; in the other instantiations the extra code costs 2-3 % (measured:
@@ -266,7 +244,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
       fill_share();
       return;
     }
-  } else if (!xcd_tile<kWinXcdBand>(P.tiles_x, P.tiles_y, tx, ty, workgroup)) return; // whole workgroup
+  } else if (!xcd_tile<kWinXcdBand>(P.tiles_x, P.tiles_y, tx, ty, blockIdx.x)) return; // whole workgroup
 #if defined(LRP_WAVE_STAMPS)
   const unsigned long long stamp_start = wall_clock64();
 #endif
@@ -1538,10 +1516,8 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
     // >= 2 rounds of wavefronts; the launches that read the geometry cache >= 4 (their wavefronts differ more in what a block
     // costs them — nothing is computed, everything is waited for: pole face of the 8192^2 -> 2048^2 cubemap 107.5 -> 98.4 us)
     const long long min_waves = GeoRead ? 16384 : 8192;
-    const int n_faces = (GeoRead && P.face_n > 0) ? P.face_n : 1;
-    while (!strip_forced && G > 1 && (long long)P.tiles_x * kWinWaves * ((row_blocks + G - 1) / G) * n_faces < min_waves) G >>= 1;
+    while (!strip_forced && G > 1 && (long long)P.tiles_x * kWinWaves * ((row_blocks + G - 1) / G) < min_waves) G >>= 1;
     if (GeoRead && P.geo_work != nullptr && in_mode != kInRect) return hipErrorInvalidValue; // (lists: the rectilinear source's instantiations)
-    if (GeoRead && n_faces > 1 && !strip_forced) G = 1; // (a multi-output launch has wavefronts enough; 8192^2 -> six 2048^2 faces: 364 us against 370-392 with strips of two)
     if (GeoRead && P.geo_work != nullptr) G = 1; // a listed launch: one block per wavefront, the blocks of the work list only
     P.blocks_per_wave = G;
     P.tiles_y = (row_blocks + G - 1) / G;
@@ -1579,10 +1555,6 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
     if (kWinWaves != 1) return hipErrorInvalidValue; // (the work list names blocks, one per workgroup)
     if (P.geo_n_work == 0) return hipSuccess;       // every block is a corner block
     grid_x = P.geo_n_work;
-  }
-  if (GeoRead && P.face_n > 0) {
-    if (P.face_n > kMaxFaces || P.batch_n > 0 || P.geo_work != nullptr) return hipErrorInvalidValue;
-    grid_x *= (unsigned)P.face_n; // (the outputs interleaved inside every XCD's sequence of workgroups)
   }
   hipLaunchKernelGGL(fn, dim3(grid_x, (unsigned)groups), dim3(kWinThreads), 0, stream, P);
   return hipGetLastError();

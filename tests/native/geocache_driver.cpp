@@ -25,7 +25,8 @@ struct Event {
 std::set<void *> live_device, live_host;
 std::map<hipEvent_t, Event *> events;
 std::vector<std::pair<hipStream_t, hipEvent_t>> waits; // hipStreamWaitEvent calls, in order
-int device_syncs = 0, stream_syncs = 0, frees = 0, mallocs = 0, frees_of_busy_buffers = 0;
+int device_syncs = 0, stream_syncs = 0, frees = 0, mallocs = 0, frees_of_busy_buffers = 0, set_devices = 0;
+int fail_event_creates_after = -1; // >= 0: that many more hipEventCreateWithFlags calls succeed, then they fail
 thread_local int current_device = 0;
 size_t bytes_live = 0;
 std::map<void *, size_t> sizes;
@@ -71,6 +72,8 @@ hipError_t hipHostFree(void *p) {
 }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) {
   std::lock_guard<std::mutex> fake_lock(fake::mu);
+  if (fake::fail_event_creates_after == 0) return hipErrorOutOfMemory;
+  if (fake::fail_event_creates_after > 0) --fake::fail_event_creates_after;
   auto *ev = new fake::Event;
   *e = reinterpret_cast<hipEvent_t>(ev);
   fake::events[*e] = ev;
@@ -126,6 +129,7 @@ hipError_t hipGetDevice(int *d) {
 hipError_t hipSetDevice(int d) {
   std::lock_guard<std::mutex> fake_lock(fake::mu);
   fake::current_device = d;
+  ++fake::set_devices;
   return hipSuccess;
 }
 hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) {
@@ -164,7 +168,7 @@ static lrp::GeoUse fill(const lrp::GeoKey &k, hipStream_t s, bool boxes, bool li
   lrp::geo_acquire(k, boxes, s, &u);
   if (u.mode == 1 || u.mode == 3) {
     if (lists && u.host_counts) {
-      const uint32_t counts[8] = {800, 12, 40, 1000, 0, 800, 123, 456}; // (... 6, 7: the census of the entry's windows)
+      const uint32_t counts[8] = {800, 12, 40, 1000, 0, 0, 123, 456}; // (4, 5 unused; 6, 7: the census of the entry's windows)
       std::memcpy(u.host_counts, counts, sizeof(counts)); // (what the device-side copy would deliver)
       u.lists_enqueued = true;
     }
@@ -190,7 +194,7 @@ static int scenario_fill_read_lists() {
   fake::complete_all();
   fake::waits.clear();
   lrp::geo_acquire(k, true, S(1), &r);
-  CHECK(r.mode == 2 && r.lists && r.n_work == 800 && r.n_runs == 12 && r.n_corner_blocks == 40 && r.n_blocks == 1000 && r.n_rest == 800);
+  CHECK(r.mode == 2 && r.lists && r.n_work == 800 && r.n_runs == 12 && r.n_corner_blocks == 40 && r.n_blocks == 1000);
   CHECK(r.n_wide == 123 && r.n_inview == 456);
   CHECK(fake::waits.empty()); // ready parts need no event
   lrp::geo_launched(&r, S(1), true);
@@ -205,7 +209,7 @@ static int scenario_fill_read_lists() {
   return 0;
 }
 
-// The regions of an entry (lrp_params.h): map, box records + class bytes, list header, work list, runs, pairs, rest list, work
+// The regions of an entry (lrp_params.h): map, box records + class bytes, list header, work list, runs, work
 // records — disjoint, inside the entry, aligned as their readers need (256 bytes for the records and the header, 16 for the
 // 32-byte work records the list builder writes as two 16-byte vectors), for sizes around every rounding boundary.
 static int scenario_layout() {
@@ -217,11 +221,11 @@ static int scenario_layout() {
     const size_t blocks = (size_t)lrp::geo_block_cols(w) * lrp::geo_block_rows(h);
     CHECK(lrp::geo_class_offset(w, h) == blocks * 32);
     CHECK(L.box_bytes == lrp::geo_lists_offset(w, h) && L.box_bytes % 256 == 0 && L.box_bytes >= blocks * 33);
-    const size_t cap = lrp::geo_work_capacity(w, h), runs = lrp::geo_run_capacity(w, h), pairs = lrp::geo_pair_capacity(w, h);
+    const size_t cap = lrp::geo_work_capacity(w, h), runs = lrp::geo_run_capacity(w, h);
     CHECK(cap % lrp::kXcds == 0 && cap >= (size_t)lrp::geo_block_cols(w) * lrp::geo_image_block_rows(h));
     CHECK(runs >= (size_t)lrp::geo_block_cols(w) * lrp::geo_image_block_rows(h) / lrp::kGeoRunBlocks);
     const size_t recs = lrp::geo_work_recs_offset(w, h);
-    CHECK(recs == (size_t)lrp::kGeoListHeaderWords * 4 + cap * 8 + runs * 16 + pairs * 8 + cap * 8);
+    CHECK(recs == (size_t)lrp::kGeoListHeaderWords * 4 + cap * 8 + runs * 16);
     CHECK(recs % 16 == 0);                // (int4 stores of the list builder, dwordx8 scalar loads of the kernel)
     CHECK(L.list_bytes == recs + cap * 32); // the records are the last region
     CHECK(L.bytes() == L.xy_bytes + L.box_bytes + L.list_bytes);
@@ -338,6 +342,109 @@ static int scenario_failed_launch_and_key() {
   return 0;
 }
 
+// Out of memory on ONE GPU (lrp_capi.cpp's fallbacks call geo_release_device): that GPU's entries and retired buffers go back to the
+// driver behind their events; the other GPU's entry stays, nobody switches devices, what has been seen is not forgotten.
+static int scenario_release_one_device() {
+  const lrp::GeoLayout one = lrp::geo_layout(640, 480, true);
+  lrp::geo_configure((long long)(1.5 * one.bytes()), 2); // (entries from the second sighting on)
+  fake::current_device = 0;
+  (void)fill(key_of(0, 640, 480, 1.0f), S(0), true); // first sighting: no entry
+  const lrp::GeoUse a0 = fill(key_of(0, 640, 480, 1.0f), S(0), true);
+  lrp::GeoUse b0;
+  lrp::geo_acquire(key_of(0, 640, 480, 1.0f), true, S(0), &b0);
+  { lrp::GeoUse v = b0; lrp::geo_launched(&v, S(0), true); }
+  fake::current_device = 1;
+  (void)fill(key_of(1, 640, 480, 1.0f), S(1), true);
+  const lrp::GeoUse a1 = fill(key_of(1, 640, 480, 1.0f), S(1), true);
+  CHECK(a0.mode == 1 && b0.mode == 2 && a1.mode == 1);
+  // device 1 meets a geometry of another size: its first entry is evicted, the buffer fits nobody and stays retired (its
+  // launches are "in flight")
+  const lrp::GeoLayout small = lrp::geo_layout(320, 240, true);
+  lrp::geo_configure((long long)(1.1 * one.bytes()), 2);
+  (void)fill(key_of(1, 320, 240, 2.0f), S(1), true);
+  const lrp::GeoUse s1 = fill(key_of(1, 320, 240, 2.0f), S(1), true);
+  CHECK(s1.mode == 1);
+  lrp::GeoStats st;
+  lrp::geo_stats(&st);
+  CHECK(st.entries == 2 && st.evictions == 1 && st.bytes == 2 * one.bytes() + small.bytes()); // (a retired buffer counts until it has gone back)
+  const int set0 = fake::set_devices, frees0 = fake::frees;
+  lrp::geo_release_device(1);
+  CHECK(fake::set_devices == set0 && fake::frees == frees0 + 2);
+  CHECK(lrp::geo_peek(key_of(0, 640, 480, 1.0f), true) && !lrp::geo_peek(key_of(1, 320, 240, 2.0f), true));
+  lrp::geo_stats(&st);
+  CHECK(st.entries == 1 && st.bytes == one.bytes());
+  const lrp::GeoUse again = fill(key_of(1, 320, 240, 2.0f), S(1), true); // its sightings are remembered: cached at once
+  CHECK(again.mode == 1);
+  CHECK(fake::device_syncs == 0);
+  fake::current_device = 0;
+  return 0;
+}
+
+// An entry used from many short-lived streams (a context per job): the marks of streams whose launches have completed are dropped
+// when a new stream arrives — events do not pile up, a take-over does not wait for a hundred stale events.
+static int scenario_marks_are_pruned() {
+  lrp::geo_configure(64 << 20, 1);
+  const lrp::GeoKey k = key_of(0, 320, 200, 9.0f);
+  (void)fill(k, S(0), true);
+  fake::complete_all();
+  const size_t events0 = fake::events.size();
+  for (int i = 1; i <= 100; ++i) {
+    lrp::GeoUse r;
+    lrp::geo_acquire(k, true, S(i), &r);
+    CHECK(r.mode == 2);
+    lrp::geo_launched(&r, S(i), true);
+    if (i % 10 == 0) fake::complete_all(); // (every tenth job sees the earlier ones finished)
+  }
+  CHECK(fake::events.size() <= events0 + 11);
+  // marks of launches still in flight are kept: a take-over waits for exactly those
+  lrp::GeoUse r;
+  lrp::geo_acquire(k, true, S(200), &r);
+  lrp::geo_launched(&r, S(200), true);
+  lrp::geo_acquire(k, true, S(201), &r);
+  lrp::geo_launched(&r, S(201), true);
+  const lrp::GeoLayout one = lrp::geo_layout(320, 200, true);
+  lrp::geo_configure((long long)(1.2 * one.bytes()), 1);
+  fake::waits.clear();
+  const lrp::GeoUse t = fill(key_of(0, 320, 200, 10.0f), S(300), true); // evicts k, takes its buffer over
+  CHECK(t.mode == 1);
+  size_t waits_on_new = 0;
+  for (auto &w : fake::waits) waits_on_new += w.first == S(300);
+  CHECK(waits_on_new >= 2 && waits_on_new <= 12);
+  CHECK(fake::device_syncs == 0);
+  return 0;
+}
+
+// The writing launch of a new entry fails AND no event can be recorded behind it (event creation fails): the stream is drained by
+// hand, and the entry — no valid map, nobody who would ever write one — goes instead of staying behind as a permanent bypass.
+static int scenario_failed_writer_without_mark() {
+  lrp::geo_configure(64 << 20, 1);
+  const lrp::GeoKey k = key_of(0, 200, 100, 11.0f);
+  lrp::GeoUse u;
+  lrp::geo_acquire(k, true, S(0), &u);
+  CHECK(u.mode == 1);
+  fake::fail_event_creates_after = 0; // the mark's event cannot be created
+  const int syncs0 = fake::stream_syncs;
+  lrp::geo_launched(&u, S(0), false);
+  fake::fail_event_creates_after = -1;
+  CHECK(fake::stream_syncs == syncs0 + 1);
+  lrp::GeoStats st;
+  lrp::geo_stats(&st);
+  CHECK(st.entries == 0 && !lrp::geo_peek(k, false));
+  lrp::geo_acquire(k, true, S(0), &u); // ... and the next launch of the geometry writes a fresh entry
+  CHECK(u.mode == 1);
+  lrp::geo_launched(&u, S(0), true);
+  CHECK(lrp::geo_peek(k, true));
+  // the mark fails but the launch itself was fine: the entry is published and stays
+  const lrp::GeoKey k2 = key_of(0, 200, 100, 12.0f);
+  lrp::geo_acquire(k2, true, S(0), &u);
+  CHECK(u.mode == 1);
+  fake::fail_event_creates_after = 0;
+  lrp::geo_launched(&u, S(0), true);
+  fake::fail_event_creates_after = -1;
+  CHECK(lrp::geo_peek(k2, true));
+  return 0;
+}
+
 // eight threads on two devices, a cap that holds a few entries, geometries drawn from a small pool: fills, hits, evictions,
 // take-overs and failed launches race; run under -fsanitize=thread / address by tests/test_geocache_host.py
 static int scenario_threads() {
@@ -380,6 +487,9 @@ int main(int argc, char **argv) {
   if (name == "devices") rc = scenario_devices_are_independent();
   if (name == "default_cap") rc = scenario_default_cap_and_release();
   if (name == "failed_launch_and_key") rc = scenario_failed_launch_and_key();
+  if (name == "release_one_device") rc = scenario_release_one_device();
+  if (name == "marks_are_pruned") rc = scenario_marks_are_pruned();
+  if (name == "failed_writer_without_mark") rc = scenario_failed_writer_without_mark();
   if (name == "threads") rc = scenario_threads();
   fake::complete_all();
   lrp::geo_release_all(); // (the cache is process-wide state: handed back so that the leak checker sees what is really lost)

@@ -26,13 +26,10 @@ with open(os.path.join(HERE, "golden", "fullframe_golden.json")) as _f:
 def _fresh_cache(lrp):
     lrp.debug_set("geo_cache", 1)
     prev = lrp.debug_set("geo_lists", 2)
-    prev_pairs = lrp.debug_set("geo_pairs", 1)  # (off by default: here the pair kernel is part of what is tested)
     lrp.geometry_cache_configure(1 << 30, 1)
     lrp.release_cached_tables()
     yield
     lrp.debug_set("geo_lists", prev)
-    lrp.debug_set("geo_pairs", prev_pairs)
-    lrp.debug_set("multi_merge", 0)
     lrp.debug_set("geo_fill_stream", 0)
     lrp.geometry_cache_configure(1 << 30, 1)
     lrp.release_cached_tables()
@@ -92,11 +89,11 @@ def test_listed_launches_against_the_live_oracle(lrp, oracle, torch_cuda, channe
         for got in render(batch=5):
             cases.assert_same_bits(got, want, "listed batch of five, " + what)
         assert _listed(lrp) == n0 + 2 * lists
-        for knob_name in ("geo_pairs", "geo_fill_fused", "geo_lists"):  # no pair kernel; the fill kernel instead of a share per wavefront; no lists at all
+        for knob_name in ("geo_fill_fused", "geo_lists"):  # the fill kernel instead of a share per wavefront; no lists at all
             prev = lrp.debug_set(knob_name, 0)
             cases.assert_same_bits(render()[0], want, f"{knob_name} 0, " + what)
             lrp.debug_set(knob_name, prev)
-        assert _listed(lrp) == n0 + 4 * lists
+        assert _listed(lrp) == n0 + 3 * lists
 
 
 def test_all_corner_one_block_and_no_corner_frames(lrp, oracle, torch_cuda):
@@ -145,10 +142,9 @@ def test_whole_frames_by_block_class(lrp, torch_cuda, name):
     frame(case["seed"] + 99)
     for fill_stream in (0, 1):
         lrp.debug_set("geo_fill_stream", fill_stream)
-        n0, p0 = _listed(lrp), lrp.debug_set("pair_launches", -1)
+        n0 = _listed(lrp)
         d_out = frame(case["seed"])
         assert _listed(lrp) == n0 + 1
-        assert lrp.debug_set("pair_launches", -1) == p0 + 1, "the view and its copy behind the camera: alias pairs by the pair kernel"
         sha, bands, n_nan = ffc.frame_digests(d_out.cpu().numpy())
         bad = [b for b in range(ffc.BANDS) if bands[b] != want["bands"][b]]
         assert not bad, f"{name}: row bands {bad} of {ffc.BANDS} differ from the committed oracle digest (fill_stream {fill_stream})"
@@ -156,13 +152,11 @@ def test_whole_frames_by_block_class(lrp, torch_cuda, name):
 
 
 @pytest.mark.parametrize("channels", [3, 4, 5])
-def test_outputs_of_one_source_in_one_launch(lrp, oracle, torch_cuda, channels):
-    """lrp_reproject_multi_device (BASELINE configs[4]: six faces of one panorama): the first call renders every face by a launch
-    of its own and leaves six geometry-cache entries; from the second call on the faces go out as ONE launch (blockIdx.z =
-    face).  Six and nine outputs (two launches: eight + one), odd sizes, a rectilinear source as well, fused tonemap — every
-    face against the live oracle, the counter proving the merged launch ran; `multi_merge` 0 gives the same bits."""
+def test_outputs_of_one_source(lrp, oracle, torch_cuda, channels):
+    """lrp_reproject_multi_device (BASELINE configs[4]: six faces of one panorama): a launch per face, dealt over the caller's stream
+    and a side stream; the first call fills six geometry-cache entries, later calls read them.  Six and nine outputs, odd sizes, a
+    rectilinear source as well, fused tonemap — every face of three consecutive calls against the live oracle."""
     torch = torch_cuda
-    lrp.debug_set("multi_merge", 1)  # (off by default: measured level or slower; the path is tested all the same)
     faces = [(0.0, 0.0, 0.0), (90.0, 0.0, 0.0), (180.0, 0.0, 0.0), (270.0, 0.0, 0.0), (0.0, 90.0, 0.0), (0.0, -90.0, 0.0),
              (30.0, -15.0, 5.0), (45.0, 45.0, 0.0), (10.0, 0.0, 80.0)]
     for (iw, ih, ow, oh), in_name, n_faces, post in (((256, 128, 72, 72), "eqr_full", 6, None), ((200, 100, 53, 41), "eqr_full", 9, (1.5, 3.0)),
@@ -184,16 +178,8 @@ def test_outputs_of_one_source_in_one_launch(lrp, oracle, torch_cuda, channels):
             return [o.cpu().numpy() for o in outs]
 
         what = f"{in_name} {iw}x{ih} -> {n_faces} x {ow}x{oh} C={channels} post={post}"
-        m0 = lrp.debug_set("merged_launches", -1)
-        for f, got in enumerate(render()):
-            cases.assert_same_bits(got, wants[f], f"first call (a launch per face), face {f}, " + what)
-        assert lrp.debug_set("merged_launches", -1) == m0
-        for f, got in enumerate(render()):
-            cases.assert_same_bits(got, wants[f], f"second call (one launch), face {f}, " + what)
-        assert lrp.debug_set("merged_launches", -1) == m0 + (2 if n_faces > 8 else 1), what
-        lrp.debug_set("multi_merge", 0)
-        for f, got in enumerate(render()):
-            cases.assert_same_bits(got, wants[f], f"multi_merge 0, face {f}, " + what)
-        lrp.debug_set("multi_merge", 1)
-        assert lrp.debug_set("merged_launches", -1) == m0 + (2 if n_faces > 8 else 1)
-    lrp.debug_set("multi_merge", 0)
+        hits0 = lrp.geometry_cache_stats()["hits"]
+        for call in ("first call (fills the entries)", "second call (reads them)", "third call"):
+            for f, got in enumerate(render()):
+                cases.assert_same_bits(got, wants[f], f"{call}, face {f}, " + what)
+        assert lrp.geometry_cache_stats()["hits"] >= hits0 + 2 * n_faces, what

@@ -56,8 +56,6 @@ SETTINGS = {
     "geo_lists2": {"geo_cache": 1, "geo_lists": 2},
     "geo_lists2_fill_kernel": {"geo_cache": 1, "geo_lists": 2, "geo_fill_fused": 0},
     "geo_lists2_fill_stream": {"geo_cache": 1, "geo_lists": 2, "geo_fill_fused": 0, "geo_fill_stream": 1},
-    "geo_lists2_pairs1": {"geo_cache": 1, "geo_lists": 2, "geo_pairs": 1},  # (alias pairs of in-view blocks by the pair kernel, two wavefronts per window)
-    "multi_merge1": {"geo_cache": 1, "multi_merge": 1},  # (lrp_reproject_multi_device: the outputs whose entries exist in ONE launch)
     "win_tapdma0": {"geo_cache": 1, "win_tapdma": 0},  # (the big-window variant: passes whose window fits no buffer gather per lane)
     "geo_lists2_tapdma0": {"geo_cache": 1, "geo_lists": 2, "win_tapdma": 0},
     "geo_lists2_recs0": {"geo_cache": 1, "geo_lists": 2, "geo_list_recs": 0},  # (a listed wavefront loads its block's record from the box array)
@@ -95,7 +93,7 @@ class _DeviceSynth:
 
 def test_switch_names_and_ranges(lrp):
     for name in ("kernel", "xsep", "quad", "mirror_modes", "win_edge", "win_split", "batch_frames", "multi_fork", "geo_cache", "geo_strip", "geo_big",
-                 "geo_lists", "geo_fill_fused", "geo_fill_stream", "geo_pairs", "multi_merge", "context_streams", "win_ss", "win_tapdma", "geo_list_recs", "geo_census"):
+                 "geo_lists", "geo_fill_fused", "geo_fill_stream", "context_streams", "win_ss", "win_tapdma", "geo_list_recs", "geo_census"):
         now = lrp.debug_set(name, -1)
         assert lrp.debug_set(name, now) == now  # setting the current value returns it
         assert lrp.debug_set(name, 10 ** 6) == now and lrp.debug_set(name, -1) == now  # out of range: a query
@@ -164,7 +162,7 @@ def test_whole_frames_under_setting(lrp, torch_cuda, setting):
             torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("setting", ["multi_fork0", "multi_fork3", "multi_fork3_geo", "defaults", "geo_cache", "multi_merge1"])
+@pytest.mark.parametrize("setting", ["multi_fork0", "multi_fork3", "multi_fork3_geo", "defaults", "geo_cache"])
 def test_cubemap_through_multi_under_setting(lrp, torch_cuda, setting):
     """BASELINE configs[4]: the six faces of an 8192^2 RGB panorama in ONE lrp_reproject_multi_device call, twice."""
     torch = torch_cuda
@@ -178,11 +176,7 @@ def test_cubemap_through_multi_under_setting(lrp, torch_cuda, setting):
     with _Knobs(lrp, SETTINGS[setting]):
         for rnd in range(2):
             outs = [torch.full((m, m, c), -1.0, dtype=torch.float32, device="cuda") for _ in names]
-            merged = lrp.debug_set("merged_launches", -1)
             lrp.reproject_multi(lrp.Image(lin, n, n, c, d_in), [lrp.Image(lout, m, m, c, o) for o in outs], 1, case0["interp"], rots)
             torch.cuda.synchronize()
-            if rnd == 1:  # the second call finds six entries: ONE launch for the six faces where the setting asks for it
-                cached = SETTINGS[setting].get("geo_cache", 1) == 1 and SETTINGS[setting].get("multi_merge", 0) == 1
-                assert lrp.debug_set("merged_launches", -1) == merged + (1 if cached else 0), setting
             for nm, o in zip(names, outs):
                 assert ffc.frame_digests(o.cpu().numpy())[0] == FULL["frames"][nm]["sha256"], f"{setting}: {nm} (round {rnd})"

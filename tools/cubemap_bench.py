@@ -28,8 +28,7 @@ def run(i):
     pkg.reproject_multi(ins[i % n_src], outs[i % n_src], 1, 2, rots, stream=stream)
 
 
-for merge, fork, strip in ((1, 1, 0), (0, 1, 0), (0, 0, 0), (1, 1, 1), (1, 1, 2), (1, 1, 4), (1, 1, 0), (0, 1, 0)):
-    pkg.debug_set("multi_merge", merge)
+for fork, strip in ((1, 0), (0, 0), (2, 0), (1, 1), (1, 2), (1, 4), (1, 0)):
     pkg.debug_set("multi_fork", fork)
     pkg.debug_set("geo_strip", strip)
     with torch.cuda.stream(stream):
@@ -44,4 +43,4 @@ for merge, fork, strip in ((1, 1, 0), (0, 1, 0), (0, 0, 0), (1, 1, 1), (1, 1, 2)
         torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     once = (n * n + 6 * m * m) * c * 4
-    print(f"multi_merge {merge} multi_fork {fork} geo_strip {strip}: {us:7.1f} us per cubemap   frac_source_once {once / (us * 1e-6) / 8e12:.3f}", flush=True)
+    print(f"multi_fork {fork} geo_strip {strip}: {us:7.1f} us per cubemap   frac_source_once {once / (us * 1e-6) / 8e12:.3f}", flush=True)

@@ -13,7 +13,7 @@ cp $f/roofline.md profiles/${r}_roofline.md
 (echo "# 16-frame launches, default"; cat $f/kbench_rgba_batched.log; echo; echo "# 16-frame launches, geometry cache off"; cat $f/kbench_rgba_batched_geo0.log) > profiles/${r}_kbench_rgba_batched.txt
 (cat $f/kbench_rgb_batched.log; echo; cat $f/kbench_rgbaz_batched.log; echo; cat $f/kbench_rgbaz_single.log) > profiles/${r}_kbench_rgb_rgbaz.txt
 cp $f/kbench_configs3_lists.log profiles/${r}_kbench_configs3_lists.txt
-(cat $f/kbench_cubemap_faces.log; echo "# geometry cache off"; cat $f/kbench_cubemap_faces_geo0.log; echo "# the whole cubemap (lrp_reproject_multi_device)"; grep multi_merge $f/cubemap_bench.log) > profiles/${r}_kbench_cubemap_faces.txt
+(cat $f/kbench_cubemap_faces.log; echo "# geometry cache off"; cat $f/kbench_cubemap_faces_geo0.log; echo "# the whole cubemap (lrp_reproject_multi_device)"; grep multi_fork $f/cubemap_bench.log) > profiles/${r}_kbench_cubemap_faces.txt
 cp $f/kbench_supersampling.log profiles/${r}_kbench_supersampling.txt
 [ -f $f/kbench_tap_dma.log ] && cp $f/kbench_tap_dma.log profiles/${r}_kbench_tap_dma.txt
 cp $f/kbench_two_streams.log profiles/${r}_kbench_two_streams.txt

@@ -2,7 +2,7 @@
 // no torch.  Times lrp_reproject_device on device-resident synthetic frames with
 // HIP events on the launch stream, prints per-workload kernel time, Gpix/s and
 // the algorithmic-bytes roofline fraction, plus an FNV-1a checksum of the output
-// so two kernel variants (LRP_KERNEL=v1|v2) can be compared bit for bit at full
+// so two kernel variants (--set kernel=1|2) can be compared bit for bit at full
 // size.
 //
 // Build (tools/build_kbench.sh):
@@ -168,9 +168,8 @@ int main(int argc, char **argv) {
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
-  const char *kv = getenv("LRP_KERNEL");
-  printf("# size %d -> %d, C=%d, ns=%d, reps=%d, distinct=%d, batch=%d, LRP_KERNEL=%s, geo_cache=%d\n", size, out_size, channels, ns, reps,
-         distinct, batch, kv ? kv : "(default)", lrp_debug_set("geo_cache", -1));
+  printf("# size %d -> %d, C=%d, ns=%d, reps=%d, distinct=%d, batch=%d, kernel family %d, geo_cache=%d\n", size, out_size, channels, ns, reps,
+         distinct, batch, lrp_debug_set("kernel", -1), lrp_debug_set("geo_cache", -1));
   for (const auto &nm : names) {
     const Workload *W = nullptr;
     for (const auto &w : kWorkloads)

@@ -95,7 +95,6 @@ CHECKS = [  # (what, workload, batch, switch, settings: the first is the default
     ("block lists, configs[3] RGBAZ + tonemap batch16", C3Z, 16, "geo_lists", (1, 0, 2)),
     ("block lists, rect -> fisheye single", RFE, 0, "geo_lists", (1, 0, 2)),
     ("corner fill as shares, configs[3] RGBAZ + tonemap single", C3Z, 0, "geo_fill_fused", (1, 0)),
-    ("pair kernel (off), configs[3] RGBAZ + tonemap batch16", C3Z, 16, "geo_pairs", (0, 1)),
     ("big-window variant, configs[3] RGBA single", C3, 0, "geo_big", (1, 0)),
     ("big-window variant by census, rect -> fisheye RGBA single", RFE, 0, "geo_big", (1, 0, 2)),
     ("big-window variant by census, rect -> fisheye RGBA batch16", RFE, 16, "geo_big", (1, 0, 2)),
@@ -131,36 +130,5 @@ for what, wl, batch, switch, settings in CHECKS:
     ok = default <= best * (1.0 + tol)
     bad += 0 if ok else 1
     print(f"{'ok  ' if ok else 'SLOW'} {what:70s} {switch}: " + "  ".join(f"{v}: {t:7.1f}" for v, t in times.items()) + f"   default / best = {default / best:.3f}", flush=True)
-# merged multi-output launches (its own entry point)
-faces = [(0.0, 0.0, 0.0), (90.0, 0.0, 0.0), (180.0, 0.0, 0.0), (270.0, 0.0, 0.0), (0.0, 90.0, 0.0), (0.0, -90.0, 0.0)]
-_frames.clear()
-torch.cuda.empty_cache()
-n, m, c = 8192, 2048, 3
-srcs = []
-for k in range(3):
-    s = torch.empty((n, n, c), dtype=torch.float32, device=dev)
-    pkg.synth_fill(s, n, n, c, 0x5EED0000 + k, -1)
-    srcs.append(s)
-dsts = [[torch.empty((m, m, c), dtype=torch.float32, device=dev) for _ in range(6)] for _ in srcs]
-rots = np.stack([rot(f) for f in faces])
-lin, lout = pkg.LensInfo.equirectangular(), pkg.LensInfo.rectilinear(18.0, 36.0, m, m)
-times = {}
-for v in (0, 1, 0, 1, 0, 1):  # (alternating, the best of three each: the first launches on fresh allocations are slower whatever the setting)
-    prev = pkg.debug_set("multi_merge", v)
-    for i in range(6):
-        pkg.reproject_multi(pkg.Image(lin, n, n, c, srcs[i % 3]), [pkg.Image(lout, m, m, c, d) for d in dsts[i % 3]], 1, 2, rots)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for i in range(24):
-        pkg.reproject_multi(pkg.Image(lin, n, n, c, srcs[i % 3]), [pkg.Image(lout, m, m, c, d) for d in dsts[i % 3]], 1, 2, rots)
-    e1.record()
-    torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) * 1e3 / 24
-    times[v] = min(t, times.get(v, t))
-    pkg.debug_set("multi_merge", prev)
-ok = times[0] <= min(times.values()) * (1.0 + tol)
-bad += 0 if ok else 1
-print(f"{'ok  ' if ok else 'SLOW'} {'cubemap 8192^2 -> six 2048^2 faces, six launches (default) against one':70s} multi_merge: 0: {times[0]:7.1f}  1: {times[1]:7.1f}   default / best = {times[0] / min(times.values()):.3f}")
-print(f"# {bad} of {len(CHECKS) + 1} defaults more than {tol:.0%} behind their best alternative")
+print(f"# {bad} of {len(CHECKS)} defaults more than {tol:.0%} behind their best alternative")
 sys.exit(1 if bad else 0)

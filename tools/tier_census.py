@@ -14,8 +14,6 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["LRP_MIRROR_MODES"] = "0"
-os.environ["LRP_QUAD"] = "0"
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -23,6 +21,8 @@ native = importlib.import_module("image-lens-reproject_amd._native")
 native.LIB_PATH = os.path.abspath(sys.argv[1])
 lrp = importlib.import_module("image-lens-reproject_amd")
 lib = native.load()
+lrp.debug_set("mirror_modes", 0)
+lrp.debug_set("quad", 0)
 NAMES = ["coefficient", "raw", "direct", "corner", "edge-row", "edge-col", "split"]
 out = (ctypes.c_uint * 8)()
 
