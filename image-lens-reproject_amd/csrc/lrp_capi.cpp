@@ -22,6 +22,7 @@
 #include "../../include/lrp.h"
 #include "lrp_geocache.h"
 #include "lrp_params.h"
+#include "lrp_plan.h"
 #include "lrp_tables.h"
 
 namespace lrp {
@@ -188,13 +189,6 @@ struct KnobSpec {
   int lo, hi, initial;
 };
 constexpr int kMaxSideStreams = 5;
-// Listed launches render one block per wavefront, the enumerating launch strips of two (its wavefronts fetch the next block's
-// record under the current block): with the corner runs written by every n-th wavefront the listed launch is level at a third of
-// a frame of corner blocks (BASELINE configs[3], 37 %: RGBA +-1 %, RGBAZ + tonemap 2-4 % ahead) and ahead beyond that (rect ->
-// fisheye 2-3 %, narrower views 10-40 %); below, the plain enumeration stays.
-constexpr unsigned kListedCornerPercent = 30;
-constexpr unsigned kBigWidePercent = 30; // in-view blocks no 10 KiB window stages, per cent: from there on the big-window variant renders a panorama source
-constexpr unsigned kMinWavesForFusedFill = 2048; // wavefronts a listed window launch must have to carry the corner runs itself
 const KnobSpec kKnobs[kKnobCount] = {
     {"kernel", 0, 3, 2},
     {"xsep", 0, 1, 1},                  // column-separable source x tables
@@ -225,11 +219,6 @@ const bool g_knobs_initialised = [] {
 }();
 int knob(int k) { return g_knobs[k].load(std::memory_order_relaxed); }
 int kernel_choice() { return knob(kKnobKernel); }
-bool quad_enabled() { return knob(kKnobQuad) != 0; }
-bool mirror_modes_enabled() { return knob(kKnobMirrorModes) != 0; }
-bool win_edge_enabled() { return knob(kKnobWinEdge) != 0; }
-bool win_split_enabled() { return knob(kKnobWinSplit) != 0; }
-bool xsep_enabled() { return knob(kKnobXsep) != 0; }
 
 // The fill kernel of a listed launch (lrp_geo_lists.hip).  In front of the window kernel on the caller's stream, or — knob
 // "geo_fill_stream" — beside it on a side stream of the device: the two write disjoint pixels, the window kernel holds
@@ -285,6 +274,43 @@ hipError_t fill_corner_runs(const lrp::KParams &P, int device, hipStream_t strea
 // row_count > 0: only output rows [row_first, row_first + row_count) are rendered (the rows of the reference
 // loop are independent, src/reproject.cpp:284); the kernels that share work between mirrored rows need the
 // whole image and are not used for a band.
+// The switches the planner reads, at their current values.
+lrp::PlanSwitches plan_switches() {
+  lrp::PlanSwitches s;
+  s.kernel = kernel_choice();
+  s.xsep = knob(kKnobXsep), s.quad = knob(kKnobQuad), s.mirror_modes = knob(kKnobMirrorModes);
+  s.win_edge = knob(kKnobWinEdge), s.win_split = knob(kKnobWinSplit), s.win_tapdma = knob(kKnobWinTapDma), s.win_ss = knob(kKnobWinSS);
+  s.batch_frames = knob(kKnobBatchFrames);
+  s.geo_cache = knob(kKnobGeoCache), s.geo_strip = knob(kKnobGeoStrip), s.geo_big = knob(kKnobGeoBig), s.geo_lists = knob(kKnobGeoLists);
+  s.geo_fill_fused = knob(kKnobGeoFillFused), s.geo_list_recs = knob(kKnobGeoListRecs);
+  return s;
+}
+
+lrp::PlanRequest plan_request(const lrp_image *in, const lrp_image *out, int num_samples, int interpolation, const float *rotation,
+                              int n_batch, bool band) {
+  lrp::PlanRequest r;
+  r.out_type = out->lens.type == LRP_RECTILINEAR ? lrp::kPlanRect : (out->lens.type == LRP_FISHEYE_EQUIDISTANT ? lrp::kPlanEquidistant : lrp::kPlanEquirect);
+  r.in_type = in->lens.type == LRP_RECTILINEAR ? lrp::kPlanRect : (in->lens.type == LRP_FISHEYE_EQUIDISTANT ? lrp::kPlanEquidistant : lrp::kPlanEquirect);
+  r.in_mode = in_lens_mode(in->lens);
+  r.out_w = out->width, r.out_h = out->height, r.in_w = in->width, r.in_h = in->height, r.channels = out->channels;
+  r.num_samples = num_samples, r.interpolation = interpolation;
+  r.has_rot = rotation != nullptr;
+  if (rotation) std::memcpy(r.rot, rotation, sizeof(r.rot));
+  r.out_lon_span = out->lens.u.equirectangular.longitude_max - out->lens.u.equirectangular.longitude_min;
+  r.n_batch = n_batch;
+  r.band = band;
+  r.byte_offsets_fit = image_fits_byte_offsets(*in) && image_fits_byte_offsets(*out);
+  return r;
+}
+static_assert((int)lrp::kPlanRect == (int)lrp::kRect && (int)lrp::kPlanEquidistant == (int)lrp::kEquidistant && (int)lrp::kPlanEquirect == (int)lrp::kEquirect,
+              "lrp_plan.h numbers lenses like lrp_params.h");
+static_assert((int)lrp::kPlanInRect == (int)lrp::kInRect && (int)lrp::kPlanInEquidistant == (int)lrp::kInEquidistant &&
+                  (int)lrp::kPlanInEquirect == (int)lrp::kInEquirect && (int)lrp::kPlanInEquirectLoop == (int)lrp::kInEquirectLoop,
+              "lrp_plan.h numbers input modes like lrp_params.h");
+static_assert((int)lrp::kPlanNearest == LRP_NEAREST && (int)lrp::kPlanBilinear == LRP_BILINEAR && (int)lrp::kPlanBicubic == LRP_BICUBIC, "interpolation numbering");
+
+// The launcher: asks the planner (lrp_plan.h — every decision is there, as pure functions the CPU tests call too), fetches what
+// the plan wants (output-lens tables, the column-separable x table, the geometry-cache entry) and enqueues the launches.
 int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int interpolation,
                       const float *rotation, const lrp_post *post, int device, hipStream_t stream, int n_batch = 0,
                       int row_first = 0, int row_count = 0) {
@@ -300,116 +326,46 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
   hipError_t e;
   lrp::TableLease lease; // pins the cached tables until every launch of this call is enqueued (scope end)
   lrp::GeoUse geo;       // this launch's use of the geometry cache (none unless set below)
-  const bool tile_channels = out->channels >= 3 && out->channels <= 5;
-  int symmetry = 0; // bit 0 / 1: the column / row terms of the output-lens tables are mirror images about the image centre
-  bool tile = kernel_choice() != 0 && tile_channels && image_fits_byte_offsets(*in) && image_fits_byte_offsets(*out) &&
-              in->width <= 65535 && in->height <= 32767 &&
-              (long long)out->width * num_samples < (1ll << 30) && (long long)out->height * num_samples < (1ll << 30);
-  if (tile && out->lens.type != LRP_FISHEYE_EQUIDISTANT) {
+  const lrp::PlanSwitches sw = plan_switches();
+  const lrp::PlanRequest req = plan_request(in, out, num_samples, interpolation, rotation, n_batch, band);
+  lrp::PlanFamily family = lrp::plan_family(req, sw);
+  lrp::TableFacts tables;
+  if (family.wants_tables) {
     // separable output-lens terms (cached per device / lens / size / num_samples)
     const int out_kind = out->lens.type == LRP_RECTILINEAR ? lrp::kRect : lrp::kEquirect;
-    bool plain = false;
     e = lrp::get_output_tables(device, out_kind, P.out_lens, out->width, out->height, num_samples, stream, lease,
-                               &P.col_tab, &P.row_tab, &plain, &symmetry);
+                               &P.col_tab, &P.row_tab, &tables.plain, &tables.symmetry);
     if (e == hipErrorOutOfMemory) { // the geometry cache of THIS GPU holds what it holds for speed only: give it back, once
       (void)hipGetLastError();
       lrp::geo_release_device(device);
       e = lrp::get_output_tables(device, out_kind, P.out_lens, out->width, out->height, num_samples, stream, lease,
-                                 &P.col_tab, &P.row_tab, &plain, &symmetry);
+                                 &P.col_tab, &P.row_tab, &tables.plain, &tables.symmetry);
     }
     if (e == hipErrorOutOfMemory) {
       (void)hipGetLastError();
-      tile = false; // no memory for the tables: per-pixel kernel
+      family.tile = false; // no memory for the tables: per-pixel kernel
     } else if (e != hipSuccess) {
       return hip_fail(e, "output-lens table build");
-    } else if (plain) {
-      // Every ray component is finite and no -0.0f: multiplying by the exact identity matrix
-      // (what the CLI passes for --rotation 0,0,0) changes no bit of (vx, vy, vz) — drop it.
-      static const float kIdentity[9] = {1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f};
-      if (P.has_rot && std::memcmp(P.rot, kIdentity, sizeof(kIdentity)) == 0) P.has_rot = 0;
-      // Column-separable source x (lrp_tables.hip): ray x and z independent of the row.
-      const bool rows_free = !P.has_rot || (P.rot[1] == 0.0f && P.rot[7] == 0.0f);
-      if (xsep_enabled() && rows_free && im != lrp::kInEquidistant)
+    } else {
+      tables.built = true;
+      const lrp::PlanRotation pr = lrp::plan_rotation(req, sw, family, tables);
+      P.has_rot = pr.has_rot ? 1 : 0;
+      if (pr.wants_xsep)
         P.xsep_tab = lrp::get_xsep_table(device, P.col_tab, out_kind, out->width, num_samples, P.in_lens, im, in->width,
                                          P.in_lon_span, P.has_rot ? P.rot : nullptr, stream, lease);
     }
   }
-  if (tile) {
-    // Mirrored pixels / blocks: without a rotation the mapping is symmetric about both image axes
-    // and the lens-plane coordinates of the four mirror pixels differ in sign only (lrp_kernel_v2.h).
-    // Rectilinear / equirectangular target: the ray tables must be mirror images bit for bit;
-    // equidistant target: the ray is odd in cx, cy by construction.  An equirectangular source
-    // takes part through the column-separable x table only (its longitude is not odd in x).
-    // Family 3 keeps every sharing path of the tile / window kernels off (cross-checks).
-    const bool in_eqr = im == lrp::kInEquirect || im == lrp::kInEquirectLoop;
-    const bool sym_out = out->lens.type == LRP_FISHEYE_EQUIDISTANT ? true : symmetry == 3;
-    P.quad = !band && quad_enabled() && kernel_choice() != 3 && num_samples == 1 && !P.has_rot && sym_out &&
-             (!in_eqr || P.xsep_tab != nullptr);
-    // A batch of nearest-neighbour frames shares its coordinates between up to 16 frames (the plain path of the tile
-    // kernel keeps them in registers), which beats sharing them between four mirror pixels: 71 -> 66 us per 4K frame.
-    // ... and likewise for bilinear (same-box A/B, 16-frame launches: equirect -> rect 91.7 -> 83.7 us, fisheye -> rect 90.9 ->
-    // 84.2, equirect -> fisheye rotated 127.4 -> 118.6 with plain pixels + frames instead of mirrored pixels / rays).
-    const bool batch_plain = n_batch >= 4 && interpolation != LRP_BICUBIC && num_samples == 1;
-    if (P.quad && batch_plain) P.quad = 0;
-    // (num_samples == 2 — the reference's --samples 2 — has its own instantiations: plain blocks, no mirror mode, no cache)
-    const bool window = interpolation == LRP_BICUBIC && kernel_choice() >= 2 && (num_samples == 1 || (num_samples == 2 && knob(kKnobWinSS) != 0)) &&
-                        (out->channels == 4 || out->channels == 3 || out->channels == 5);
-    const bool window1 = window && num_samples == 1;
-    // Equidistant target, rotated (or an equirectangular source): the four mirror pixels still
-    // share the ray through the output lens (tile kernels only).
-    if (!band && !P.quad && !window && !batch_plain && quad_enabled() && kernel_choice() != 3 && num_samples == 1 &&
-        out->lens.type == LRP_FISHEYE_EQUIDISTANT)
-      P.quad = 2;
-    P.win_coef = kernel_choice() == 2;
-    P.win_edge = (kernel_choice() == 2 && win_edge_enabled()) ? 1 : 0;
-    P.win_split = (kernel_choice() == 2 && win_split_enabled()) ? 1 : 0;
-    P.win_tapdma = knob(kKnobWinTapDma) != 0 ? 1 : 0;
-    // Mirror mode of the window kernel (lrp_kernel_v2.h QMode): both axes without a rotation; rows only for a pan,
-    // columns only for a pitch into a rectilinear target.  Signed zeros count as zeros in the matrix tests.
-    P.win_mode = P.quad == 1 ? 1 : 0;
-    // equidistant target that is not fully mirrored (a rotation, or an equirectangular source): the four mirror pixels
-    // still share the ray through the output lens
-    // (not for a batch: its wavefronts share ALL of the coordinate math between up to 16 frames on plain blocks at
-    // four wavefronts per SIMD — equirect -> fisheye rotated 143 us against 147 with shared rays at three)
-    if (window1 && P.win_mode == 0 && !band && quad_enabled() && mirror_modes_enabled() && kernel_choice() != 3 &&
-        out->lens.type == LRP_FISHEYE_EQUIDISTANT && n_batch < 4)
-      P.win_mode = 4;
-    if (window1 && P.win_mode == 0 && !band && quad_enabled() && mirror_modes_enabled() && kernel_choice() != 3 && P.has_rot) {
-      const float *R = P.rot;
-      auto tiny = [](float v) { return !(std::fabs(v) >= 0x1p-20f); }; // (also true for a NaN)
-      if (P.xsep_tab != nullptr && (symmetry & 2) && R[3] == 0.0f && R[5] == 0.0f && !tiny(R[4]))
-        P.win_mode = 2; // ny = R4 vy exactly: odd in vy; nx, nz come from the column table
-      else if (out->lens.type == LRP_RECTILINEAR && (symmetry & 1) && R[1] == 0.0f && R[2] == 0.0f && R[3] == 0.0f && R[6] == 0.0f &&
-               !tiny(R[0]) && R[5] != 0.0f && R[8] != 0.0f && std::isfinite(R[4]) && std::isfinite(R[5]) && std::isfinite(R[7]) &&
-               std::isfinite(R[8]))
-        P.win_mode = 3; // nx = R0 vx exactly: odd in vx; ny, nz end in the non-zero terms R5 vz, R8 vz (vz = -1: no underflow)
-    }
-    // The view's copy behind the camera sits half a turn away, upside down (lrp_kernel_v2.h "alias pairs"): only when
-    // the panorama spans the full turn and the rotation neither pitches nor rolls.
-    P.alias_pairs = 0;
-    if (out->lens.type == LRP_EQUIRECTANGULAR && in->lens.type == LRP_RECTILINEAR) {
-      const float turn = out->lens.u.equirectangular.longitude_max - out->lens.u.equirectangular.longitude_min;
-      const bool yaw_only = !P.has_rot || (P.rot[1] == 0.0f && P.rot[3] == 0.0f && P.rot[5] == 0.0f && P.rot[7] == 0.0f);
-      P.alias_pairs = std::fabs(turn - 6.2831855f) < 1e-3f && yaw_only;
-    }
-    P.frames_per_wave = knob(kKnobBatchFrames); // 0: the launcher decides
-    // Geometry cache (lrp_geocache.h): a single whole-image launch of the window kernel loads the coordinates of its
-    // pixels and the window extremes of its blocks when an earlier launch of the same geometry has left them in HBM,
-    // and leaves them there when it is the first.  Both run plain blocks: the entry is a plain per-pixel map.
-    // Batched bicubic launches read the entry as well (their wavefronts load a block's coordinates once and walk its frames);
-    // the first frame of a batch whose geometry has no entry yet is rendered by a launch of its own, which writes it.
-    // Nearest / bilinear single launches (tile kernel, one sample per pixel) use the coordinate map of the same entries.
-    // (nearest without a rotation: the mirrored pixels of the compute kernel are as fast as a load per pixel — 75.8 against 78.2 us
-    // per 4K frame — and need no entry)
-    // (... and a rectilinear source under a rectilinear / equirectangular target: four divides a pixel cost less than the 8 bytes
-    // a pixel the map adds to these memory-bound kernels — rect -> equirect nearest 105 -> 117 us, bilinear 144 -> 159 with it)
-    const bool cheap_coordinates = im == lrp::kInRect && out->lens.type != LRP_FISHEYE_EQUIDISTANT;
-    // Batched bilinear launches read the map too, a frame per workgroup (8 wavefronts per SIMD against the 4 of the instantiations
-    // that hold coordinates across frames: equirect -> fisheye rotated 129.4 -> 107.1 us per frame, equirect -> rect 89.3 -> 84.3);
-    // batched nearest keeps the frame loop (69.4 against 72.9 us).
-    const bool tile_single = !window && interpolation != LRP_BICUBIC && num_samples == 1 && (n_batch <= 0 || interpolation == LRP_BILINEAR) &&
-                             !(interpolation == LRP_NEAREST && P.quad != 0) && !cheap_coordinates;
-    if ((window1 || tile_single) && !band && kernel_choice() == 2 && knob(kKnobGeoCache) != 0) {
+  if (family.tile) {
+    lrp::PlanRotation pr;
+    pr.has_rot = P.has_rot != 0;
+    const lrp::PlanSharing sh = lrp::plan_sharing(req, sw, family, tables, pr, P.xsep_tab != nullptr);
+    const bool window = sh.window;
+    P.quad = sh.quad;
+    P.win_coef = sh.win_coef, P.win_edge = sh.win_edge, P.win_split = sh.win_split, P.win_tapdma = sh.win_tapdma;
+    P.win_mode = sh.win_mode;
+    P.alias_pairs = sh.alias_pairs;
+    P.frames_per_wave = sh.frames_per_wave;
+    if (sh.wants_geo) {
       lrp::GeoKey key;
       std::memset(&key, 0, sizeof(key));
       key.device = device;
@@ -419,46 +375,30 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
       key.has_rot = P.has_rot;
       key.out_lens = lrp::geo_canonical_lens(P.out_lens, out->lens.type), key.in_lens = lrp::geo_canonical_lens(P.in_lens, in->lens.type);
       if (P.has_rot) std::memcpy(key.rot, P.rot, sizeof(key.rot));
-      lrp::geo_acquire(key, window1, stream, &geo);
-      if (geo.mode != 0) {
-        P.geo_mode = geo.mode;
+      lrp::geo_acquire(key, sh.geo_want_boxes, stream, &geo);
+      lrp::GeoFacts facts;
+      facts.mode = geo.mode, facts.lists = geo.lists;
+      facts.n_work = geo.n_work, facts.n_runs = geo.n_runs, facts.n_corner_blocks = geo.n_corner_blocks, facts.n_blocks = geo.n_blocks;
+      facts.n_wide = geo.n_wide, facts.n_inview = geo.n_inview;
+      const lrp::PlanGeo pg = lrp::plan_geo(req, sw, sh, facts);
+      if (pg.geo_mode != 0) {
+        P.geo_mode = pg.geo_mode;
         P.geo_xy = geo.xy;
         P.geo_box = geo.box;
-        P.win_mode = 0;
-        P.quad = 0; // (tile kernels: the plain path writes / the GeoRead kernels read the map)
-        P.blocks_per_wave = knob(kKnobGeoStrip); // 0: the launcher decides
-        P.rgbaz_runs = (out->lens.type == LRP_EQUIRECTANGULAR && in->lens.type == LRP_RECTILINEAR) ? 1 : 0;
-        // The big-window variant (lrp_win_kernel.h kBigWin: 20 KiB of LDS per wavefront, two wavefronts per SIMD, tap DMA): a
-        // rectilinear view rendered into a panorama; and any geometry out of a rectilinear or panorama source whose census
-        // (lrp_geo_lists.hip) says that at least kBigWidePercent % of its in-view blocks have windows the 10 KiB buffer of the
-        // four-wavefront kernels cannot stage (a cubemap's pole faces: 97 -> 80 us, a rectilinear view into a fisheye frame
-        // 160 -> 145; a cubemap's side faces and the ~1:1 mappings have no such block and lose 25-30 % there).
-        const bool wide = geo.mode == 2 && geo.lists && im != lrp::kInEquidistant && geo.n_inview != 0 &&
-                          (unsigned long long)geo.n_wide * 100u >= (unsigned long long)geo.n_inview * kBigWidePercent;
-        P.big_windows = knob(kKnobGeoBig) == 2 ? 1 : knob(kKnobGeoBig) != 0 ? (P.rgbaz_runs != 0 || wide ? 1 : 0) : 0; // (2: wherever the variant is instantiated)
-        // Rendering by block class (lrp_params.h "Block lists"): once the lists of the entry are known, the corner blocks
-        // — every pixel the one clamped corner texel — are written by the store-only fill kernel and the window kernel
-        // walks the work list, which holds no corner block.  Where corner blocks are rare the plain enumeration stays.
-        const int lists_knob = knob(kKnobGeoLists);
-        if (window && im == lrp::kInRect && geo.mode == 2 && geo.lists && lists_knob != 0 && geo.n_blocks != 0 &&
-            (lists_knob == 2 || (unsigned long long)geo.n_corner_blocks * 100u >= (unsigned long long)geo.n_blocks * kListedCornerPercent)) {
+        P.win_mode = pg.win_mode;
+        P.quad = pg.quad;
+        P.blocks_per_wave = pg.blocks_per_wave;
+        P.rgbaz_runs = pg.rgbaz_runs;
+        P.big_windows = pg.big_windows;
+        if (pg.listed) { // rendering by block class: the lists of the entry (lrp_params.h "Block lists")
           const uint8_t *const lists = reinterpret_cast<const uint8_t *>(geo.box) + lrp::geo_lists_offset(out->width, out->height);
           P.geo_work = reinterpret_cast<const int32_t *>(lists + (size_t)lrp::kGeoListHeaderWords * 4);
           P.geo_runs = reinterpret_cast<const uint32_t *>(P.geo_work + 2 * lrp::geo_work_capacity(out->width, out->height));
           P.geo_n_work = geo.n_work;
           P.geo_n_runs = geo.n_runs;
-          P.geo_work_rec = knob(kKnobGeoListRecs) != 0 ? reinterpret_cast<const int32_t *>(lists + lrp::geo_work_recs_offset(out->width, out->height)) : nullptr;
-          // the corner runs: a share per wavefront of the window launch where it has enough wavefronts to spread them over,
-          // else (few or no blocks to render: the frame is nearly all corners) the fill kernel at its own, full occupancy
-          if (knob(kKnobGeoFillFused) != 0 && P.geo_n_work >= kMinWavesForFusedFill && geo.n_runs != 0) {
-            // every stride-th wavefront (odd stride: all XCDs) writes at least one whole run (16 row segments)
-            const unsigned long long segs = (unsigned long long)geo.n_runs * 16u;
-            unsigned stride = (unsigned)std::max<unsigned long long>(1, 16ull * P.geo_n_work / segs) | 1u;
-            stride = std::min(stride, std::max(1u, P.geo_n_work / 1024u) | 1u); // (at least ~1024 filling wavefronts)
-            const unsigned fillers = (P.geo_n_work + stride - 1) / stride;
-            P.geo_fill_stride = stride;
-            P.geo_fill_per_wave = (unsigned)((segs + fillers - 1) / fillers);
-          }
+          P.geo_work_rec = pg.list_recs ? reinterpret_cast<const int32_t *>(lists + lrp::geo_work_recs_offset(out->width, out->height)) : nullptr;
+          P.geo_fill_stride = pg.fill_stride;
+          P.geo_fill_per_wave = pg.fill_per_wave;
         }
       }
     }
