@@ -34,7 +34,7 @@ constexpr unsigned kBigWidePercent = 30;
 // wavefronts a listed window launch must have to carry the corner runs itself
 constexpr unsigned kMinWavesForFusedFill = 2048;
 // largest num_samples the window kernel's supersampling instantiations take (sub-sample loop; 5 and more: the tile kernel)
-constexpr int kMaxWindowSamples = 2;
+constexpr int kMaxWindowSamples = 4;
 
 // The switches of lrp_debug_set that decide anything here, at their current values (lrp_capi.cpp reads them once per call).
 struct PlanSwitches {

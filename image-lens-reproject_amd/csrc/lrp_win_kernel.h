@@ -83,12 +83,17 @@ __device__ unsigned g_tier_stats[8]; // coefficient, raw, direct, corner, beyond
 // the plain-block instantiation (P.geo_mode == 1) the first time a geometry is rendered; the loaded values are the
 // stored ones, so the rendered bits are the same.  No lens math is compiled in: the output lens is irrelevant (kRect by
 // convention), plain blocks only.
-// SS: the supersampling instantiation, num_samples == 2 (the reference's --samples 2, src/reproject.cpp:294-298, what its README
-// asks for when an image is scaled down by two).  A block is 16 x 4 OUTPUT pixels, a lane owns one of them, and the four
-// "passes" of the block are the pixel's four sub-samples in the reference's order (k = 2 ssx + ssy): the window is the bounding
-// box of all of them, every pass samples it like a pass of an ordinary block, the samples are summed in registers in that order
-// (0.0f + s0 + s1 + s2 + s3, :334-336) and pass 3 stores sum * 0.25f (:338-341).  Plain blocks that compute their coordinates;
-// no geometry cache (its map holds one coordinate pair per pixel), no frame loop.
+// SS: the supersampling instantiation, num_samples 2, 3 or 4 (the reference's --samples, src/reproject.cpp:294-298; its help text
+// prescribes --scale 0.5 --samples 2, --scale 0.33334 --samples 3, --scale 0.25 --samples 4, src/main.cpp:192-196).  A LANE is one
+// SUB-SAMPLE: the ns^2 sub-samples of a pixel sit in ns^2 consecutive lanes in the reference's order (sub = ns ssx + ssy), a pass
+// is one output row of 64 / ns^2 pixels (16, 7 — lane 63 idles —, 4), a block four such rows: 256 samples whose taps span
+// ~(npx ns + 3) x (4 ns + 3) source texels at the scales the option exists for — a window as compact as an ordinary block's, so
+// the same plan, DMA and tiers serve it.  (Lanes as pixels and passes as sub-samples — round 5's layout, num_samples 2 only —
+// would stage the footprint of 64 PIXELS per pass: 67 x 19 texels at --scale 0.25, beyond any buffer.)  The sub-samples of a
+// pixel are summed in the reference's order (0.0f + s0 + s1 + ..., :334-336) by a chain of ns^2 - 1 DPP steps — step t: every
+// lane adds its sample to the sum its left neighbour holds (wave_shr:1), so that after it the lane of sub-sample t holds
+// 0 + s0 + ... + st — and the pixel's last lane stores sum * (1 / ns^2) (:338-341).  Plain blocks that compute their
+// coordinates; no geometry cache (its map holds one coordinate pair per pixel), no frame loop.
 template <int OutLens, int InMode, int QMode, int CH, bool Frames = false, bool GeoRead = false, bool SS = false>
 #ifndef LRP_WIN_MINWAVES5
 #define LRP_WIN_MINWAVES5 3 // RGBAZ: 168 VGPRs (the 80 registers of a direct-path tap set do not fit 128 without spilling)
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   using WinBlock = WinBlockT<Quad>;
   static_assert(CH == 3 || CH == 4 || CH == 5, "window kernel: RGB, RGBA or RGBAZ");
   static_assert(!SS || (QMode == 0 && !Frames && !GeoRead), "supersampling: plain blocks that compute their coordinates");
-  constexpr int kBlockRows = SS ? kPassRows : kBlkH; // output rows of a block (SS: the four passes are the sub-samples of ONE row group)
+  constexpr int kBlockRows = SS ? 4 : kBlkH; // output rows of a block (SS: a pass is ONE output row)
   static_assert(QMode != 2 || (OutLens != kEquidistant && InMode != kInEquidistant), "rows-only mirroring goes through the column-separable source x");
   static_assert(QMode != 3 || OutLens == kRect, "columns-only mirroring needs vz == -1");
   static_assert(!GeoRead || (QMode == 0 && (OutLens == kRect || (OutLens == kEquirect && !Frames))),
@@ -309,10 +314,24 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   // workgroup tile = 16 kWinWaves x 16G (x 16 of the quadrant when mirrored): one strip per wavefront
   int prow, pcol; // this lane's pixel of a pass
   win_lane_pixel(lane, prow, pcol);
-  const int x = tx * (kBlkW * kWinWaves) + wave * kBlkW + pcol;
+  // SS: this lane's pixel of the pass (pcol; every lane of a pass lies in one output row) and its sub-sample; wave-uniform:
+  // sub-samples per pixel and pixels per pass.  (The divisors are 4, 9, 16 and 2, 3, 4: a multiply and a shift.)
+  const int ss_ns = SS ? Pk.num_samples : 1, ss_n = ss_ns * ss_ns, ss_npx = SS ? 64 / ss_n : kBlkW;
+  int ss_x = 0, ss_y = 0;
+  bool ss_owner = false; // the lane that ends up with the pixel's sum: its last sub-sample
+  if constexpr (SS) {
+    const int l = min(lane, ss_npx * ss_n - 1); // (num_samples 3: lane 63 repeats lane 62 and stores nothing)
+    pcol = ss_n == 4 ? l >> 2 : ss_n == 16 ? l >> 4 : (l * 57) >> 9;
+    prow = 0;
+    const int sub = l - pcol * ss_n;
+    ss_x = ss_ns == 2 ? sub >> 1 : ss_ns == 4 ? sub >> 2 : (sub * 11) >> 5;
+    ss_y = sub - ss_x * ss_ns;
+    ss_owner = sub == ss_n - 1 && lane < ss_npx * ss_n;
+  }
+  const int x = tx * ((SS ? ss_npx : kBlkW) * kWinWaves) + wave * (SS ? ss_npx : kBlkW) + pcol;
   const int y_lane = P.y_offset + ty * (quad ? kBlkH : kBlockRows * Gs) + prow; // + kBlockRows * g + kPassRows * pass
-  // output row of this lane's pixel in pass k of strip block g (plain blocks; SS: every pass is the same pixel)
-  auto pixel_row = [&](int g, int k) { return y_lane + (quad ? 0 : kBlockRows * block_row(g)) + (SS ? 0 : kPassRows * k); };
+  // output row of this lane's pixel in pass k of strip block g (plain blocks; SS: pass k is row k of the block)
+  auto pixel_row = [&](int g, int k) { return y_lane + (quad ? 0 : kBlockRows * block_row(g)) + (SS ? k : kPassRows * k); };
   const int xe = x < qw ? x : qw - 1;
   const int in_w = P.in_w;
   SrcView src = source_view<2, CH>(P);
@@ -331,9 +350,8 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     out_lds = s_out[wave];
   }
   ColTerms col{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-  if constexpr (!GeoRead) col = column_terms<OutLens>(P, xe, 0);
-  ColTerms col_m = col; // the mirrored column (SS: the column's second horizontal sub-sample)
-  if constexpr (SS) col_m = column_terms<OutLens>(P, xe, 1);
+  if constexpr (!GeoRead) col = column_terms<OutLens>(P, xe, ss_x); // (SS: the terms of this lane's horizontal sub-sample)
+  ColTerms col_m = col; // the mirrored column
   if constexpr (MirX && !kSharedRays) col_m = column_terms<OutLens>(P, P.out_w - 1 - xe, 0);
   // Stage-1 results of the four quadrant pixels of this lane, kept for the whole strip:
   //   rectilinear / equidistant source: (qa, qb) = plane coordinates (u, v); a mirror image negates them;
@@ -458,7 +476,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int yk = pixel_row(g, k);
-        row_v[k] = row_term<OutLens>(P, yk < qh ? yk : qh - 1, SS ? (k & 1) : 0);
+        row_v[k] = row_term<OutLens>(P, yk < qh ? yk : qh - 1, ss_y);
       }
     }
     if (quad && g == 0) {
@@ -525,14 +543,12 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     // for the whole kernel: 80-100 MB of scratch traffic per 4K frame.  Opaque here, those few multiplies run per block.)
     ColTerms col_g = col;
     if constexpr (!Quad) asm volatile("" : "+v"(col_g.a), "+v"(col_g.b), "+v"(col_g.nx), "+v"(col_g.nz), "+v"(col_g.sx));
-    ColTerms col_s = col_m; // SS: sub-samples 2, 3 (ssx == 1)
-    if constexpr (SS) asm volatile("" : "+v"(col_s.a), "+v"(col_s.b), "+v"(col_s.nx), "+v"(col_s.nz), "+v"(col_s.sx));
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int yk = pixel_row(g, k);
       const int ye = yk < qh ? yk : qh - 1;
       if (!quad)
-        pixel_source_rt<OutLens, InMode>(P, (SS && k >= 2) ? col_s : col_g, row_v[k], ye, SS ? (k & 1) : 0, b.sx[k], b.sy[k]);
+        pixel_source_rt<OutLens, InMode>(P, col_g, row_v[k], ye, ss_y, b.sx[k], b.sy[k]);
       else
         quad_xy(gm, k, b.sx[k], b.sy[k]);
       note_pixel(e, k, b.sx[k], b.sy[k]);
@@ -927,14 +943,14 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     // strip — which spilled — so the row is re-derived from an opaque copy here: an add and a min per pass)
     int y_base = y_lane;
     asm volatile("" : "+v"(y_base)); // (likewise not hoisted out of the frame loop)
-    const int yk = y_base + (quad ? 0 : kBlockRows * block_row(g)) + (SS ? 0 : kPassRows * k);
+    const int yk = y_base + (quad ? 0 : kBlockRows * block_row(g)) + (SS ? k : kPassRows * k);
     const int yc = yk < qh ? yk : qh - 1;
     const int gm = image_of(g);
     PassOut o;
     o.xo = (quad && (gm & 1)) ? P.out_w - 1 - xe : xe; // mirrored blocks write the mirrored pixel
     o.yo = (quad && (gm >> 1)) ? P.out_h - 1 - yc : yc;
     const int x_blk = tx * (kBlkW * kWinWaves) + wave * kBlkW;
-    const int y_top = P.y_offset + ty * (quad ? kBlkH : kBlockRows * Gs) + (quad ? 0 : kBlockRows * block_row(g)) + (SS ? 0 : kPassRows * k);
+    const int y_top = P.y_offset + ty * (quad ? kBlkH : kBlockRows * Gs) + (quad ? 0 : kBlockRows * block_row(g)) + (SS ? k : kPassRows * k);
     o.whole = x_blk + kBlkW <= qw && y_top + kPassRows <= qh;
     o.mxo = quad && (gm & 1);
     const bool myo = quad && (gm >> 1);
@@ -942,16 +958,30 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     o.row_step = myo ? -P.out_w : P.out_w;
     return o;
   };
-  Px<CH> ss_sum = px_zero<CH>(); // SS: the running sum of this lane's pixel over the passes (= sub-samples) of the block
+  // SS: does this lane's pixel of pass k of block g exist (its column inside the image, its row inside the band)?  Lanes beyond
+  // recompute the pixel they were clamped to and store nothing.
+  auto ss_inside = [&](int g, int k) { return x < qw && pixel_row(g, k) < qh; };
   auto emit = [&](int g, int k, const Rgba &s, auto as_runs, bool runs_rt = true) {
     if constexpr (SS) { // src/reproject.cpp:334-341: acc = 0.0f; acc += sample (ssx outer, ssy inner); dst = acc * normalize
-      if (k == 0)
-        ss_sum = accumulate(s);
-      else
-        px_add<CH>(ss_sum, Px<CH>{s.lo, CH >= 4 ? s.hi : f2{0.0f, 0.0f}, CH == 3 ? s.hi.x : s.e});
-      if (k != 3) return;
-      const PassOut o = pass_out(g, k);
-      store_px<CH, false>(P, (uint32_t)o.yo * (uint32_t)P.out_w + (uint32_t)o.xo, ss_sum);
+      // The chain: a lane whose sub-sample is the pixel's first starts from 0.0f + s, every other from s (a placeholder); step t
+      // replaces every lane's value by (its left neighbour's value) + s — after it the lane of sub-sample t holds the reference's
+      // sum up to and including st, whatever the lanes of later sub-samples hold meanwhile.
+      const Px<CH> sp{s.lo, CH >= 4 ? s.hi : f2{0.0f, 0.0f}, CH == 3 ? s.hi.x : s.e};
+      Px<CH> a = (ss_x | ss_y) == 0 ? accumulate(s) : sp;
+      auto from_left = [](float v) { return u2f((uint32_t)__builtin_amdgcn_update_dpp((int)f2u(v), (int)f2u(v), 0x138 /* wave_shr:1 */, 0xF, 0xF, false)); };
+#pragma unroll 1
+      for (int t = 1; t < ss_n; ++t) {
+        Px<CH> b;
+        b.lo = f2{from_left(a.lo.x), from_left(a.lo.y)};
+        b.hi = CH >= 4 ? f2{from_left(a.hi.x), from_left(a.hi.y)} : f2{0.0f, 0.0f};
+        b.e = CH != 4 ? from_left(a.e) : 0.0f;
+        px_add<CH>(b, sp);
+        a = b;
+      }
+      if (ss_owner && ss_inside(g, k)) {
+        const PassOut o = pass_out(g, k);
+        store_px<CH, false>(P, (uint32_t)o.yo * (uint32_t)P.out_w + (uint32_t)o.xo, a);
+      }
       return;
     }
     const Px<CH> a = accumulate(s);
@@ -979,13 +1009,18 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   auto emit_corner = [&](int g, const Rgba &s, auto before_last) {
     Px<CH> a = accumulate(s);
     float c[5];
-    if constexpr (SS) { // four equal sub-samples summed like any others, one store (the block is one pass of pixels)
-#pragma unroll
-      for (int i = 1; i < 4; ++i) px_add<CH>(a, Px<CH>{s.lo, CH >= 4 ? s.hi : f2{0.0f, 0.0f}, CH == 3 ? s.hi.x : s.e});
+    if constexpr (SS) { // ns^2 equal sub-samples summed like any others (no lane needs another's), the pixels' last lanes store the four rows
+#pragma unroll 1
+      for (int t = 1; t < ss_n; ++t) px_add<CH>(a, Px<CH>{s.lo, CH >= 4 ? s.hi : f2{0.0f, 0.0f}, CH == 3 ? s.hi.x : s.e});
       finish_px<CH, false>(P, a, c);
-      before_last();
-      const PassOut o = pass_out(g, 3);
-      store_texel_nt<CH>(P.dst + (size_t)((uint32_t)o.yo * (uint32_t)P.out_w + (uint32_t)o.xo) * CH, c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k == 3) before_last();
+        if (ss_owner && ss_inside(g, k)) {
+          const PassOut o = pass_out(g, k);
+          store_texel_nt<CH>(P.dst + (size_t)((uint32_t)o.yo * (uint32_t)P.out_w + (uint32_t)o.xo) * CH, c);
+        }
+      }
       return;
     }
     finish_px<CH, true>(P, a, c);
@@ -1194,7 +1229,9 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     if (n_frames > 1 || g == 0) set_frame(f);
     const bool last_frame = f + 1 == n_frames; // the next step is the next block
     // (a launch that writes the geometry cache has the stores of coords(g + 1) in flight as well: it waits for everything)
-    if ((g == 0 && f == 0) || !dma_early || geo_write)
+    // (SS: the stores are predicated — a pass whose pixels all lie beyond the image issues none — so nothing may be assumed
+    // to be younger than the window's request)
+    if ((g == 0 && f == 0) || !dma_early || geo_write || SS)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the window was the last thing requested
     else
       asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); // window g has landed; block g-1's last store may be in flight
@@ -1373,7 +1410,12 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
           // (split blocks: h = 1 reads the window of passes 2-3, requested behind pass 1's taps — its arithmetic and store and
           // the other wavefronts cover part of the round trip — and waited for in front of pass 2)
           const int half = (t_split && h == 1) ? 1 : 0;
-          if (t_split && k == 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); // the DMA is older than every store behind it
+          if (t_split && k == 2) { // the DMA is older than every store behind it (SS: predicated stores — nothing is assumed)
+            if constexpr (SS)
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else
+              asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+          }
           const float tx_ = __builtin_truncf(psx), ty_ = __builtin_truncf(psy);
           const int slot0 = cur.org() + __mul24((int)ty_ - 1 - (kSplit ? cur.first_row_of(half) : cur.y_lo), cur.spitch()) + ((int)tx_ - 1 - cur.x_lo);
           s = win_tier_raw<CH>(win + slot0, cur.spitch(),
@@ -1478,7 +1520,7 @@ template <int CH> struct WinSSKernelTable {
   }
 };
 
-// num_samples must be 1 — or 2 for the SS launcher (the pipeline keeps ONE pixel's sum across the four passes of a block).
+// num_samples must be 1 — or 2, 3, 4 for the SS launcher (a lane per sub-sample).
 // QMode != 0: P.win_mode == QMode, set by the host only for cells where the mode exists.  GeoRead: P.geo_mode == 2, a single
 // whole-image launch.
 template <int QMode, int CH, bool GeoRead = false, bool SS = false>
@@ -1486,7 +1528,7 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
   static_assert(!GeoRead || QMode == 0, "the geometry cache feeds plain blocks");
   static_assert(!SS || (QMode == 0 && !GeoRead), "supersampling: plain blocks that compute");
   if (GeoRead && (P.geo_mode != 2 || P.y_offset != 0 || P.y_end != P.out_h)) return hipErrorInvalidValue;
-  if (P.num_samples != (SS ? 2 : 1) || (SS && P.geo_mode != 0)) return hipErrorInvalidValue;
+  if ((SS ? (P.num_samples < 2 || P.num_samples > 4) : P.num_samples != 1) || (SS && P.geo_mode != 0)) return hipErrorInvalidValue;
   constexpr int kRowsPerBlock = SS ? kPassRows : kBlkH; // output rows of a block
   const int rows = P.y_end - P.y_offset;
   if (QMode != 0) {
@@ -1498,7 +1540,8 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
     P.tiles_y = (qh + kBlkH - 1) / kBlkH;
     P.blocks_per_wave = (QMode == 1 || QMode == 4) ? 4 : 2;
   } else {
-    P.tiles_x = (P.out_w + kBlkW * kWinWaves - 1) / (kBlkW * kWinWaves);
+    const int cols_per_block = SS ? 64 / (P.num_samples * P.num_samples) : kBlkW; // (SS: pixels of a pass — 16, 7, 4)
+    P.tiles_x = (P.out_w + cols_per_block * kWinWaves - 1) / (cols_per_block * kWinWaves);
     // strips of LRP_WIN_STRIP blocks when that still leaves >= 8 workgroups per CU, else shorter
     const int row_blocks = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
 #ifndef LRP_SS_STRIP

@@ -1,8 +1,11 @@
-"""-m gpu: bicubic with num_samples == 2 through the window kernel's supersampling instantiations (csrc/lrp_win_kernel.h SS).
+"""-m gpu: bicubic with num_samples 2, 3 and 4 through the window kernel's supersampling instantiations (csrc/lrp_win_kernel.h
+SS) — the settings the reference's own help text prescribes: --scale 0.5 --samples 2, --scale 0.33334 --samples 3, --scale 0.25
+--samples 4 (src/main.cpp:192-196).
 
 The reference sums the ns x ns sub-samples of a pixel in ssx-outer, ssy-inner order into a zero-initialised accumulator and
-multiplies by 1 / (ns * ns) (src/reproject.cpp:290-298, 334-341).  In the SS instantiations a block is 16 x 4 output pixels and
-its four passes are the four sub-samples of every pixel, summed in registers in that order.  Every lens pair, channel count,
+multiplies by 1 / (ns * ns) (src/reproject.cpp:290-298, 334-341).  In the SS instantiations a block is 16 x 4 output pixels, a
+lane owns one pixel and takes its sub-samples in that order in rounds of four (one round for 2 x 2, three for 3 x 3 — the last
+holds one sub-sample —, four for 4 x 4), summed in registers; num_samples 5 and more stay with the tile kernel.  Every lens pair, channel count,
 rotation, odd sizes, strong down-scaling (what --samples is for), corner / edge blocks, fused tonemap, row bands and batches,
 against the live oracle at 0 ULP; `win_ss` 0 (the tile kernel) must give the same bits."""
 import numpy as np
@@ -24,10 +27,11 @@ def _render(lrp, torch, lin, d_in, lout, ow, oh, rot, post=None, ns=2):
     return d_out.cpu().numpy()
 
 
+@pytest.mark.parametrize("ns", [2, 3, 4])
 @pytest.mark.parametrize("channels", [3, 4, 5])
-def test_every_lens_pair_against_the_live_oracle(lrp, oracle, torch_cuda, channels):
+def test_every_lens_pair_against_the_live_oracle(lrp, oracle, torch_cuda, channels, ns):
     torch = torch_cuda
-    k = 0
+    k = ns
     for out_name in ("rect", "eqd180", "eqr_full", "eqr_part"):
         for in_name in ("rect", "rect_tele", "eqd180", "eqr_full", "eqr_part"):
             k += 1
@@ -37,48 +41,51 @@ def test_every_lens_pair_against_the_live_oracle(lrp, oracle, torch_cuda, channe
             src = cases.hash_noise(ih, iw, channels, seed=0x552 + 8 * k + channels, planted=(k % 2 == 0))
             lin, lout = cases.lenses(lrp, iw, ih)[in_name], cases.lenses(lrp, ow, oh)[out_name]
             rot = cases.rotation(lrp, golden_cases.ROTS[rot_name])
-            want = oracle.reproject(lin, src, lout, ow, oh, 2, BICUBIC, rot)
+            want = oracle.reproject(lin, src, lout, ow, oh, ns, BICUBIC, rot)
             if post:
                 want = oracle.post_process(want, *post)
             d_in = torch.from_numpy(src).cuda()
-            what = f"{in_name} {iw}x{ih} -> {out_name} {ow}x{oh} C={channels} {rot_name} post={post}"
-            cases.assert_same_bits(_render(lrp, torch, lin, d_in, lout, ow, oh, rot, post), want, "window kernel (SS), " + what)
+            what = f"{in_name} {iw}x{ih} -> {out_name} {ow}x{oh} C={channels} ns={ns} {rot_name} post={post}"
+            cases.assert_same_bits(_render(lrp, torch, lin, d_in, lout, ow, oh, rot, post, ns=ns), want, "window kernel (SS), " + what)
             prev = lrp.debug_set("win_ss", 0)
-            cases.assert_same_bits(_render(lrp, torch, lin, d_in, lout, ow, oh, rot, post), want, "tile kernel, " + what)
+            cases.assert_same_bits(_render(lrp, torch, lin, d_in, lout, ow, oh, rot, post, ns=ns), want, "tile kernel, " + what)
             lrp.debug_set("win_ss", prev)
 
 
 def test_bands_batches_and_the_other_sample_counts(lrp, oracle, torch_cuda):
-    """Row bands (lrp_reproject_rows_device: bands that start and end inside a 4-row block), a batch of five frames, and
-    num_samples 1 / 3 around it (their own kernels) on one geometry."""
+    """Row bands (lrp_reproject_rows_device: bands that start and end inside a 4-row block) and a batch of five frames for every
+    sample count of the SS instantiations, and num_samples 1 / 5 around them (their own kernels) on one geometry."""
     torch = torch_cuda
     iw, ih, ow, oh, c = 300, 200, 147, 101, 4
     lin, lout = lrp.LensInfo.equirectangular(), lrp.LensInfo.rectilinear(18.0, 36.0, ow, oh)
     rot = lrp.rotation_matrix(0.4, -0.2, 0.05)
     srcs = [cases.hash_noise(ih, iw, c, seed=0xBA2D + i, planted=True) for i in range(5)]
     d_ins = [torch.from_numpy(s).cuda() for s in srcs]
-    for ns in (1, 2, 3):
+    for ns in (1, 2, 3, 4, 5):
         want = oracle.reproject(lin, srcs[0], lout, ow, oh, ns, BICUBIC, rot)
         cases.assert_same_bits(_render(lrp, torch, lin, d_ins[0], lout, ow, oh, rot, ns=ns), want, f"num_samples {ns}")
-    wants = [oracle.reproject(lin, s, lout, ow, oh, 2, BICUBIC, rot) for s in srcs]
-    outs = [torch.full((oh, ow, c), -1.0, dtype=torch.float32, device="cuda") for _ in srcs]
-    lrp.reproject_batch([lrp.Image(lin, iw, ih, c, d) for d in d_ins], [lrp.Image(lout, ow, oh, c, o) for o in outs], 2, BICUBIC, rot)
-    torch.cuda.synchronize()
-    for i, o in enumerate(outs):
-        cases.assert_same_bits(o.cpu().numpy(), wants[i], f"batch of five, frame {i}")
-    banded = torch.full((oh, ow, c), -7.0, dtype=torch.float32, device="cuda")
-    cuts = [0, 3, 10, 11, 50, 97, oh]
-    for a, b in zip(cuts[:-1], cuts[1:]):
-        lrp.reproject_rows(lrp.Image(lin, iw, ih, c, d_ins[0]), lrp.Image(lout, ow, oh, c, banded), 2, BICUBIC, a, b - a, rot)
-    torch.cuda.synchronize()
-    cases.assert_same_bits(banded.cpu().numpy(), wants[0], "row bands")
+    for ns in (2, 3, 4):
+        wants = [oracle.reproject(lin, s, lout, ow, oh, ns, BICUBIC, rot) for s in srcs]
+        outs = [torch.full((oh, ow, c), -1.0, dtype=torch.float32, device="cuda") for _ in srcs]
+        lrp.reproject_batch([lrp.Image(lin, iw, ih, c, d) for d in d_ins], [lrp.Image(lout, ow, oh, c, o) for o in outs], ns, BICUBIC, rot)
+        torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            cases.assert_same_bits(o.cpu().numpy(), wants[i], f"num_samples {ns}: batch of five, frame {i}")
+        banded = torch.full((oh, ow, c), -7.0, dtype=torch.float32, device="cuda")
+        cuts = [0, 3, 10, 11, 50, 97, oh]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            lrp.reproject_rows(lrp.Image(lin, iw, ih, c, d_ins[0]), lrp.Image(lout, ow, oh, c, banded), ns, BICUBIC, a, b - a, rot)
+        torch.cuda.synchronize()
+        cases.assert_same_bits(banded.cpu().numpy(), wants[0], f"num_samples {ns}: row bands")
 
 
-def test_downscale_4k_to_2k_whole_frame_rows(lrp, oracle, torch_cuda):
-    """The case --samples exists for (README: raise it when scaling down): 4096^2 -> 2048^2, num_samples 2, bicubic RGBA —
-    sampled rows against the oracle, the whole frame against the tile kernel and the one-pixel-per-lane kernel."""
+@pytest.mark.parametrize("ns,m", [(2, 2048), (3, 1365), (4, 1024)])
+def test_downscale_4k_whole_frame_rows(lrp, oracle, torch_cuda, ns, m):
+    """The cases --samples exists for (src/main.cpp:192-196: --scale 0.5 --samples 2, 0.33334 / 3, 0.25 / 4): 4096^2 -> 2048^2,
+    1365^2 (int(4096 * 0.33334), src/main.cpp:581-587) and 1024^2, bicubic RGBA — sampled rows against the oracle, the whole frame
+    against the tile kernel and the one-pixel-per-lane kernel."""
     torch = torch_cuda
-    n, m, c = 4096, 2048, 4
+    n, c = 4096, 4
     d_in = torch.empty((n, n, c), dtype=torch.float32, device="cuda")
     lrp.synth_fill(d_in, n, n, c, 0x5EED0002)
     torch.cuda.synchronize()
@@ -86,16 +93,16 @@ def test_downscale_4k_to_2k_whole_frame_rows(lrp, oracle, torch_cuda):
     for in_name, out_name, deg in (("eqd180", "rect", None), ("eqr_full", "rect", (30.0, -15.0, 5.0)), ("rect", "eqr_full", (0.0, 0.0, 0.0))):
         lin, lout = cases.lenses(lrp, n, n)[in_name], cases.lenses(lrp, m, m)[out_name]
         rot = cases.rotation(lrp, deg)
-        got = _render(lrp, torch, lin, d_in, lout, m, m, rot)
-        rows = [0, 1, 2, 3, 4, 511, 1023, 1024, 1500, 2044, 2045, 2046, 2047]
-        want = oracle.reproject_rows(lin, src, lout, m, m, 2, BICUBIC, rot, rows)
+        got = _render(lrp, torch, lin, d_in, lout, m, m, rot, ns=ns)
+        rows = sorted({0, 1, 2, 3, 4, m // 4 - 1, m // 2 - 1, m // 2, (3 * m) // 4 + 1, m - 4, m - 3, m - 2, m - 1})
+        want = oracle.reproject_rows(lin, src, lout, m, m, ns, BICUBIC, rot, rows)
         for y in rows:
             cases.assert_same_bits(got[y], want[y], f"{in_name} -> {out_name} {deg}: row {y}")
         prev = lrp.debug_set("win_ss", 0)
-        tile = _render(lrp, torch, lin, d_in, lout, m, m, rot)
+        tile = _render(lrp, torch, lin, d_in, lout, m, m, rot, ns=ns)
         lrp.debug_set("win_ss", prev)
         assert np.array_equal(got.view(np.uint32), tile.view(np.uint32)), f"{in_name} -> {out_name}: window (SS) and tile kernels differ"
         prev = lrp.debug_kernel(0)
-        pixel = _render(lrp, torch, lin, d_in, lout, m, m, rot)
+        pixel = _render(lrp, torch, lin, d_in, lout, m, m, rot, ns=ns)
         lrp.debug_kernel(prev)
         assert np.array_equal(got.view(np.uint32), pixel.view(np.uint32)), f"{in_name} -> {out_name}: window (SS) and pixel kernels differ"

@@ -89,6 +89,9 @@ CASES = [
     # supersampling (the reference's --samples): the window kernel's SS instantiations, never the cache
     ("--samples 2 bicubic", dict(HEAD, ns=2, out_w=2048, out_h=2048), dict(family="window", wants_geo=0, quad=0, win_mode=0)),
     ("--samples 2 bicubic, win_ss 0", dict(HEAD, ns=2, **{"s.win_ss": 0}), dict(family="tile", wants_geo=0)),
+    ("--samples 3 bicubic (--scale 0.33334)", dict(HEAD, ns=3, out_w=1365, out_h=1365), dict(family="window", wants_geo=0, quad=0, win_mode=0)),
+    ("--samples 4 bicubic (--scale 0.25)", dict(HEAD, ns=4, out_w=1024, out_h=1024), dict(family="window", wants_geo=0)),
+    ("--samples 5 bicubic: the tile kernel", dict(HEAD, ns=5, out_w=819, out_h=819), dict(family="tile", wants_geo=0)),
     ("--samples 2 bilinear", dict(HEAD, ns=2, interp=BL), dict(family="tile", wants_geo=0, quad=0)),
     # where the map does not pay: a rectilinear source under a rectilinear / panorama target, nearest / bilinear
     ("rect -> equirect bilinear: four divides beat 8 B per pixel", dict(C3, channels=4, interp=BL), dict(family="tile", wants_geo=0)),
