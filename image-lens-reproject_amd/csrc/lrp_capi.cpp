@@ -373,6 +373,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
       key.in_mode = im;
       key.out_w = out->width, key.out_h = out->height, key.in_w = in->width, key.in_h = in->height;
       key.has_rot = P.has_rot;
+      key.num_samples = num_samples;
       key.out_lens = lrp::geo_canonical_lens(P.out_lens, out->lens.type), key.in_lens = lrp::geo_canonical_lens(P.in_lens, in->lens.type);
       if (P.has_rot) std::memcpy(key.rot, P.rot, sizeof(key.rot));
       lrp::geo_acquire(key, sh.geo_want_boxes, stream, &geo);

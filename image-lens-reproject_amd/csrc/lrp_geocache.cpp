@@ -284,7 +284,7 @@ void geo_acquire(const GeoKey &key, bool want_boxes, hipStream_t stream, GeoUse 
     // a new geometry
     const int need_sightings = std::max(g_min_sightings.load(std::memory_order_relaxed), d.useless_evictions >= kUselessEvictionsBeforeCaution ? 2 : 1);
     if (sightings_of(d, key) < need_sightings) return bypass();
-    const GeoLayout layout = geo_layout(key.out_w, key.out_h, true);
+    const GeoLayout layout = geo_layout(key.out_w, key.out_h, true, key.num_samples > 1 ? key.num_samples : 1);
     const size_t need = layout.bytes();
     if (g_max_bytes.load(std::memory_order_relaxed) < 0) d.largest_need = std::max(d.largest_need, need);
     const size_t cap_bytes_dev = cap_of(d);

@@ -30,6 +30,7 @@ struct GeoKey {
   int32_t out_type, in_mode; // output lens (kRect / kEquidistant / kEquirect), input mode (kIn*)
   int32_t out_w, out_h, in_w, in_h;
   int32_t has_rot;
+  int32_t num_samples; // 1; 2-4: the entry of the supersampling instantiations (a coordinate pair per sub-sample, no records)
   LensP out_lens, in_lens;
   float rot[9];
 };

@@ -162,10 +162,16 @@ inline __host__ __device__ size_t geo_lists_offset(int out_w, int out_h) { // by
   const size_t blocks = (size_t)geo_block_cols(out_w) * geo_block_rows(out_h);
   return (blocks * 32 + blocks + 255) & ~(size_t)255;
 }
-inline GeoLayout geo_layout(int out_w, int out_h, bool with_boxes) {
+// num_samples > 1 (the supersampling instantiations of the window kernel): the map holds one pair per SUB-SAMPLE, the ns^2 of a
+// pixel next to each other in the reference's order — element geo_ss_map_index — and nothing else (a block's window is planned
+// from the loaded coordinates).
+inline __host__ __device__ uint32_t geo_ss_map_index(int x, int y, int out_w, int ns2, int sub) {
+  return ((uint32_t)y * (uint32_t)out_w + (uint32_t)x) * (uint32_t)ns2 + (uint32_t)sub;
+}
+inline GeoLayout geo_layout(int out_w, int out_h, bool with_boxes, int num_samples = 1) {
   GeoLayout L{};
-  L.xy_bytes = ((size_t)out_w * (size_t)out_h * 8 + 255) & ~(size_t)255; // (the records and lists behind the map start on a 256-byte boundary)
-  if (with_boxes) {
+  L.xy_bytes = ((size_t)out_w * (size_t)out_h * (size_t)(num_samples * num_samples) * 8 + 255) & ~(size_t)255; // (the records and lists behind the map start on a 256-byte boundary)
+  if (with_boxes && num_samples == 1) {
     L.box_bytes = geo_lists_offset(out_w, out_h);
     L.list_bytes = geo_work_recs_offset(out_w, out_h) + geo_work_capacity(out_w, out_h) * 32;
   }

@@ -108,7 +108,15 @@ PlanSharing plan_sharing(const PlanRequest &r, const PlanSwitches &s, const Plan
   // batched nearest keeps the frame loop (69.4 against 72.9 us).
   const bool tile_single = !p.window && interp != kPlanBicubic && ns == 1 && (r.n_batch <= 0 || interp == kPlanBilinear) &&
                            !(interp == kPlanNearest && p.quad != 0) && !cheap_coordinates;
-  p.wants_geo = (p.window1 || tile_single) && !r.band && k == 2 && s.geo_cache != 0;
+  // The supersampling instantiations (num_samples 2-4) keep an entry of their own kind — a coordinate pair per SUB-SAMPLE, no
+  // records — written by the first launch of the geometry and read by every later one (no lens math in those); element indices
+  // are 32-bit.
+  // (not for a rectilinear view rendered into a panorama: most of that frame is out of view — corner blocks, edge rows — and its
+  // coordinates are four divides: rect -> equirect ns 2 208 us computing, 248 reading 8 bytes per sub-sample; rect -> rect gains
+  // like everybody: 176 -> 160)
+  const bool window_ss = p.window && !p.window1 && !(r.in_mode == kPlanInRect && r.out_type == kPlanEquirect) &&
+                         (long long)r.out_w * r.out_h * ns * ns < (1ll << 31);
+  p.wants_geo = (p.window1 || tile_single || window_ss) && !r.band && k == 2 && s.geo_cache != 0;
   p.geo_want_boxes = p.window1;
   return p;
 }
@@ -121,6 +129,10 @@ PlanGeo plan_geo(const PlanRequest &r, const PlanSwitches &s, const PlanSharing 
   p.geo_mode = g.mode;
   p.win_mode = 0;
   p.quad = 0; // (tile kernels: the plain path writes / the GeoRead kernels read the map)
+  if (sh.window && !sh.window1) { // an entry of sub-samples: written (1) or read (2) by the SS instantiations, nothing else applies
+    if (g.mode != 1 && g.mode != 2) p.geo_mode = 0;
+    return p;
+  }
   p.blocks_per_wave = s.geo_strip; // 0: the launcher decides
   p.rgbaz_runs = (r.out_type == kPlanEquirect && r.in_type == kPlanRect) ? 1 : 0;
   // The big-window variant (lrp_win_kernel.h kBigWin: 17.5-20 KiB of LDS per wavefront, two wavefronts per SIMD, tap DMA): a

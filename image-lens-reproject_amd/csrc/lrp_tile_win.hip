@@ -23,15 +23,19 @@ hipError_t launch_win_bicubic_geo_c5(const KParams &P, int out_idx, int in_mode,
 hipError_t launch_win_bicubic_ss_c3(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_wins3.hip
 hipError_t launch_win_bicubic_ss_c4(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_wins.hip
 hipError_t launch_win_bicubic_ss_c5(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_wins5.hip
+hipError_t launch_win_bicubic_ssg_c3(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winsg3.hip
+hipError_t launch_win_bicubic_ssg_c4(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winsg.hip
+hipError_t launch_win_bicubic_ssg_c5(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // lrp_tile_winsg5.hip
 // P.channels must be 3, 4 or 5, P.num_samples 1 to 4; P.win_mode = the mirror mode (lrp_kernel_v2.h QMode).
 // P.geo_mode == 2: the instantiations that load their coordinates from the geometry cache (plain blocks).
-// P.num_samples 2, 3, 4: the supersampling instantiations (plain blocks, no cache).
+// P.num_samples 2, 3, 4: the supersampling instantiations (plain blocks; P.geo_mode 1 / 2: they write / read an entry of sub-samples).
 hipError_t launch_win_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream) {
   using Fn = hipError_t (*)(const KParams &, int, int, hipStream_t);
   if (P.num_samples >= 2) {
     static const Fn ss_table[3] = {launch_win_bicubic_ss_c3, launch_win_bicubic_ss_c4, launch_win_bicubic_ss_c5};
-    if (P.win_mode != 0 || P.geo_mode != 0) return hipErrorInvalidValue;
-    return ss_table[P.channels - 3](P, out_idx, in_mode, stream);
+    static const Fn ssg_table[3] = {launch_win_bicubic_ssg_c3, launch_win_bicubic_ssg_c4, launch_win_bicubic_ssg_c5};
+    if (P.win_mode != 0 || P.geo_mode == 3) return hipErrorInvalidValue;
+    return (P.geo_mode == 2 ? ssg_table : ss_table)[P.channels - 3](P, out_idx, in_mode, stream); // (2: the entry of sub-samples is read)
   }
   if (P.geo_mode == 2) {
     static const Fn geo_table[3] = {launch_win_bicubic_geo_c3, launch_win_bicubic_geo_c4, launch_win_bicubic_geo_c5};

@@ -93,7 +93,9 @@ __device__ unsigned g_tier_stats[8]; // coefficient, raw, direct, corner, beyond
 // pixel are summed in the reference's order (0.0f + s0 + s1 + ..., :334-336) by a chain of ns^2 - 1 DPP steps — step t: every
 // lane adds its sample to the sum its left neighbour holds (wave_shr:1), so that after it the lane of sub-sample t holds
 // 0 + s0 + ... + st — and the pixel's last lane stores sum * (1 / ns^2) (:338-341).  Plain blocks that compute their
-// coordinates; no geometry cache (its map holds one coordinate pair per pixel), no frame loop.
+// coordinates and, as a side output, write them into a geometry-cache entry of their own kind (one pair per sub-sample, the
+// ns^2 of a pixel next to each other: a pass loads 512 contiguous bytes); GeoRead + SS: the instantiation that loads them — no
+// lens math — and plans its windows from the loaded values.  No frame loop.
 template <int OutLens, int InMode, int QMode, int CH, bool Frames = false, bool GeoRead = false, bool SS = false>
 #ifndef LRP_WIN_MINWAVES5
 #define LRP_WIN_MINWAVES5 3 // RGBAZ: 168 VGPRs (the 80 registers of a direct-path tap set do not fit 128 without spilling)
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   constexpr int kAllMirrors = (MirX ? 1 : 0) | (MirY ? 2 : 0); // the image mirrored in every mirrored axis
   using WinBlock = WinBlockT<Quad>;
   static_assert(CH == 3 || CH == 4 || CH == 5, "window kernel: RGB, RGBA or RGBAZ");
-  static_assert(!SS || (QMode == 0 && !Frames && !GeoRead), "supersampling: plain blocks that compute their coordinates");
+  static_assert(!SS || (QMode == 0 && !Frames), "supersampling: plain blocks, no frame loop");
   constexpr int kBlockRows = SS ? 4 : kBlkH; // output rows of a block (SS: a pass is ONE output row)
   static_assert(QMode != 2 || (OutLens != kEquidistant && InMode != kInEquidistant), "rows-only mirroring goes through the column-separable source x");
   static_assert(QMode != 3 || OutLens == kRect, "columns-only mirroring needs vz == -1");
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
 #define LRP_BIG_PASSCOLS 64 // (128 — two DMA instructions per row for the wider ones — measured 1 % slower once such passes can fetch their taps instead)
 #endif
   constexpr int kMaxPassCols = kBigWin ? LRP_BIG_PASSCOLS : 64; // widest pass window (texels): DMA instructions per window row = ceil(bw / 64)
-  constexpr bool kGeoWrite = !GeoRead && !Frames && QMode == 0 && kWinWaves == 1 && !SS; // (P.geo_mode == 1: the side output)
+  constexpr bool kGeoWrite = !GeoRead && !Frames && QMode == 0 && kWinWaves == 1; // (P.geo_mode == 1: the side output)
   const bool geo_write = kGeoWrite && (Pk.geo_mode == 1 || Pk.geo_mode == 3) && blockIdx.y == 0; // wave-uniform (3: the extremes only — the map is there; a batched launch: its first frame writes)
   // Frames of a batched launch share one geometry: the source coordinates of a pixel, the window of a block and its tier
   // are the same in every frame.  A wavefront therefore renders its strip for `frames_per_wave` consecutive frames
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   // blocks this strip renders.  (A block wholly below the image re-renders the image's last row — every lane stores — which is
   // how the compute kernels keep their store count.  GeoRead skips such blocks: the entry holds extremes only for the block
   // rows the WRITING launch walked, and that launch may have cut its strips differently.)
-  const int G = GeoRead ? min(Gs, (P.y_end - P.y_offset + kBlkH - 1) / kBlkH - ty * Gs) : Gs;
+  const int G = GeoRead ? min(Gs, (P.y_end - P.y_offset + kBlockRows - 1) / kBlockRows - ty * Gs) : Gs;
   auto block_row = [&](int g) { return (kAliasPairs && g_reverse) ? G - 1 - g : g; }; // block of a plain strip rendered by iteration g
   // ... and its class byte (lrp_params.h)
   auto geo_classes = [&]() { return reinterpret_cast<uint8_t *>(P.geo_box) + geo_class_offset(P.out_w, P.out_h); };
@@ -463,6 +465,68 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
       asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(plan) : "s"(v[i]), "n"(i));
   };
 
+  // The window of a block whose coordinates b.sx / b.sy are known (computed by coords() below, or — GeoRead + SS — loaded):
+  // per-pixel exactness, wave-wide extremes, the plan; a launch that fills a geometry-cache entry writes its side output here.
+  auto plan_from_coords = [&](int g, WinBlock &b) {
+    Extremes e;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) note_pixel(e, k, b.sx[k], b.sy[k]);
+    bool all_exact_x, all_exact_y;
+    if constexpr (kEdge) { // per axis: a block beyond one side of the source has no exact taps along that axis and needs none
+      all_exact_x = wave_all(e.exact_x != 0);
+      all_exact_y = wave_all(e.exact_y != 0);
+      if (!(all_exact_x && all_exact_y)) { // the precise test, for the stripe of blocks next to a power-of-two coordinate
+        int ok_x = 1, ok_y = 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          ok_x &= taps_consecutive(b.sx[k], 2.0f);
+          ok_y &= taps_consecutive(b.sy[k], 2.0f);
+        }
+        all_exact_x = wave_all(ok_x != 0);
+        all_exact_y = wave_all(ok_y != 0);
+      }
+    } else {
+      bool all_exact = wave_all((e.exact_x & e.exact_y) != 0);
+      if (!all_exact) { // the precise test, for the stripe of blocks next to a power-of-two coordinate
+        int ok = 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ok &= taps_consecutive(b.sx[k], 2.0f) & taps_consecutive(b.sy[k], 2.0f);
+        all_exact = wave_all(ok != 0);
+      }
+      all_exact_x = all_exact_y = all_exact;
+    }
+    const bool planned = kEdge ? true : (all_exact_x && all_exact_y);
+    if (planned) {
+      wave_box(e.lo_x, e.hi_x, e.lo_y[0], e.hi_y[0], e.lo_y[1], e.hi_y[1]);
+      plan_window(b, e.lo_x, e.hi_x, e.lo_y[0], e.hi_y[0], e.lo_y[1], e.hi_y[1], all_exact_x, all_exact_y);
+    }
+    if constexpr (kGeoWrite) {
+      if (geo_write) { // side output: this block's coordinates and the extremes its window was planned from
+        vf2 *const map = reinterpret_cast<vf2 *>(P.geo_xy);
+        if (Pk.geo_mode == 1) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int yk = pixel_row(g, k);
+            const int ye = yk < qh ? yk : qh - 1;
+            // (lanes / rows beyond the image hold the pixel they were clamped to and write its values to its place again)
+            if constexpr (SS)
+              map[geo_ss_map_index(xe, ye, P.out_w, ss_n, ss_x * ss_ns + ss_y)] = vf2{b.sx[k], b.sy[k]};
+            else
+              map[geo_map_index(xe, ye, P.out_w)] = vf2{b.sx[k], b.sy[k]};
+          }
+        }
+        if constexpr (SS) return; // (an entry of sub-samples holds the map only: the reading launch plans from the loaded coordinates)
+        const int words[7] = {planned ? e.lo_x : 0, planned ? e.hi_x : 0, planned ? e.lo_y[0] : 0, planned ? e.hi_y[0] : 0,
+                              planned ? e.lo_y[1] : 0, planned ? e.hi_y[1] : 0,
+                              (all_exact_x ? 1 : 0) | (all_exact_y ? 2 : 0) | (planned ? 4 : 0)};
+        int bv = 0; // lane i = word i (written once per geometry: plain selects will do)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) bv = lane == i ? words[i] : bv;
+        if (lane < 8) P.geo_box[geo_block(g) * 8u + (uint32_t)lane] = bv;
+        if (lane == 0) geo_classes()[geo_class_index(g)] = (uint8_t)(planned ? b.corner() : 0);
+      }
+    }
+  };
   // phase A of block g: coordinates, interior vote, window box
   auto coords = [&](int g, WinBlock &b) {
     // the four row terms first, all loads in flight together (one exposed latency per
@@ -537,7 +601,6 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
         return;
       }
     }
-    Extremes e;
     // (plain blocks: everything derived from the column terms alone — their products with the rotation matrix, the
     // column's share of the source lens — is loop-invariant, gets hoisted out of the block loop and then spilled to scratch
     // for the whole kernel: 80-100 MB of scratch traffic per 4K frame.  Opaque here, those few multiplies run per block.)
@@ -551,74 +614,24 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
         pixel_source_rt<OutLens, InMode>(P, col_g, row_v[k], ye, ss_y, b.sx[k], b.sy[k]);
       else
         quad_xy(gm, k, b.sx[k], b.sy[k]);
-      note_pixel(e, k, b.sx[k], b.sy[k]);
       // (shared rays: one pixel's rotation + source lens after the other — interleaved they do not fit the registers)
       if constexpr (kSharedRays) __builtin_amdgcn_sched_barrier(0);
     }
-    bool all_exact_x, all_exact_y;
-    if constexpr (kEdge) { // per axis: a block beyond one side of the source has no exact taps along that axis and needs none
-      all_exact_x = wave_all(e.exact_x != 0);
-      all_exact_y = wave_all(e.exact_y != 0);
-      if (!(all_exact_x && all_exact_y)) { // the precise test, for the stripe of blocks next to a power-of-two coordinate
-        int ok_x = 1, ok_y = 1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          ok_x &= taps_consecutive(b.sx[k], 2.0f);
-          ok_y &= taps_consecutive(b.sy[k], 2.0f);
-        }
-        all_exact_x = wave_all(ok_x != 0);
-        all_exact_y = wave_all(ok_y != 0);
-      }
-    } else {
-      bool all_exact = wave_all((e.exact_x & e.exact_y) != 0);
-      if (!all_exact) { // the precise test, for the stripe of blocks next to a power-of-two coordinate
-        int ok = 1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ok &= taps_consecutive(b.sx[k], 2.0f) & taps_consecutive(b.sy[k], 2.0f);
-        all_exact = wave_all(ok != 0);
-      }
-      all_exact_x = all_exact_y = all_exact;
-    }
-    const bool planned = kEdge ? true : (all_exact_x && all_exact_y);
-    if (planned) {
-      wave_box(e.lo_x, e.hi_x, e.lo_y[0], e.hi_y[0], e.lo_y[1], e.hi_y[1]);
-      plan_window(b, e.lo_x, e.hi_x, e.lo_y[0], e.hi_y[0], e.lo_y[1], e.hi_y[1], all_exact_x, all_exact_y);
-    }
-    if constexpr (kGeoWrite) {
-      if (geo_write) { // side output: this block's coordinates and the extremes its window was planned from
-        vf2 *const map = reinterpret_cast<vf2 *>(P.geo_xy);
-        if (Pk.geo_mode == 1) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int yk = y_lane + kBlkH * block_row(g) + kPassRows * k;
-            const int ye = yk < qh ? yk : qh - 1;
-            // (lanes / rows beyond the image hold the pixel they were clamped to and write its values to its place again)
-            map[geo_map_index(xe, ye, P.out_w)] = vf2{b.sx[k], b.sy[k]};
-          }
-        }
-        const int words[7] = {planned ? e.lo_x : 0, planned ? e.hi_x : 0, planned ? e.lo_y[0] : 0, planned ? e.hi_y[0] : 0,
-                              planned ? e.lo_y[1] : 0, planned ? e.hi_y[1] : 0,
-                              (all_exact_x ? 1 : 0) | (all_exact_y ? 2 : 0) | (planned ? 4 : 0)};
-        int bv = 0; // lane i = word i (written once per geometry: plain selects will do)
-#pragma unroll
-        for (int i = 0; i < 7; ++i) bv = lane == i ? words[i] : bv;
-        if (lane < 8) P.geo_box[geo_block(g) * 8u + (uint32_t)lane] = bv;
-        if (lane == 0) geo_classes()[geo_class_index(g)] = (uint8_t)(planned ? b.corner() : 0);
-      }
-    }
+    plan_from_coords(g, b);
   };
   // GeoRead: the coordinates of block g and (geo_boxv, lane i = word i) its window extremes are requested by geo_fetch and
   // turned into a window plan by geo_plan, a few hundred instructions later
   int geo_boxv = 0;
   auto geo_fetch = [&](int g, WinBlock &b) {
     // (the extremes first: loads return in order, and the first block of a strip plans its window before anything else)
-    if (!(kListRec && have_list_rec)) geo_boxv = __builtin_nontemporal_load(P.geo_box + (geo_block(g) * 8u + (uint32_t)(lane & 7)));
+    if constexpr (!SS)
+      if (!(kListRec && have_list_rec)) geo_boxv = __builtin_nontemporal_load(P.geo_box + (geo_block(g) * 8u + (uint32_t)(lane & 7)));
     const vf2 *const map = reinterpret_cast<const vf2 *>(P.geo_xy);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int yk = y_lane + kBlkH * block_row(g) + kPassRows * k;
+      const int yk = pixel_row(g, k);
       const int ye = yk < qh ? yk : qh - 1;
-      const vf2 v = __builtin_nontemporal_load(map + geo_map_index(xe, ye, P.out_w));
+      const vf2 v = __builtin_nontemporal_load(map + (SS ? geo_ss_map_index(xe, ye, P.out_w, ss_n, ss_x * ss_ns + ss_y) : geo_map_index(xe, ye, P.out_w)));
       b.sx[k] = v.x;
       b.sy[k] = v.y;
     }
@@ -646,8 +659,12 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
     if constexpr (kGeoClasses) return (int)((strip_classes >> (8u * (uint32_t)block_row(g))) & 7u);
     return 0;
   };
-  auto geo_plan = [&](WinBlock &b, int cls) {
+  auto geo_plan = [&](WinBlock &b, int cls, int g_of_b) {
     clear_block(b);
+    if constexpr (SS) { // (no records in an entry of sub-samples: the extremes come from the loaded coordinates)
+      plan_from_coords(g_of_b, b);
+      return;
+    }
     if (cls != 0) {
       b.tier = cls << 3;
       return;
@@ -898,7 +915,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   if constexpr (GeoRead) {
     const int cls0 = geo_class(0);
     if (cls0 == 0) geo_fetch(0, cur);
-    geo_plan(cur, cls0);
+    geo_plan(cur, cls0, 0);
   } else {
     coords(0, cur);
   }
@@ -968,16 +985,40 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
       // sum up to and including st, whatever the lanes of later sub-samples hold meanwhile.
       const Px<CH> sp{s.lo, CH >= 4 ? s.hi : f2{0.0f, 0.0f}, CH == 3 ? s.hi.x : s.e};
       Px<CH> a = (ss_x | ss_y) == 0 ? accumulate(s) : sp;
-      auto from_left = [](float v) { return u2f((uint32_t)__builtin_amdgcn_update_dpp((int)f2u(v), (int)f2u(v), 0x138 /* wave_shr:1 */, 0xF, 0xF, false)); };
+      // One VOP2 add with a DPP operand per component and step (as a move + a packed add it is six instructions per step
+      // instead of four: num_samples 4 runs fifteen steps per pass).  A DPP operand written by the previous VALU instruction
+      // needs two wait states: the s_nop in front of a step's first add; the step's other adds keep a component's add of step
+      // t + 1 at least two instructions behind its add of step t.
+      float a0 = a.lo.x, a1 = a.lo.y, a2 = CH >= 4 ? a.hi.x : a.e, a3 = CH >= 4 ? a.hi.y : 0.0f, a4 = CH == 5 ? a.e : 0.0f;
+      const float s0 = sp.lo.x, s1 = sp.lo.y, s2 = CH >= 4 ? sp.hi.x : sp.e, s3 = CH >= 4 ? sp.hi.y : 0.0f, s4 = CH == 5 ? sp.e : 0.0f;
 #pragma unroll 1
       for (int t = 1; t < ss_n; ++t) {
-        Px<CH> b;
-        b.lo = f2{from_left(a.lo.x), from_left(a.lo.y)};
-        b.hi = CH >= 4 ? f2{from_left(a.hi.x), from_left(a.hi.y)} : f2{0.0f, 0.0f};
-        b.e = CH != 4 ? from_left(a.e) : 0.0f;
-        px_add<CH>(b, sp);
-        a = b;
+        if constexpr (CH == 3)
+          asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                       "v_add_f32_dpp %1, %1, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                       "v_add_f32_dpp %2, %2, %5 wave_shr:1 row_mask:0xf bank_mask:0xf"
+                       : "+v"(a0), "+v"(a1), "+v"(a2)
+                       : "v"(s0), "v"(s1), "v"(s2));
+        else if constexpr (CH == 4)
+          asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                       "v_add_f32_dpp %1, %1, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                       "v_add_f32_dpp %2, %2, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                       "v_add_f32_dpp %3, %3, %7 wave_shr:1 row_mask:0xf bank_mask:0xf"
+                       : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+                       : "v"(s0), "v"(s1), "v"(s2), "v"(s3));
+        else
+          asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                       "v_add_f32_dpp %1, %1, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                       "v_add_f32_dpp %2, %2, %7 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                       "v_add_f32_dpp %3, %3, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                       "v_add_f32_dpp %4, %4, %9 wave_shr:1 row_mask:0xf bank_mask:0xf"
+                       : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4)
+                       : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4));
       }
+      a.lo = f2{a0, a1};
+      if constexpr (CH >= 4) a.hi = f2{a2, a3};
+      if constexpr (CH == 3) a.e = a2;
+      if constexpr (CH == 5) a.e = a4;
       if (ss_owner && ss_inside(g, k)) {
         const PassOut o = pass_out(g, k);
         store_px<CH, false>(P, (uint32_t)o.yo * (uint32_t)P.out_w + (uint32_t)o.xo, a);
@@ -1254,7 +1295,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
       const Rgba cs = corner_value(cur);
       if (Quad && !kSharedRays && last_frame && g + 1 < G) coords(g + 1, nxt);
       if constexpr (GeoRead)
-        if (g + 1 < G && last_frame) geo_plan(nxt, geo_class(g + 1));
+        if (g + 1 < G && last_frame) geo_plan(nxt, geo_class(g + 1), g + 1);
       emit_corner(g, cs, [&]() { next_window(); });
       if (!dma_early && has_next()) issue_next();
       if (last_frame) cur = nxt;
@@ -1281,7 +1322,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
         bool behind_store = true; // what this pass reads was requested behind the previous pass's store: nothing younger in flight
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) {
-          if (k == 3 && g + 1 < G && last_frame) geo_plan(nxt, geo_class(g + 1));
+          if (k == 3 && g + 1 < G && last_frame) geo_plan(nxt, geo_class(g + 1), g + 1);
           const float psx = pass_x(k), psy = pass_y(k);
           if constexpr (!kPipeline) { // planned, requested, waited for and read on the spot
             const bool last_pass = k == 3;
@@ -1372,7 +1413,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
         const int k = 2 * h + kk;
         if (Quad && !kSharedRays && k == 3 && last_frame && g + 1 < G) coords(g + 1, nxt); // only its box is kept
         if constexpr (GeoRead)
-          if (k == 3 && g + 1 < G && last_frame) geo_plan(nxt, geo_class(g + 1));
+          if (k == 3 && g + 1 < G && last_frame) geo_plan(nxt, geo_class(g + 1), g + 1);
         const bool last_pass = k == 3;
         float psx = kk == 0 ? hx0 : hx1, psy = kk == 0 ? hy0 : hy1;
         if constexpr (Quad && !kSharedRays) quad_xy(image_of(g), k, psx, psy); // re-derived (2-4 instructions) instead of held in registers
@@ -1520,15 +1561,25 @@ template <int CH> struct WinSSKernelTable {
   }
 };
 
+// ... and the ones that read an entry of sub-samples from the geometry cache: one per source mode.
+template <int CH> struct WinSSGeoKernelTable {
+  static TileKernelFn get(int in_mode) {
+    static const TileKernelFn table[4] = {
+        reproject_bicubic_win_kernel<kRect, kInRect, 0, CH, false, true, true>, reproject_bicubic_win_kernel<kRect, kInEquidistant, 0, CH, false, true, true>,
+        reproject_bicubic_win_kernel<kRect, kInEquirect, 0, CH, false, true, true>, reproject_bicubic_win_kernel<kRect, kInEquirectLoop, 0, CH, false, true, true>};
+    return table[in_mode];
+  }
+};
+
 // num_samples must be 1 — or 2, 3, 4 for the SS launcher (a lane per sub-sample).
 // QMode != 0: P.win_mode == QMode, set by the host only for cells where the mode exists.  GeoRead: P.geo_mode == 2, a single
 // whole-image launch.
 template <int QMode, int CH, bool GeoRead = false, bool SS = false>
 inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, hipStream_t stream) {
   static_assert(!GeoRead || QMode == 0, "the geometry cache feeds plain blocks");
-  static_assert(!SS || (QMode == 0 && !GeoRead), "supersampling: plain blocks that compute");
+  static_assert(!SS || QMode == 0, "supersampling: plain blocks");
   if (GeoRead && (P.geo_mode != 2 || P.y_offset != 0 || P.y_end != P.out_h)) return hipErrorInvalidValue;
-  if ((SS ? (P.num_samples < 2 || P.num_samples > 4) : P.num_samples != 1) || (SS && P.geo_mode != 0)) return hipErrorInvalidValue;
+  if ((SS ? (P.num_samples < 2 || P.num_samples > 4) : P.num_samples != 1) || (SS && !GeoRead && P.geo_mode != 0 && P.geo_mode != 1)) return hipErrorInvalidValue;
   constexpr int kRowsPerBlock = SS ? kPassRows : kBlkH; // output rows of a block
   const int rows = P.y_end - P.y_offset;
   if (QMode != 0) {
@@ -1548,14 +1599,14 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
 #define LRP_SS_STRIP 4
 #endif
     int G = SS ? LRP_SS_STRIP : LRP_WIN_STRIP; // (SS: a block is four rows of pixels; strips of sixteen rows like everybody's)
-    if (GeoRead && P.blocks_per_wave > 0) G = std::min(P.blocks_per_wave, kGeoStripRows); // the caller's override (lrp_debug_set "geo_strip")
+    if (GeoRead && !SS && P.blocks_per_wave > 0) G = std::min(P.blocks_per_wave, kGeoStripRows); // the caller's override (lrp_debug_set "geo_strip")
     // (a batch whose wavefronts walk several frames pipelines the windows of one block across its frames: one block per
     // wavefront measured 2-3 % faster there — equirect -> fisheye rotated 143 -> 139 us, rect -> rect 130.5 -> 128 —, four 5 % slower)
     if (P.batch_n > 1 && !(out_idx == 2 && in_mode == kInRect)) G = 1;
-    const bool strip_forced = GeoRead && P.blocks_per_wave > 0;
+    const bool strip_forced = GeoRead && !SS && P.blocks_per_wave > 0;
     // (a rectilinear source under a rectilinear / fisheye target: half of the blocks are corner blocks, the rest wait for
     // gathers or edge rows — single blocks balance the launch: rect -> fisheye single launches 164 -> 154 us)
-    if (GeoRead && !strip_forced && in_mode == kInRect && P.big_windows == 0 && P.batch_n <= 1) G = 1;
+    if (GeoRead && !SS && !strip_forced && in_mode == kInRect && P.big_windows == 0 && P.batch_n <= 1) G = 1;
     // >= 2 rounds of wavefronts; the launches that read the geometry cache >= 4 (their wavefronts differ more in what a block
     // costs them — nothing is computed, everything is waited for: pole face of the 8192^2 -> 2048^2 cubemap 107.5 -> 98.4 us)
     const long long min_waves = GeoRead ? 16384 : 8192;
@@ -1586,7 +1637,9 @@ inline hipError_t launch_win_bicubic_impl(KParams P, int out_idx, int in_mode, h
     groups = (P.batch_n + F - 1) / F;
   }
   TileKernelFn fn;
-  if constexpr (SS)
+  if constexpr (SS && GeoRead)
+    fn = WinSSGeoKernelTable<CH>::get(in_mode);
+  else if constexpr (SS)
     fn = WinSSKernelTable<CH>::get(out_idx, in_mode);
   else if constexpr (GeoRead)
     fn = P.frames_per_wave > 1 ? WinGeoFramesKernelTable<CH>::get(in_mode) : WinGeoKernelTable<CH>::get(in_mode, P.big_windows != 0);

@@ -15,8 +15,19 @@ import cases
 import golden_cases
 
 pytestmark = pytest.mark.gpu
+USES_GEO_CACHE = True  # (the product's default: the first launch of a geometry fills an entry of sub-samples, later launches read it)
 
 BICUBIC = 2
+
+
+@pytest.fixture(autouse=True)
+def _fresh_cache(lrp):
+    lrp.debug_set("geo_cache", 1)
+    lrp.geometry_cache_configure(1 << 30, 1)
+    lrp.release_cached_tables()
+    yield
+    lrp.geometry_cache_configure(1 << 30, 1)
+    lrp.release_cached_tables()
 
 
 def _render(lrp, torch, lin, d_in, lout, ow, oh, rot, post=None, ns=2):
@@ -46,7 +57,15 @@ def test_every_lens_pair_against_the_live_oracle(lrp, oracle, torch_cuda, channe
                 want = oracle.post_process(want, *post)
             d_in = torch.from_numpy(src).cuda()
             what = f"{in_name} {iw}x{ih} -> {out_name} {ow}x{oh} C={channels} ns={ns} {rot_name} post={post}"
-            cases.assert_same_bits(_render(lrp, torch, lin, d_in, lout, ow, oh, rot, post, ns=ns), want, "window kernel (SS), " + what)
+            fills0, hits0 = (lrp.geometry_cache_stats()[key] for key in ("fills", "hits"))
+            cases.assert_same_bits(_render(lrp, torch, lin, d_in, lout, ow, oh, rot, post, ns=ns), want, "window kernel (SS), the launch that fills the entry of sub-samples, " + what)
+            cases.assert_same_bits(_render(lrp, torch, lin, d_in, lout, ow, oh, rot, post, ns=ns), want, "window kernel (SS), a launch that reads it, " + what)
+            stats = lrp.geometry_cache_stats()
+            cached = 0 if (in_name.startswith("rect") and out_name.startswith("eqr")) else 1  # (a rectilinear view into a panorama computes: lrp_plan.cpp)
+            assert stats["fills"] == fills0 + cached and stats["hits"] == hits0 + cached, what
+            prev_geo = lrp.debug_set("geo_cache", 0)
+            cases.assert_same_bits(_render(lrp, torch, lin, d_in, lout, ow, oh, rot, post, ns=ns), want, "window kernel (SS), cache off, " + what)
+            lrp.debug_set("geo_cache", prev_geo)
             prev = lrp.debug_set("win_ss", 0)
             cases.assert_same_bits(_render(lrp, torch, lin, d_in, lout, ow, oh, rot, post, ns=ns), want, "tile kernel, " + what)
             lrp.debug_set("win_ss", prev)
@@ -93,7 +112,9 @@ def test_downscale_4k_whole_frame_rows(lrp, oracle, torch_cuda, ns, m):
     for in_name, out_name, deg in (("eqd180", "rect", None), ("eqr_full", "rect", (30.0, -15.0, 5.0)), ("rect", "eqr_full", (0.0, 0.0, 0.0))):
         lin, lout = cases.lenses(lrp, n, n)[in_name], cases.lenses(lrp, m, m)[out_name]
         rot = cases.rotation(lrp, deg)
-        got = _render(lrp, torch, lin, d_in, lout, m, m, rot, ns=ns)
+        first = _render(lrp, torch, lin, d_in, lout, m, m, rot, ns=ns)  # fills the entry of sub-samples
+        got = _render(lrp, torch, lin, d_in, lout, m, m, rot, ns=ns)    # reads it
+        assert np.array_equal(got.view(np.uint32), first.view(np.uint32)), f"{in_name} -> {out_name}: the filling and the reading launch differ"
         rows = sorted({0, 1, 2, 3, 4, m // 4 - 1, m // 2 - 1, m // 2, (3 * m) // 4 + 1, m - 4, m - 3, m - 2, m - 1})
         want = oracle.reproject_rows(lin, src, lout, m, m, ns, BICUBIC, rot, rows)
         for y in rows:

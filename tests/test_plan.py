@@ -87,10 +87,18 @@ CASES = [
     ("... mirror modes off", dict(POLE, **{"s.geo_cache": 0, "s.mirror_modes": 0}), dict(win_mode=0)),
     ("an equidistant source never takes the variant by census", dict(HEAD, **{"g.mode": 2, "g.lists": 1, "g.n_inview": 100, "g.n_wide": 100}), dict(big_windows=0)),
     # supersampling (the reference's --samples): the window kernel's SS instantiations, never the cache
-    ("--samples 2 bicubic", dict(HEAD, ns=2, out_w=2048, out_h=2048), dict(family="window", wants_geo=0, quad=0, win_mode=0)),
+    ("--samples 2 bicubic, first call: fills an entry of sub-samples", dict(HEAD, ns=2, out_w=2048, out_h=2048, **{"g.mode": 1}),
+     dict(family="window", wants_geo=1, geo_want_boxes=0, geo_mode=1, quad=0, win_mode=0, big_windows=0, listed=0)),
+    ("--samples 2 bicubic, later calls read it", dict(HEAD, ns=2, out_w=2048, out_h=2048, **{"g.mode": 2, "g.lists": 1, "g.n_inview": 9, "g.n_wide": 9}),
+     dict(family="window", geo_mode=2, big_windows=0, listed=0, blocks_per_wave=0)),
+    ("--samples 2 bicubic, rect -> equirect: cheap coordinates are computed, not loaded", dict(C3, channels=4, ns=2, out_w=2048, out_h=2048, **{"g.mode": 2}), dict(family="window", wants_geo=0, geo_mode=0)),
+    ("--samples 2 bicubic, rect -> rect reads its entry like everybody", dict(out_type=RECT, in_type=RECT, in_mode=IN_RECT, ns=2, out_w=2048, out_h=2048, **{"g.mode": 2}), dict(family="window", wants_geo=1, geo_mode=2)),
+    ("--samples 2 bicubic, cache off", dict(HEAD, ns=2, out_w=2048, out_h=2048, **{"s.geo_cache": 0, "g.mode": 2}), dict(family="window", wants_geo=0, geo_mode=0)),
+    ("--samples 2 bicubic, a row band", dict(HEAD, ns=2, out_w=2048, out_h=2048, band=1), dict(family="window", wants_geo=0)),
+    ("--samples 4 of a huge output: 2^31 sub-samples and more are not cached", dict(HEAD, ns=4, out_w=16384, out_h=8192), dict(family="window", wants_geo=0)),
     ("--samples 2 bicubic, win_ss 0", dict(HEAD, ns=2, **{"s.win_ss": 0}), dict(family="tile", wants_geo=0)),
-    ("--samples 3 bicubic (--scale 0.33334)", dict(HEAD, ns=3, out_w=1365, out_h=1365), dict(family="window", wants_geo=0, quad=0, win_mode=0)),
-    ("--samples 4 bicubic (--scale 0.25)", dict(HEAD, ns=4, out_w=1024, out_h=1024), dict(family="window", wants_geo=0)),
+    ("--samples 3 bicubic (--scale 0.33334)", dict(HEAD, ns=3, out_w=1365, out_h=1365, **{"g.mode": 2}), dict(family="window", wants_geo=1, geo_mode=2, quad=0, win_mode=0)),
+    ("--samples 4 bicubic (--scale 0.25)", dict(HEAD, ns=4, out_w=1024, out_h=1024, **{"g.mode": 1}), dict(family="window", wants_geo=1, geo_mode=1)),
     ("--samples 5 bicubic: the tile kernel", dict(HEAD, ns=5, out_w=819, out_h=819), dict(family="tile", wants_geo=0)),
     ("--samples 2 bilinear", dict(HEAD, ns=2, interp=BL), dict(family="tile", wants_geo=0, quad=0)),
     # where the map does not pay: a rectilinear source under a rectilinear / panorama target, nearest / bilinear
