@@ -50,6 +50,7 @@ const Option kOptions[] = {
     {"dry-run", 0, false, nullptr, "", "Do not reproject; only create the output directory.", "Runtime"},
     {"device", 0, true, "0", "index", "First GPU to use (MI355X addition).", "Runtime"},
     {"gpus", 0, true, "1", "count", "Spread the file list over this many GPUs, contiguous blocks (MI355X addition).", "Runtime"},
+    {"streams", 0, true, "0", "count", "Images in flight per GPU: upload, kernel and download of consecutive images overlap (0: one more than the GPU's share of -j, at least 3; MI355X addition).", "Runtime"},
     {"help", 'h', false, nullptr, "", "Show help.", "Runtime"},
 };
 

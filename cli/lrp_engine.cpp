@@ -205,7 +205,9 @@ RunResult run_files(const RunPlan &plan, const std::vector<fs::path> &files) {
     if (needs_gpu) {
       const int on_this_device = (workers - g + gpus - 1) / gpus; // workers t with t % gpus == g
       // one slot more than images in flight: a slot is only re-used after its owner has collected its ticket
-      if (lrp_context_create(&devices[(size_t)g].pipeline, devices[(size_t)g].index, std::max(3, on_this_device + 1)) != LRP_OK) {
+      // (--streams asks for more — never fewer: a worker that found no free slot would wait for its own ticket)
+      const int slots = std::max({3, on_this_device + 1, plan.streams});
+      if (lrp_context_create(&devices[(size_t)g].pipeline, devices[(size_t)g].index, std::min(64, slots)) != LRP_OK) {
         std::printf("Error: %s: %s\n", "cannot create the GPU pipeline", lrp_last_error());
         for (Device &d : devices) lrp_context_destroy(d.pipeline);
         result.aborted = true;

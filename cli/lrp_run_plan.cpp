@@ -132,6 +132,7 @@ int resolve_io(const CommandLine &cl, const char *argv0, RunPlan &p) {
   p.workers = std::max(1, std::atoi(cl["parallel"].c_str()));
   p.first_device = std::atoi(cl["device"].c_str());
   p.gpus = std::max(1, std::atoi(cl["gpus"].c_str()));
+  p.streams = std::max(0, std::min(64, std::atoi(cl["streams"].c_str())));
   return 0;
 }
 

@@ -38,6 +38,7 @@ struct RunPlan {
   std::string output_config_path;
   // execution
   int workers = 1, first_device = 0, gpus = 1;
+  int streams = 0; // image slots of a GPU's pipeline (--streams; 0: automatic)
 
   bool post_process() const { return exposure != 1.0 || reinhard != 1.0; } // src/main.cpp:601
   bool copies_pixels() const { return !reproject && scale == 1.0; }        // :592-595

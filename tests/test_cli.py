@@ -62,6 +62,8 @@ def test_help_lists_every_reference_flag(cli):
                  "--no-reproject", "--rectilinear", "--equisolid", "--equidistant", "--equirectangular", "--rotation",
                  "--exposure", "--reinhard", "--skip-if-exists", "--parallel", "--dry-run", "--help"):
         assert flag in r.stdout, flag
+    for flag in ("--device", "--gpus", "--streams"):  # the MI355X additions of SURVEY 8f (f2), beside the reference's set
+        assert flag in r.stdout, flag
 
 
 @pytest.mark.parametrize("args,message", [
@@ -390,6 +392,26 @@ def test_gpus_flag_splits_the_sorted_list_into_blocks(cli, lrp, torch_cuda, tmp_
         assert (tmp_path / "one" / f"f{i}.png").read_bytes() == (tmp_path / "two" / f"f{i}.png").read_bytes()
     if torch_cuda.cuda.device_count() < 2:
         pytest.skip("one visible device: --gpus 2 was clamped to 1 (outputs verified)")
+
+
+@pytest.mark.gpu
+def test_streams_flag_changes_nothing_but_the_images_in_flight(cli, torch_cuda, tmp_path):
+    """--streams N: image slots of a GPU's pipeline — upload, kernel and download of consecutive images overlap.
+    Seven files with 1, 2 and 8 slots asked for (fewer than the pipeline needs are raised) and -j 3: byte-identical outputs."""
+    from PIL import Image
+
+    rng = np.random.default_rng(7)
+    src = tmp_path / "in"
+    src.mkdir()
+    for i in range(7):
+        Image.fromarray(rng.integers(0, 256, (48, 96, 3), dtype=np.uint8), "RGB").save(src / f"f{i:02d}.png")
+    common = ["-i", src, "--png", "--no-configs", "96,48", "--i-equirectangular", "full", "--rectilinear", "18,36", "--rotation", "30,-15,5", "-j", "3"]
+    outs = {}
+    for n in ("0", "1", "2", "8"):
+        r = run(cli, *common, "-o", tmp_path / f"o{n}", "--streams", n)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[n] = [(tmp_path / f"o{n}" / f"f{i:02d}.png").read_bytes() for i in range(7)]
+    assert outs["0"] == outs["1"] == outs["2"] == outs["8"]
 
 
 @pytest.mark.gpu
