@@ -74,19 +74,25 @@ WORKLOADS = {
     "rect_to_equirect_bicubic": dict(in_lens="rect", out_lens="eqr", interp=2, rot=(0.0, 0.0, 0.0), channels=4,
                                      size=4096),
     # the reference's --samples 2 on the down-scale its README asks it for (src/reproject.cpp:294-298): 4096^2 -> 2048^2, four
-    # sub-samples per pixel through the window kernel's SS instantiations
+    # sub-samples per pixel through the window kernel's SS instantiations (a lane per sub-sample; an entry of sub-samples in the
+    # geometry cache)
     "fisheye_to_rect_bicubic_half_ns2": dict(in_lens="eqd", out_lens="rect", interp=2, rot=None, channels=4, size=4096, out_size=2048, ns=2),
+    # ... and the other two settings the reference's help text prescribes (src/main.cpp:192-196): --scale 0.33334 --samples 3 (4096 ->
+    # int(4096 * 0.33334) = 1365, src/main.cpp:581-587) and --scale 0.25 --samples 4
+    "fisheye_to_rect_bicubic_third_ns3": dict(in_lens="eqd", out_lens="rect", interp=2, rot=None, channels=4, size=4096, out_size=1365, ns=3),
+    "fisheye_to_rect_bicubic_quarter_ns4": dict(in_lens="eqd", out_lens="rect", interp=2, rot=None, channels=4, size=4096, out_size=1024, ns=4),
     # BASELINE.json configs[4]: one 8192^2 RGB panorama -> six 2048^2 rectilinear faces, bicubic; a "frame" is a cubemap
     "cubemap_8k_rgb": dict(in_lens="eqr", out_lens="rect", interp=2, channels=3, size=8192, out_size=2048,
                            faces=[(0.0, 0.0, 0.0), (90.0, 0.0, 0.0), (180.0, 0.0, 0.0), (270.0, 0.0, 0.0), (0.0, 90.0, 0.0),
                                   (0.0, -90.0, 0.0)], rot=None),
 }
 DEFAULT_SECONDARY = ("equirect_to_rect_bicubic,equirect_to_rect_bicubic_rot,equirect_to_fisheye_bilinear,"
-                     "equirect_to_fisheye_bicubic_rot,rect_to_equirect_bicubic_rgbaz_post,cubemap_8k_rgb,fisheye_to_rect_bicubic_half_ns2")
+                     "equirect_to_fisheye_bicubic_rot,rect_to_equirect_bicubic_rgbaz_post,cubemap_8k_rgb,fisheye_to_rect_bicubic_half_ns2,"
+                     "fisheye_to_rect_bicubic_third_ns3,fisheye_to_rect_bicubic_quarter_ns4")
 INTERP_NAMES = {0: "nearest", 1: "bilinear", 2: "bicubic"}
 KERNEL_NAMES = {0: "reproject_tile_kernel (nearest)", 1: "reproject_tile_kernel (bilinear)",
                 2: "reproject_bicubic_win_kernel (LDS window)"}
-TRAFFIC_FILE = os.path.join("profiles", "traffic_r05.json")
+TRAFFIC_FILE = os.path.join("profiles", "traffic_r06.json")
 
 
 def kernel_source_sha():

@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the taps (and every older store)
               const int j = lane & 3;
               const int slot0 = kTapRotate ? (256 * j + (lane & 48) + ((((lane >> 2) + j) & 3) << 2)) : (257 * j + (lane & ~3));
-              s = win_tier_raw<CH>(win0 + slot0, 64, reinterpret_cast<const float *>(win0 + 1024) + slot0, psx - __builtin_truncf(psx), psy - __builtin_truncf(psy), [&]() {
+              s = win_tier_raw<CH, true>(win0 + slot0, 64, reinterpret_cast<const float *>(win0 + 1024) + slot0, psx - __builtin_truncf(psx), psy - __builtin_truncf(psy), [&]() {
                 if (last_pass) next_window(); // behind the last reads of the taps
               });
             } else {
@@ -1377,7 +1377,7 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
             } else { // (the taps: a window of constant pitch — every row offset is an immediate of the read)
               const int j = lane & 3;
               const int slot0 = kTapRotate ? (256 * j + (lane & 48) + ((((lane >> 2) + j) & 3) << 2)) : (257 * j + (lane & ~3));
-              s = win_tier_raw<CH>(win0 + slot0, 64, reinterpret_cast<const float *>(win0 + 1024) + slot0, psx - tx_, psy - ty_, after_reads);
+              s = win_tier_raw<CH, true>(win0 + slot0, 64, reinterpret_cast<const float *>(win0 + 1024) + slot0, psx - tx_, psy - ty_, after_reads);
             }
           } else {
             after_reads(); // nothing of this pass reads the buffer

@@ -21,13 +21,21 @@ namespace lrp {
 // Depth of one pixel: its 16 taps from the float plane (`d` = the tap (int(sx) - 1, int(sy) - 1), `pitch` floats per row),
 // the four vertical cubics as two packed ones (tap columns 0 | 1 and 2 | 3 in the halves of a register pair: each half of a
 // v_pk_* rounds like the scalar instruction), then the horizontal one.
-template <class After>
+// Aligned: `d` and the rows behind it are 16-byte aligned (the taps of tap DMA: lrp_win_kernel.h request_taps) — a tap row is ONE
+// ds_read_b128 instead of two ds_read2_b32.
+template <bool Aligned = false, class After>
 __device__ __forceinline__ float win_depth_sample(const float *d, int pitch, float fx, float fy, float hfx, float hfy, After after_reads) {
   float t[4][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int r = 0; r < 4; ++r) {
+    if constexpr (Aligned) {
+      const float4 v = *reinterpret_cast<const float4 *>(d + r * pitch);
+      t[0][r] = v.x, t[1][r] = v.y, t[2][r] = v.z, t[3][r] = v.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t[j][r] = d[r * pitch + j];
+      for (int j = 0; j < 4; ++j) t[j][r] = d[r * pitch + j];
+    }
+  }
   after_reads();
   const f2 k01 = catmull_rom2(f2{t[0][0], t[1][0]}, f2{t[0][1], t[1][1]}, f2{t[0][2], t[1][2]}, f2{t[0][3], t[1][3]}, fy, hfy);
   const f2 k23 = catmull_rom2(f2{t[2][0], t[3][0]}, f2{t[2][1], t[3][1]}, f2{t[2][2], t[3][2]}, f2{t[2][3], t[3][3]}, fy, hfy);
@@ -36,7 +44,7 @@ __device__ __forceinline__ float win_depth_sample(const float *d, int pitch, flo
 
 // Raw taps: `t` = slot of tap (int(sx) - 1, int(sy) - 1), `pitch` slots per window row; RGBAZ: `depth` = that tap in the
 // float plane.  All 16 taps first (in the last pass they are the block's last reads of the window), then the cubics.
-template <int CH, class After>
+template <int CH, bool AlignedDepth = false, class After>
 __device__ __forceinline__ Rgba win_tier_raw(const float4 *t, int pitch, const float *depth, float fx, float fy, After after_reads) {
   const float hfx = 0.5f * fx, hfy = 0.5f * fy;
   const float4 *t1 = t + pitch, *t2 = t1 + pitch, *t3 = t2 + pitch;
@@ -54,7 +62,7 @@ __device__ __forceinline__ Rgba win_tier_raw(const float4 *t, int pitch, const f
   const Rgba k2 = cubic4(q[2][0], q[2][1], q[2][2], q[2][3], fy, hfy);
   const Rgba k3 = cubic4(q[3][0], q[3][1], q[3][2], q[3][3], fy, hfy);
   Rgba s = cubic4(k0, k1, k2, k3, fx, hfx);
-  if constexpr (CH == 5) s.e = win_depth_sample(depth, pitch, fx, fy, hfx, hfy, after_reads);
+  if constexpr (CH == 5) s.e = win_depth_sample<AlignedDepth>(depth, pitch, fx, fy, hfx, hfy, after_reads);
   return s;
 }
 

@@ -22,5 +22,6 @@ cp $f/staged.log profiles/${r}_staged_pcie.txt
 cp $f/fov_sweep.log profiles/${r}_rect_eqr_fov_sweep.txt
 [ -f $f/hbm_stream.log ] && cp $f/hbm_stream.log profiles/${r}_hbm_stream_microbench.txt
 [ -f $f/policy_check.txt ] && cp $f/policy_check.txt profiles/${r}_policy_check.txt
+[ -f $f/tier_account.md ] && cp $f/tier_account.md profiles/${r}_tier_account.md && cp $f/tier_account_counters.txt profiles/${r}_tier_account_counters.txt
 tail -3 $f/gpu_tests.log > profiles/${r}_gpu_tests_tail.txt
 echo "collected into profiles/${r}_*"

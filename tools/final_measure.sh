@@ -39,12 +39,17 @@ done
 timeout 200 ./tools/kbench --sum --reps 20 --size 8192 --out-size 2048 --channels 3 --distinct 4 eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch > $out/kbench_cubemap_faces.log 2>&1
 timeout 200 ./tools/kbench --sum --reps 20 --size 8192 --out-size 2048 --channels 3 --distinct 4 --geo 0 eqr_rect_bc eqr_rect_bc_rot eqr_rect_bc_pitch > $out/kbench_cubemap_faces_geo0.log 2>&1
 timeout 300 python3 tools/cubemap_bench.py 30 > $out/cubemap_bench.log 2>&1
-for S in 1 0; do
-  (echo "# num_samples 2, 4096^2 -> 2048^2, win_ss=$S (1: the window kernel's SS instantiations; 0: the tile kernel)"; timeout 300 ./tools/kbench --sum --reps 20 --distinct 16 --ns 2 --size 4096 --out-size 2048 --set win_ss=$S eqd_rect_bc eqr_rect_bc eqr_rect_bc_gen rect_eqr_bc eqd_eqd_bc;
-   echo "# ... 16-frame launches"; timeout 300 ./tools/kbench --sum --reps 6 --batch 16 --distinct 16 --ns 2 --size 4096 --out-size 2048 --set win_ss=$S eqd_rect_bc eqr_rect_bc;
-   echo "# ... 4096^2 -> 4096^2"; timeout 300 ./tools/kbench --sum --reps 10 --distinct 16 --ns 2 --set win_ss=$S eqd_rect_bc eqr_rect_bc) >> $out/kbench_supersampling.log 2>&1
+SSW="eqd_rect_bc eqr_rect_bc eqr_rect_bc_gen rect_eqr_bc eqd_eqd_bc rect_rect_bc"
+for N in "2 2048" "3 1365" "4 1024"; do
+  set -- $N
+  (echo "# num_samples $1, 4096^2 -> $2^2 (the reference's --scale / --samples pairs, src/main.cpp:192-196), single launches"
+   echo "# window kernel's SS instantiations reading their entry of sub-samples (default)"; timeout 300 ./tools/kbench --sum --reps 16 --distinct 16 --ns $1 --size 4096 --out-size $2 $SSW | grep -v "^#"
+   echo "# ... geometry cache off (every launch computes its sub-sample coordinates)"; timeout 300 ./tools/kbench --sum --reps 16 --distinct 16 --geo 0 --ns $1 --size 4096 --out-size $2 $SSW | grep -v "^#"
+   echo "# ... win_ss=0: the tile kernel"; timeout 300 ./tools/kbench --sum --reps 10 --distinct 16 --ns $1 --size 4096 --out-size $2 --set win_ss=0 $SSW | grep -v "^#"
+   echo "# ... 16-frame launches (default)"; timeout 300 ./tools/kbench --sum --reps 4 --batch 16 --distinct 16 --ns $1 --size 4096 --out-size $2 eqd_rect_bc eqr_rect_bc_gen | grep -v "^#") >> $out/kbench_supersampling.log 2>&1
 done
-(echo "# num_samples 1 and 3 (4096^2 -> 2048^2) for reference"; timeout 300 ./tools/kbench --sum --reps 20 --distinct 16 --ns 1 --size 4096 --out-size 2048 eqd_rect_bc eqr_rect_bc; timeout 300 ./tools/kbench --sum --reps 10 --distinct 16 --ns 3 --size 4096 --out-size 2048 eqd_rect_bc eqr_rect_bc) >> $out/kbench_supersampling.log 2>&1
+(echo "# num_samples 5 (the tile kernel) and 1 for reference, 4096^2 -> 2048^2"; timeout 300 ./tools/kbench --sum --reps 6 --distinct 16 --ns 5 --size 4096 --out-size 819 eqd_rect_bc | grep -v "^#"; timeout 300 ./tools/kbench --sum --reps 20 --distinct 16 --ns 1 --size 4096 --out-size 2048 eqd_rect_bc eqr_rect_bc | grep -v "^#"
+ echo "# num_samples 2 at scale 1 (4096^2 -> 4096^2)"; timeout 300 ./tools/kbench --sum --reps 8 --distinct 16 --ns 2 eqd_rect_bc eqr_rect_bc | grep -v "^#") >> $out/kbench_supersampling.log 2>&1
 for S in 1 2; do timeout 200 ./tools/kbench --reps 64 --distinct 16 --streams $S eqd_rect_bc eqr_rect_bc eqr_eqd_bc_rot rect_eqr_bc; done > $out/kbench_two_streams.log 2>&1
 timeout 300 ./tools/staged_bench > $out/staged.log 2>&1
 (echo "# RGBA"; python3 tools/fov_sweep.py 4 2>&1 | grep focal; echo "# RGBAZ + tonemap"; python3 tools/fov_sweep.py 5 post 2>&1 | grep focal) > $out/fov_sweep.log
@@ -67,5 +72,6 @@ done
 python3 $R/tools/pmc_summary.py $R/$out/sq > $R/$out/sq_counters.txt
 cd $R
 (timeout 1800 python3 tools/policy_check.py 0.05 2>&1 | grep -v amdgpu.ids > $out/policy_check.txt; echo "policy_check rc=$?" >> $out/policy_check.txt)
+(bash tools/raw_tap_account.sh > $out/account.log 2>&1; cp gpurun_out/account/table.md $out/tier_account.md; cp gpurun_out/account/counters.txt $out/tier_account_counters.txt)
 python3 tools/roofline_table.py $out/bench.json $out/kernel_trace_by_launch_shape.txt > $out/roofline.md
 cat $out/bench_line.json
