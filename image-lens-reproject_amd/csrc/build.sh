@@ -7,8 +7,9 @@ obj="$out/obj"
 mkdir -p "$out" "$obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 jobs="${1:-$(( $(nproc) + 4 ))}"
-# Parity flags: no FMA contraction, IEEE divide/sqrt, denormals kept, no fast-math.
-FLAGS=(--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off
+# Parity flags: no FMA contraction, IEEE divide/sqrt, denormals kept, no fast-math.  --offload-compress: the code objects are
+# stored compressed in the fat binary (the runtime unpacks them when the library is loaded): liblrp_hip.so 39.7 -> ~8 MB.
+FLAGS=(--offload-arch=gfx950 --offload-compress -std=c++17 -O3 -fPIC -ffp-contract=off
        -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -fno-gpu-flush-denormals-to-zero
        -Wall -Wno-unused-function -Wno-inline-asm -Wno-cuda-compat -I"$here" -I"$here/../../include" ${LRP_BUILD_FLAGS:-})
 srcs=(lrp_kernels_nn.hip lrp_kernels_bl.hip lrp_kernels_bc.hip lrp_tile_nn.hip lrp_tile_bl.hip lrp_tile_bc.hip lrp_tile_win.hip lrp_tile_winq.hip lrp_tile_win3.hip lrp_tile_winq3.hip lrp_tile_win5.hip lrp_tile_winq5.hip lrp_tile_winy.hip lrp_tile_winx.hip lrp_tile_winy3.hip lrp_tile_winx3.hip lrp_tile_winy5.hip lrp_tile_winx5.hip lrp_tile_winr.hip lrp_tile_winr3.hip lrp_tile_winr5.hip lrp_tile_wing.hip lrp_tile_wing3.hip lrp_tile_wing5.hip lrp_tile_wins.hip lrp_tile_wins3.hip lrp_tile_wins5.hip lrp_tile_winsg.hip lrp_tile_winsg3.hip lrp_tile_winsg5.hip lrp_tables.hip lrp_geo_lists.hip lrp_aux_kernels.hip lrp_pixel_kernels.hip lrp_capi.cpp lrp_plan.cpp lrp_geocache.cpp lrp_host_util.cpp)
