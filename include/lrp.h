@@ -111,8 +111,7 @@ const char *lrp_last_error(void);
  * (any channel count), 1 = tile kernel (RGB / RGBA / RGBAZ), 2 = tile kernel + LDS-window
  * bicubic (default; the library picks the pixel kernel by itself where the others
  * do not apply), 3 = as 2 with the window kernel's shared-coefficient tier switched off.  Testing / A-B knob: sets the family for subsequent calls of all
- * threads and returns the previous one; an out-of-range value only queries.
- * The environment variable LRP_KERNEL=pixel|tile|window-raw sets the initial value. */
+ * threads and returns the previous one; an out-of-range value only queries.  (The library reads no environment variable.) */
 int lrp_debug_kernel(int choice);
 /* The other testing / A-B switches, by name: "kernel" (as lrp_debug_kernel), "xsep", "quad", "mirror_modes",
  * "win_edge", "win_split", "geo_cache" (0 / 1: a sharing or staging path of the tile / window kernels off / on — the bits
@@ -122,14 +121,12 @@ int lrp_debug_kernel(int choice);
  * 30 % of its in-view blocks are too large for a 10 KiB window, 0 = never, 2 = always),
  * "geo_lists" (rendering by block class from the lists of a geometry-cache entry: 0 never, 1 where corner blocks are at least
  * 30 % of the frame, 2 whenever the lists are known), "geo_fill_fused" (0: the corner runs of such a launch always by the fill kernel, not as a share per
- * wavefront of the window kernel), "geo_fill_stream" (1: that fill kernel on a side stream), "geo_pairs" (1: the pair kernel — alias pairs of in-view blocks, a rectilinear view
- * and its copy behind the camera in a full panorama, two wavefronts per staged window — in a listed launch; default 0: not faster), "multi_merge" (1: lrp_reproject_multi_device merges the outputs whose
- * geometry-cache entries exist into one launch; default 0: a launch per output, measured level), "merged_launches", "big_launches" (counters), "context_streams" (0: an lrp_context keeps all its kernels on one compute stream instead of alternating two),
+ * wavefront of the window kernel), "geo_fill_stream" (1: that fill kernel on a side stream), "big_launches" (a counter), "context_streams" (0: an lrp_context keeps all its kernels on one compute stream instead of alternating two),
+ * "win_ss" (0: bicubic with num_samples 2-4 through the tile kernel instead of the window kernel's supersampling instantiations),
  * "geo_census" (0: no census of a new entry's windows), "geo_list_recs" (0: listed wavefronts read their block's record from the box array),
  * "win_tapdma" (0: passes of the big-window variant whose window fits no buffer gather per lane instead of fetching their taps quad by quad through LDS-DMA),
  * "listed_launches" (a counter: launches rendered by block class so far; 0 resets).  Sets the value for subsequent calls of all threads
- * and returns the previous one; a value outside the switch's range only queries; an unknown name returns -1.  The
- * environment variables LRP_XSEP, LRP_QUAD, ... supply the initial values once, when the library is loaded. */
+ * and returns the previous one; a value outside the switch's range only queries; an unknown name returns -1. */
 int lrp_debug_set(const char *name, int value);
 /* Frees the cached per-output-lens tables and the geometry cache of every device (after
  * synchronising them).  Optional: both caches are bounded and reused across calls. */
@@ -144,9 +141,12 @@ void lrp_release_cached_tables(void);
  * lrp_reproject_multi_device, lrp_context_submit*) leaves those coordinates in device memory as a side
  * output (8 bytes per output pixel + 2 per 16 pixels) and later launches of the same geometry on that device load them
  * instead of computing them: same values, same rendered bits, 1.2-1.9x the kernel rate.  Keyed on
- * (device, both lenses, both sizes, rotation); least recently used entries are dropped when
+ * (device, both lenses, both sizes, rotation, num_samples); least recently used entries are dropped when
  * `max_bytes` per device would be exceeded; a launch being captured into a hipGraph does not use it.
- *   max_bytes      bytes per device (default 1 GiB); 0 switches the cache off and frees it; < 0 keeps the value
+ * Bicubic with num_samples 2-4 (the reference's --samples) keeps an entry of its own kind: a coordinate pair per
+ * SUB-SAMPLE, 8 x num_samples^2 bytes per output pixel.
+ *   max_bytes      bytes per device (default: min(4 GiB, 2 % of the device's memory), at least two entries of the largest
+ *                  geometry seen; -2 restores it); 0 switches the cache off and frees it; -1 keeps the value
  *   min_sightings  a geometry is cached from its n-th launch on (default 1; 2 suits callers whose
  *                  rotation changes with every call — the library switches to 2 by itself after
  *                  evicting several entries that were never read); < 1 keeps the value */

@@ -5,7 +5,7 @@ frame: reads and writes every byte of the 256 MiB frame exactly once with 16-byt
 also SEPARATES the groups of dispatches: for every bench workload
     separator, WARM single-frame launches (table builds, the launch that fills the geometry cache and builds its lists,
                the per-face launches of a cubemap's first call), separator, REPS single-frame launches of the steady state
-               (whatever kernels a frame takes: one window launch, a fill launch in front of it, one merged launch for six faces),
+               (whatever kernels a frame takes: one window launch, a fill launch in front of it, six launches for six faces),
     separator, one 16-frame launch to warm up, separator, BATCH_LAUNCHES 16-frame launches (lrp_reproject_batch_device: what
                bench.py times), cycling over more distinct frames than the 256 MiB Infinity Cache holds.
 The order of the groups is written next to the counters (argv[1]) for tools/traffic_summary.py, which sums ALL dispatches of a
