@@ -55,8 +55,9 @@ def test_kernel_trace_summary_on_a_synthetic_trace(tmp_path):
     assert batched[-5:] == ["16", "1", "1500.0", "1500.0", "93.8"], batched
 
 
-def test_roofline_table_is_generated_from_the_bench_line(tmp_path):
-    bench = os.path.join(ROOT, "profiles", "r04_bench.json")
+@pytest.mark.parametrize("name", ["r04_bench.json", "r06_bench.json"])  # (round 4's single line; round 6's detail file)
+def test_roofline_table_is_generated_from_the_bench_line(tmp_path, name):
+    bench = os.path.join(ROOT, "profiles", name)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "roofline_table.py"), bench], capture_output=True, text=True, check=True).stdout
     rec = json.load(open(bench))
     head = [ln for ln in out.splitlines() if ln.startswith("| fisheye_to_rect_bicubic:")][0]
@@ -111,3 +112,23 @@ def test_the_drivers_bench_line_is_compact_and_complete():
     fat = dict(detail, secondary={f"workload_{i}_{'x' * 40}": {"frac": 0.5, "us_per_frame": 100.0} for i in range(60)})
     with pytest.raises(AssertionError):
         bench.compact_line(fat)
+
+
+def test_every_bench_workload_has_a_row_label_and_the_compact_line_of_round_6_is_on_file():
+    """tools/roofline_table.py names every workload bench.py can measure; profiles/r06_bench_line.json — what the driver's parser
+    was given on the measurement pass — is one line, below the limit, and agrees with the detail file it points to."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    spec = importlib.util.spec_from_file_location("roofline_table", os.path.join(ROOT, "tools", "roofline_table.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert set(bench.WORKLOADS) <= set(mod.CONFIG_OF), sorted(set(bench.WORKLOADS) - set(mod.CONFIG_OF))
+    assert set(bench.DEFAULT_SECONDARY.split(",")) <= set(bench.WORKLOADS)
+    text = open(os.path.join(ROOT, "profiles", "r06_bench_line.json")).read().rstrip("\n")
+    last = text.splitlines()[-1]
+    assert len(last) < bench.COMPACT_LIMIT
+    rec, detail = json.loads(last), json.load(open(os.path.join(ROOT, "profiles", "r06_bench.json")))
+    assert set(rec) <= set(bench.TOP_KEYS) and rec["value"] == pytest.approx(detail["value"], rel=1e-5)
+    assert json.loads(bench.compact_line(detail, rec.get("detail_file"))) == rec  # the line IS compact_line(detail)
+    assert set(rec["secondary"]) == set(bench.DEFAULT_SECONDARY.split(","))
