@@ -116,7 +116,13 @@ PlanSharing plan_sharing(const PlanRequest &r, const PlanSwitches &s, const Plan
   // like everybody: 176 -> 160)
   const bool window_ss = p.window && !p.window1 && !(r.in_mode == kPlanInRect && r.out_type == kPlanEquirect) &&
                          (long long)r.out_w * r.out_h * ns * ns < (1ll << 31);
-  p.wants_geo = (p.window1 || tile_single || window_ss) && !r.band && k == 2 && s.geo_cache != 0;
+  // ... and so do nearest / bilinear with num_samples 2 (tile kernel, a lane per PIXEL: its four pairs are two 16-byte loads):
+  // equirect -> rect bilinear 82 -> 70 us, rotated 110 -> 71, equirect -> fisheye rotated 167 -> 141; the same entry serves all
+  // three samplers.  Not for num_samples 3, 4 — a lane's 9 / 16 pairs lie 72 / 128 bytes from its neighbour's, the loads of a
+  // wavefront use a fraction of every line they touch: 123 / 193 us against 81 / 87 computing — and not where the coordinates are
+  // cheap (above).
+  const bool tile_ss = !p.window && interp != kPlanBicubic && ns == 2 && !cheap_coordinates && (long long)r.out_w * r.out_h * ns * ns < (1ll << 31);
+  p.wants_geo = (p.window1 || tile_single || window_ss || tile_ss) && !r.band && k == 2 && s.geo_cache != 0;
   p.geo_want_boxes = p.window1;
   return p;
 }
@@ -129,7 +135,7 @@ PlanGeo plan_geo(const PlanRequest &r, const PlanSwitches &s, const PlanSharing 
   p.geo_mode = g.mode;
   p.win_mode = 0;
   p.quad = 0; // (tile kernels: the plain path writes / the GeoRead kernels read the map)
-  if (sh.window && !sh.window1) { // an entry of sub-samples: written (1) or read (2) by the SS instantiations, nothing else applies
+  if (r.num_samples > 1) { // an entry of sub-samples: written (1) or read (2) by the SS instantiations / the tile kernel, nothing else applies
     if (g.mode != 1 && g.mode != 2) p.geo_mode = 0;
     return p;
   }

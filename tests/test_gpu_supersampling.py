@@ -71,6 +71,62 @@ def test_every_lens_pair_against_the_live_oracle(lrp, oracle, torch_cuda, channe
             lrp.debug_set("win_ss", prev)
 
 
+@pytest.mark.parametrize("interp", [0, 1])
+@pytest.mark.parametrize("ns", [2, 3, 4])
+def test_nearest_and_bilinear_share_the_entry_of_sub_samples(lrp, oracle, torch_cuda, ns, interp):
+    """Nearest / bilinear with num_samples 2-4 (tile kernel).  num_samples 2: the launch that fills an entry of sub-samples, a launch
+    that reads it, a batch of three that reads it, the cache off — and bicubic reading the entry a bilinear launch wrote (one entry
+    serves the three samplers); 3 and 4 compute (and must not touch the cache) — against the live oracle, RGB / RGBA / RGBAZ, every
+    target lens over every source lens."""
+    torch = torch_cuda
+    k = 3 * ns + interp
+    for out_name in ("rect", "eqd180", "eqr_full", "eqr_part"):
+        for in_name in ("rect_tele", "eqd180", "eqr_full", "eqr_part"):
+            k += 1
+            channels = 3 + k % 3
+            rot_name = list(golden_cases.ROTS)[k % 5]
+            iw, ih, ow, oh = [(61, 47, 53, 41), (160, 120, 72, 67), (256, 128, 35, 19), (96, 80, 131, 90)][k % 4]
+            post = (1.5, 3.0) if k % 3 == 0 else None
+            src = cases.hash_noise(ih, iw, channels, seed=0x7155 + 8 * k + channels, planted=(k % 2 == 0))
+            lin, lout = cases.lenses(lrp, iw, ih)[in_name], cases.lenses(lrp, ow, oh)[out_name]
+            rot = cases.rotation(lrp, golden_cases.ROTS[rot_name])
+            d_in = torch.from_numpy(src).cuda()
+
+            def render(interpolation, batch=0):
+                outs = [torch.full((oh, ow, channels), -12345.0, dtype=torch.float32, device="cuda") for _ in range(max(batch, 1))]
+                im_in = lrp.Image(lin, iw, ih, channels, d_in)
+                if batch:
+                    lrp.reproject_batch([im_in] * batch, [lrp.Image(lout, ow, oh, channels, o) for o in outs], ns, interpolation, rot, post=post)
+                else:
+                    lrp.reproject(im_in, lrp.Image(lout, ow, oh, channels, outs[0]), ns, interpolation, rot, post=post)
+                torch.cuda.synchronize()
+                return [o.cpu().numpy() for o in outs]
+
+            def want_of(interpolation):
+                w = oracle.reproject(lin, src, lout, ow, oh, ns, interpolation, rot)
+                return oracle.post_process(w, *post) if post else w
+
+            want = want_of(interp)
+            what = f"{in_name} {iw}x{ih} -> {out_name} {ow}x{oh} C={channels} ns={ns} interp={interp} {rot_name} post={post}"
+            # (num_samples 2 only — a lane's 9 / 16 pairs are strided loads —, and cheap coordinates are computed: lrp_plan.cpp)
+            cached = 0 if (ns != 2 or (in_name.startswith("rect") and not out_name.startswith("eqd"))) else 1
+            fills0, hits0 = (lrp.geometry_cache_stats()[key] for key in ("fills", "hits"))
+            cases.assert_same_bits(render(interp)[0], want, "the launch that fills the entry, " + what)
+            cases.assert_same_bits(render(interp)[0], want, "a launch that reads it, " + what)
+            for i, got in enumerate(render(interp, batch=3)):
+                cases.assert_same_bits(got, want, f"a batch of three, frame {i}, " + what)
+            stats = lrp.geometry_cache_stats()
+            assert stats["fills"] == fills0 + cached and stats["hits"] >= hits0 + 2 * cached, what
+            if cached:  # ... and the bicubic SS instantiations read the entry this sampler wrote
+                hits1 = lrp.geometry_cache_stats()["hits"]
+                cases.assert_same_bits(render(BICUBIC)[0], want_of(BICUBIC), "bicubic on the entry a nearest / bilinear launch wrote, " + what)
+                if not (in_name.startswith("rect") and out_name.startswith("eqr")):
+                    assert lrp.geometry_cache_stats()["hits"] == hits1 + 1, what
+            prev_geo = lrp.debug_set("geo_cache", 0)
+            cases.assert_same_bits(render(interp)[0], want, "cache off, " + what)
+            lrp.debug_set("geo_cache", prev_geo)
+
+
 def test_bands_batches_and_the_other_sample_counts(lrp, oracle, torch_cuda):
     """Row bands (lrp_reproject_rows_device: bands that start and end inside a 4-row block) and a batch of five frames for every
     sample count of the SS instantiations, and num_samples 1 / 5 around them (their own kernels) on one geometry."""
