@@ -12,7 +12,7 @@ jobs="${1:-$(( $(nproc) + 4 ))}"
 FLAGS=(--offload-arch=gfx950 --offload-compress -std=c++17 -O3 -fPIC -ffp-contract=off
        -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -fno-gpu-flush-denormals-to-zero
        -Wall -Wno-unused-function -Wno-inline-asm -Wno-cuda-compat -I"$here" -I"$here/../../include" ${LRP_BUILD_FLAGS:-})
-srcs=(lrp_kernels_nn.hip lrp_kernels_bl.hip lrp_kernels_bc.hip lrp_tile_nn.hip lrp_tile_bl.hip lrp_tile_bc.hip lrp_tile_win.hip lrp_tile_winq.hip lrp_tile_win3.hip lrp_tile_winq3.hip lrp_tile_win5.hip lrp_tile_winq5.hip lrp_tile_winy.hip lrp_tile_winx.hip lrp_tile_winy3.hip lrp_tile_winx3.hip lrp_tile_winy5.hip lrp_tile_winx5.hip lrp_tile_winr.hip lrp_tile_winr3.hip lrp_tile_winr5.hip lrp_tile_wing.hip lrp_tile_wing3.hip lrp_tile_wing5.hip lrp_tile_wins.hip lrp_tile_wins3.hip lrp_tile_wins5.hip lrp_tile_winsg.hip lrp_tile_winsg3.hip lrp_tile_winsg5.hip lrp_tables.hip lrp_geo_lists.hip lrp_aux_kernels.hip lrp_pixel_kernels.hip lrp_capi.cpp lrp_plan.cpp lrp_geocache.cpp lrp_host_util.cpp)
+srcs=(lrp_kernels_nn.hip lrp_kernels_bl.hip lrp_kernels_bc.hip lrp_tile_nn.hip lrp_tile_bl.hip lrp_tile_bc.hip lrp_tile_win.hip lrp_tile_winq.hip lrp_tile_win3.hip lrp_tile_winq3.hip lrp_tile_win5.hip lrp_tile_winq5.hip lrp_tile_winy.hip lrp_tile_winx.hip lrp_tile_winy3.hip lrp_tile_winx3.hip lrp_tile_winy5.hip lrp_tile_winx5.hip lrp_tile_winr.hip lrp_tile_winr3.hip lrp_tile_winr5.hip lrp_tile_wing.hip lrp_tile_wing3.hip lrp_tile_wing5.hip lrp_tile_wins.hip lrp_tile_wins3.hip lrp_tile_wins5.hip lrp_tile_winsg.hip lrp_tile_winsg3.hip lrp_tile_winsg5.hip lrp_tile_ssg.hip lrp_tables.hip lrp_geo_lists.hip lrp_aux_kernels.hip lrp_pixel_kernels.hip lrp_capi.cpp lrp_plan.cpp lrp_geocache.cpp lrp_host_util.cpp)
 # Per-unit code generation options (measured on MI355X, tools/ablate.sh variants; bits are unaffected):
 #   the plain-block window kernels schedule for instruction-level parallelism: rectilinear -> equirectangular bicubic
 #   (BASELINE configs[3]) 229 -> 217 us, the other plain-block mappings within +-1 %; the mirrored units gain nothing.

@@ -33,6 +33,7 @@ hipError_t launch_tile_nearest(const KParams &P, int out_idx, int in_mode, hipSt
 hipError_t launch_tile_bilinear(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
 hipError_t launch_tile_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream);
 hipError_t launch_win_bicubic(const KParams &P, int out_idx, int in_mode, hipStream_t stream); // (P.geo_mode == 2: the GeoRead kernels)
+hipError_t launch_ss_gather(const KParams &P, int interpolation, int in_mode, hipStream_t stream); // lrp_tile_ssg.hip: nearest / bilinear, num_samples 2-4, from an entry of sub-samples
 hipError_t launch_geo_build_lists(int32_t *box, int out_w, int out_h, int alias_pairs, hipStream_t stream); // lrp_geo_lists.hip
 hipError_t launch_geo_census(int32_t *box, int out_w, int out_h, int in_w, int in_h, bool clear_header, hipStream_t stream); // lrp_geo_lists.hip
 hipError_t launch_corner_fill(const KParams &P, hipStream_t stream);
@@ -414,6 +415,7 @@ int enqueue_reproject(const lrp_image *in, lrp_image *out, int num_samples, int 
       }
       if (window && P.geo_mode == 2 && P.big_windows != 0) g_knobs[kKnobBigLaunches].fetch_add(1, std::memory_order_relaxed);
       if (window) return lrp::launch_win_bicubic(P, oi, im, stream);
+      if (P.geo_mode == 2 && num_samples > 1) return lrp::launch_ss_gather(P, interpolation, im, stream); // (a lane per sub-sample: coalesced loads of the entry)
       if (interpolation == LRP_NEAREST) return lrp::launch_tile_nearest(P, oi, im, stream);
       if (interpolation == LRP_BILINEAR) return lrp::launch_tile_bilinear(P, oi, im, stream);
       return lrp::launch_tile_bicubic(P, oi, im, stream);

@@ -478,6 +478,55 @@ __device__ __forceinline__ void pixel_source(const KParams &P, const ColTerms co
   pixel_source_rt<OutLens, InMode>(P, col, row_term<OutLens>(P, ye, ssy), ye, ssy, sx, sy);
 }
 
+// ---- supersampling with a lane per sub-sample: the ordered sum of a pixel ------------------
+// The n = ns^2 sub-samples of a pixel sit in n consecutive lanes in the reference's order (sub = ns ssx + ssy); `first`: this
+// lane holds the pixel's first one.  The reference sums them into a zero-initialised accumulator in that order
+// (src/reproject.cpp:334-336: 0.0f + s0 + s1 + ...).  A chain of n - 1 steps: a first lane starts from 0.0f + s, every other
+// from s (a placeholder); step t replaces every lane's value by (its left neighbour's value) + s — after it the lane of
+// sub-sample t holds the reference's sum up to and including st, whatever the lanes of later sub-samples hold meanwhile; the
+// pixel's last lane ends up with its sum.  One VOP2 add with a DPP operand (wave_shr:1) per component and step (as a move +
+// a packed add it is six instructions per step instead of four: num_samples 4 runs fifteen steps).  A DPP operand written
+// by the previous VALU instruction needs two wait states: the s_nop in front of a step's first add; the step's other adds
+// keep a component's add of step t + 1 at least two instructions behind its add of step t.  All 64 lanes must be active.
+template <int CH> __device__ __forceinline__ Px<CH> ss_ordered_sum(const Px<CH> &sp, bool first, int n) {
+  Px<CH> a = sp;
+  if (first) { // 0.0f + s: turns -0 into +0 and quiets a NaN like the reference's first += does
+    a = px_zero<CH>();
+    px_add<CH>(a, sp);
+  }
+  float a0 = a.lo.x, a1 = a.lo.y, a2 = CH >= 4 ? a.hi.x : a.e, a3 = CH >= 4 ? a.hi.y : 0.0f, a4 = CH == 5 ? a.e : 0.0f;
+  const float s0 = sp.lo.x, s1 = sp.lo.y, s2 = CH >= 4 ? sp.hi.x : sp.e, s3 = CH >= 4 ? sp.hi.y : 0.0f, s4 = CH == 5 ? sp.e : 0.0f;
+#pragma unroll 1
+  for (int t = 1; t < n; ++t) {
+    if constexpr (CH == 3)
+      asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %1, %1, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %2, %2, %5 wave_shr:1 row_mask:0xf bank_mask:0xf"
+                   : "+v"(a0), "+v"(a1), "+v"(a2)
+                   : "v"(s0), "v"(s1), "v"(s2));
+    else if constexpr (CH == 4)
+      asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %1, %1, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %2, %2, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %3, %3, %7 wave_shr:1 row_mask:0xf bank_mask:0xf"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+                   : "v"(s0), "v"(s1), "v"(s2), "v"(s3));
+    else
+      asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %1, %1, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %2, %2, %7 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %3, %3, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %4, %4, %9 wave_shr:1 row_mask:0xf bank_mask:0xf"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4)
+                   : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4));
+  }
+  a.lo = f2{a0, a1};
+  if constexpr (CH >= 4) a.hi = f2{a2, a3};
+  if constexpr (CH == 3) a.e = a2;
+  if constexpr (CH == 5) a.e = a4;
+  return a;
+}
+
 // ---- one sample, taps straight from global memory -------------------------------
 struct SrcView {
   __amdgpu_buffer_rsrc_t rsrc;

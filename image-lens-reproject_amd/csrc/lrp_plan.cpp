@@ -116,12 +116,15 @@ PlanSharing plan_sharing(const PlanRequest &r, const PlanSwitches &s, const Plan
   // like everybody: 176 -> 160)
   const bool window_ss = p.window && !p.window1 && !(r.in_mode == kPlanInRect && r.out_type == kPlanEquirect) &&
                          (long long)r.out_w * r.out_h * ns * ns < (1ll << 31);
-  // ... and so do nearest / bilinear with num_samples 2 (tile kernel, a lane per PIXEL: its four pairs are two 16-byte loads):
-  // equirect -> rect bilinear 82 -> 70 us, rotated 110 -> 71, equirect -> fisheye rotated 167 -> 141; the same entry serves all
-  // three samplers.  Not for num_samples 3, 4 — a lane's 9 / 16 pairs lie 72 / 128 bytes from its neighbour's, the loads of a
-  // wavefront use a fraction of every line they touch: 123 / 193 us against 81 / 87 computing — and not where the coordinates are
-  // cheap (above).
-  const bool tile_ss = !p.window && interp != kPlanBicubic && ns == 2 && !cheap_coordinates && (long long)r.out_w * r.out_h * ns * ns < (1ll << 31);
+  // ... and so do nearest / bilinear with num_samples 2-4: the first launch (tile kernel, computing) writes the entry, later ones
+  // read it with a lane per SUB-SAMPLE (lrp_ss_gather_kernel.h: coalesced loads, the ordered DPP sum) — one entry serves the three
+  // samplers.  (Through the tile kernel, a lane per PIXEL, the loads of num_samples 3, 4 are 72 / 128 bytes apart between lanes and
+  // lose to computing: profiles/r06_experiments_ab.txt item 10.)  Not where the coordinates are cheap: a rectilinear source
+  // (above), or a source x that comes from the column table (equirect -> rect bilinear without a rotation: 81 / 87 us computing,
+  // 91 / 91 loading at ns 3 / 4).  What it is for: equirect -> fisheye bilinear rotated ns 2 / 3 / 4 172 / 218 / 330 -> 94 / 102 /
+  // 101 us, equirect -> rect bilinear rotated 110-120 -> 78-87.
+  const bool tile_ss = !p.window && interp != kPlanBicubic && ns >= 2 && ns <= kMaxWindowSamples && !cheap_coordinates && !xsep_available &&
+                       (long long)r.out_w * r.out_h * ns * ns < (1ll << 31);
   p.wants_geo = (p.window1 || tile_single || window_ss || tile_ss) && !r.band && k == 2 && s.geo_cache != 0;
   p.geo_want_boxes = p.window1;
   return p;

@@ -14,9 +14,8 @@ namespace lrp {
 #endif
 // GeoRead: the instantiation whose pixels LOAD their source coordinates from a geometry-cache entry (lrp_geocache.h; the
 // map is written as a side output by the plain path below when P.geo_mode == 1): nearest / bilinear, whole images; no lens
-// math compiled in, the output lens is irrelevant (kRect by convention).  One sample per pixel from a plain entry, or
-// num_samples 2-4 from an entry of sub-samples (a coordinate pair per sub-sample, lrp_params.h geo_ss_map_index — the entry the
-// window kernel's supersampling instantiations use for bicubic).
+// math compiled in, the output lens is irrelevant (kRect by convention); one sample per pixel.  (num_samples 2-4 from an entry
+// of sub-samples: lrp_ss_gather_kernel.h — a lane per sub-sample.)
 template <int OutLens, int InMode, int Interp, int CH, bool Frames = false, bool GeoRead = false>
 __global__ __launch_bounds__(kT2Threads, (Frames || GeoRead) ? LRP_TILE_MINWAVES_FRAMES : LRP_TILE_MINWAVES) void reproject_tile_kernel(const KParams Pk) {
   constexpr bool Loop = (InMode == kInEquirectLoop);
@@ -90,45 +89,6 @@ __global__ __launch_bounds__(kT2Threads, (Frames || GeoRead) ? LRP_TILE_MINWAVES
   if constexpr (GeoRead) {
     const int xg = x < P.out_w ? x : P.out_w - 1;
     const vf2 *const map = reinterpret_cast<const vf2 *>(P.geo_xy);
-    if (P.num_samples > 1) { // wave-uniform: an entry of sub-samples
-      // the reference's loop (src/reproject.cpp:294-341) with loaded coordinates: sub = ns ssx + ssy in ascending order is its
-      // ssx-outer, ssy-inner order; a lane's ns^2 pairs are consecutive in the map
-      const int ns2 = P.num_samples * P.num_samples;
-      Px<CH> acc[kT2Rows];
-#pragma unroll
-      for (int k = 0; k < kT2Rows; ++k) acc[k] = px_zero<CH>();
-      // (two pairs per load, plain loads: a lane's pairs are 8 ns^2 bytes apart from its neighbour's, so an instruction uses a
-      // fraction of the lines it touches and the following ones the rest — they must stay in the L1: as one non-temporal
-      // 8-byte load per sub-sample the kernel was 1.4-4x SLOWER than computing the coordinates)
-      typedef float v4f_a8 __attribute__((ext_vector_type(4), aligned(8)));
-      for (int s = 0; s < ns2; s += 2) {
-        const bool two = s + 1 < ns2; // wave-uniform
-#pragma unroll
-        for (int k = 0; k < kT2Rows; ++k) {
-          const int yk = y_first + k;
-          const vf2 *const at = map + geo_ss_map_index(xg, yk < P.y_end ? yk : P.y_end - 1, P.out_w, ns2, s);
-          float ax, ay, bx = 0.0f, by = 0.0f;
-          if (two) {
-            const v4f_a8 v = *reinterpret_cast<const v4f_a8 *>(at);
-            ax = v.x, ay = v.y, bx = v.z, by = v.w;
-          } else {
-            const vf2 v = *at;
-            ax = v.x, ay = v.y;
-          }
-          px_add<CH>(acc[k], sample_direct<Interp, Loop, CH>(P, src, ax, ay)); // :334-336
-          if (two) px_add<CH>(acc[k], sample_direct<Interp, Loop, CH>(P, src, bx, by));
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < kT2Rows; ++k) {
-        const int yk = y_first + k;
-        const bool row_inside = yk < P.y_end; // wave-uniform
-        const uint32_t row_first = (uint32_t)yk * (uint32_t)P.out_w + (uint32_t)x0;
-        store_tile_row<CH, false>(P, run_lds, row_inside && x0 + kT2W <= P.out_w, row_inside && x < P.out_w, lane, row_first,
-                                  row_first + (uint32_t)lane, acc[k]);
-      }
-      return;
-    }
     auto coords = [&](int k, float &sx, float &sy) {
       const int yk = y_first + k;
       const vf2 v = __builtin_nontemporal_load(map + geo_map_index(xg, yk < P.y_end ? yk : P.y_end - 1, P.out_w));
@@ -359,7 +319,7 @@ template <int Interp> hipError_t launch_tile_interp(KParams P, int out_idx, int 
   TileKernelFn fn;
   if (P.geo_mode == 2) { // coordinates from the geometry cache (the host asks for it for single whole-image launches only)
     if constexpr (Interp != 2) {
-      if (P.quad != 0 || P.num_samples < 1 || P.num_samples > 4 || P.y_offset != 0 || P.y_end != P.out_h) return hipErrorInvalidValue;
+      if (P.quad != 0 || P.num_samples != 1 || P.y_offset != 0 || P.y_end != P.out_h) return hipErrorInvalidValue;
       fn = P.channels == 4 ? TileGeoKernelTable<Interp, 4>::get(in_mode) : P.channels == 3 ? TileGeoKernelTable<Interp, 3>::get(in_mode) : TileGeoKernelTable<Interp, 5>::get(in_mode);
     } else {
       return hipErrorInvalidValue;

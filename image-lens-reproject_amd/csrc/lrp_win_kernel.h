@@ -980,45 +980,8 @@ __global__ __launch_bounds__(kWinThreads, (GeoRead && OutLens == kEquirect) ? LR
   auto ss_inside = [&](int g, int k) { return x < qw && pixel_row(g, k) < qh; };
   auto emit = [&](int g, int k, const Rgba &s, auto as_runs, bool runs_rt = true) {
     if constexpr (SS) { // src/reproject.cpp:334-341: acc = 0.0f; acc += sample (ssx outer, ssy inner); dst = acc * normalize
-      // The chain: a lane whose sub-sample is the pixel's first starts from 0.0f + s, every other from s (a placeholder); step t
-      // replaces every lane's value by (its left neighbour's value) + s — after it the lane of sub-sample t holds the reference's
-      // sum up to and including st, whatever the lanes of later sub-samples hold meanwhile.
       const Px<CH> sp{s.lo, CH >= 4 ? s.hi : f2{0.0f, 0.0f}, CH == 3 ? s.hi.x : s.e};
-      Px<CH> a = (ss_x | ss_y) == 0 ? accumulate(s) : sp;
-      // One VOP2 add with a DPP operand per component and step (as a move + a packed add it is six instructions per step
-      // instead of four: num_samples 4 runs fifteen steps per pass).  A DPP operand written by the previous VALU instruction
-      // needs two wait states: the s_nop in front of a step's first add; the step's other adds keep a component's add of step
-      // t + 1 at least two instructions behind its add of step t.
-      float a0 = a.lo.x, a1 = a.lo.y, a2 = CH >= 4 ? a.hi.x : a.e, a3 = CH >= 4 ? a.hi.y : 0.0f, a4 = CH == 5 ? a.e : 0.0f;
-      const float s0 = sp.lo.x, s1 = sp.lo.y, s2 = CH >= 4 ? sp.hi.x : sp.e, s3 = CH >= 4 ? sp.hi.y : 0.0f, s4 = CH == 5 ? sp.e : 0.0f;
-#pragma unroll 1
-      for (int t = 1; t < ss_n; ++t) {
-        if constexpr (CH == 3)
-          asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                       "v_add_f32_dpp %1, %1, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                       "v_add_f32_dpp %2, %2, %5 wave_shr:1 row_mask:0xf bank_mask:0xf"
-                       : "+v"(a0), "+v"(a1), "+v"(a2)
-                       : "v"(s0), "v"(s1), "v"(s2));
-        else if constexpr (CH == 4)
-          asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                       "v_add_f32_dpp %1, %1, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                       "v_add_f32_dpp %2, %2, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                       "v_add_f32_dpp %3, %3, %7 wave_shr:1 row_mask:0xf bank_mask:0xf"
-                       : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
-                       : "v"(s0), "v"(s1), "v"(s2), "v"(s3));
-        else
-          asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                       "v_add_f32_dpp %1, %1, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                       "v_add_f32_dpp %2, %2, %7 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                       "v_add_f32_dpp %3, %3, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                       "v_add_f32_dpp %4, %4, %9 wave_shr:1 row_mask:0xf bank_mask:0xf"
-                       : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4)
-                       : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4));
-      }
-      a.lo = f2{a0, a1};
-      if constexpr (CH >= 4) a.hi = f2{a2, a3};
-      if constexpr (CH == 3) a.e = a2;
-      if constexpr (CH == 5) a.e = a4;
+      const Px<CH> a = ss_ordered_sum<CH>(sp, (ss_x | ss_y) == 0, ss_n); // (lrp_kernel_common.h: the reference's order, a DPP chain)
       if (ss_owner && ss_inside(g, k)) {
         const PassOut o = pass_out(g, k);
         store_px<CH, false>(P, (uint32_t)o.yo * (uint32_t)P.out_w + (uint32_t)o.xo, a);

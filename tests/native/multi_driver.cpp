@@ -250,6 +250,7 @@ hipError_t launch_tile_nearest(const KParams &P, int, int, hipStream_t s) { retu
 hipError_t launch_tile_bilinear(const KParams &P, int, int, hipStream_t s) { return record_launch(P, s); }
 hipError_t launch_tile_bicubic(const KParams &P, int, int, hipStream_t s) { return record_launch(P, s); }
 hipError_t launch_win_bicubic(const KParams &P, int, int, hipStream_t s) { return record_launch(P, s); }
+hipError_t launch_ss_gather(const KParams &P, int, int, hipStream_t s) { return record_launch(P, s); }
 hipError_t launch_corner_fill(const KParams &, hipStream_t) { return hipSuccess; }
 hipError_t launch_geo_build_lists(int32_t *, int, int, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_geo_census(int32_t *, int, int, int, int, bool, hipStream_t) { return hipSuccess; }

@@ -103,10 +103,12 @@ CASES = [
     ("--samples 2 bilinear: the tile kernel on the same entry of sub-samples", dict(HEAD, ns=2, interp=BL, **{"g.mode": 2}), dict(family="tile", wants_geo=1, geo_want_boxes=0, geo_mode=2, quad=0)),
     ("--samples 2 nearest into a fisheye frame, first call", dict(C2, ns=2, interp=NN, **{"g.mode": 1}), dict(family="tile", wants_geo=1, geo_mode=1, quad=0)),
     ("--samples 2 bilinear, a batch: the first frame writes, the rest read", dict(C2, ns=2, n_batch=16, **{"g.mode": 2}), dict(family="tile", wants_geo=1, geo_mode=2)),
-    ("--samples 3 bilinear: a lane's nine pairs are strided loads, computed instead", dict(C2, ns=3, **{"g.mode": 2}), dict(family="tile", wants_geo=0, geo_mode=0)),
-    ("--samples 4 nearest: computed", dict(C2, ns=4, interp=NN, **{"g.mode": 2}), dict(family="tile", wants_geo=0)),
+    ("--samples 3 bilinear reads the entry (a lane per sub-sample: lrp_ss_gather_kernel.h)", dict(C2, ns=3, **{"g.mode": 2}), dict(family="tile", wants_geo=1, geo_mode=2)),
+    ("--samples 4 nearest, first call", dict(C2, ns=4, interp=NN, **{"g.mode": 1}), dict(family="tile", wants_geo=1, geo_mode=1)),
     ("--samples 2 bilinear, rect -> equirect: cheap coordinates are computed", dict(C3, channels=4, ns=2, interp=BL, **{"g.mode": 2}), dict(family="tile", wants_geo=0, geo_mode=0)),
     ("--samples 5 bilinear: computed", dict(C2, ns=5, **{"g.mode": 2}), dict(family="tile", wants_geo=0)),
+    ("--samples 3 bilinear, equirect -> rect without a rotation: the source x comes from the column table, computed", dict(C0, interp=BL, ns=3, **{"g.mode": 2}), dict(family="tile", wants_xsep=1, wants_geo=0)),
+    ("... rotated: loaded", dict(C0, interp=BL, ns=3, rot=GEN, **{"g.mode": 2}), dict(family="tile", wants_xsep=0, wants_geo=1, geo_mode=2)),
     # where the map does not pay: a rectilinear source under a rectilinear / panorama target, nearest / bilinear
     ("rect -> equirect bilinear: four divides beat 8 B per pixel", dict(C3, channels=4, interp=BL), dict(family="tile", wants_geo=0)),
     ("rect -> fisheye bilinear reads the map", dict(out_type=EQD, in_type=RECT, in_mode=IN_RECT, interp=BL, **{"g.mode": 2}), dict(wants_geo=1, geo_mode=2)),

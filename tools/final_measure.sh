@@ -48,11 +48,12 @@ for N in "2 2048" "3 1365" "4 1024"; do
    echo "# ... win_ss=0: the tile kernel"; timeout 300 ./tools/kbench --sum --reps 10 --distinct 16 --ns $1 --size 4096 --out-size $2 --set win_ss=0 $SSW | grep -v "^#"
    echo "# ... 16-frame launches (default)"; timeout 300 ./tools/kbench --sum --reps 4 --batch 16 --distinct 16 --ns $1 --size 4096 --out-size $2 eqd_rect_bc eqr_rect_bc_gen | grep -v "^#") >> $out/kbench_supersampling.log 2>&1
 done
-(echo "# nearest / bilinear (tile kernel), num_samples 2, 4096^2 -> 2048^2: reading the entry of sub-samples (default) / geometry cache off"
- timeout 300 ./tools/kbench --sum --reps 16 --distinct 16 --ns 2 --size 4096 --out-size 2048 eqr_rect_bl eqr_rect_nn eqr_eqd_bl_rot eqr_rect_bl_rot | grep -v "^#"
- timeout 300 ./tools/kbench --sum --reps 16 --distinct 16 --geo 0 --ns 2 --size 4096 --out-size 2048 eqr_rect_bl eqr_rect_nn eqr_eqd_bl_rot eqr_rect_bl_rot | grep -v "^#"
- echo "# ... num_samples 3 -> 1365^2 and 4 -> 1024^2 (computed: no entry)"
- timeout 300 ./tools/kbench --sum --reps 12 --distinct 16 --ns 3 --size 4096 --out-size 1365 eqr_rect_bl eqr_eqd_bl_rot | grep -v "^#"; timeout 300 ./tools/kbench --sum --reps 12 --distinct 16 --ns 4 --size 4096 --out-size 1024 eqr_rect_bl eqr_eqd_bl_rot | grep -v "^#") >> $out/kbench_supersampling.log 2>&1
+for N in "2 2048" "3 1365" "4 1024"; do
+  set -- $N
+  (echo "# nearest / bilinear, num_samples $1, 4096^2 -> $2^2: reading the entry of sub-samples (default: the gather kernel, a lane per sub-sample; equirect -> rect without a rotation computes) / geometry cache off (the tile kernel computes)"
+   timeout 300 ./tools/kbench --sum --reps 16 --distinct 16 --ns $1 --size 4096 --out-size $2 eqr_rect_bl eqr_rect_nn eqr_eqd_bl_rot eqr_rect_bl_rot eqr_rect_nn_rot | grep -v "^#"
+   timeout 300 ./tools/kbench --sum --reps 16 --distinct 16 --geo 0 --ns $1 --size 4096 --out-size $2 eqr_rect_bl eqr_rect_nn eqr_eqd_bl_rot eqr_rect_bl_rot eqr_rect_nn_rot | grep -v "^#") >> $out/kbench_supersampling.log 2>&1
+done
 (echo "# num_samples 5 (the tile kernel) and 1 for reference, 4096^2 -> 2048^2"; timeout 300 ./tools/kbench --sum --reps 6 --distinct 16 --ns 5 --size 4096 --out-size 819 eqd_rect_bc | grep -v "^#"; timeout 300 ./tools/kbench --sum --reps 20 --distinct 16 --ns 1 --size 4096 --out-size 2048 eqd_rect_bc eqr_rect_bc | grep -v "^#"
  echo "# num_samples 2 at scale 1 (4096^2 -> 4096^2)"; timeout 300 ./tools/kbench --sum --reps 8 --distinct 16 --ns 2 eqd_rect_bc eqr_rect_bc | grep -v "^#") >> $out/kbench_supersampling.log 2>&1
 for S in 1 2; do timeout 200 ./tools/kbench --reps 64 --distinct 16 --streams $S eqd_rect_bc eqr_rect_bc eqr_eqd_bc_rot rect_eqr_bc; done > $out/kbench_two_streams.log 2>&1

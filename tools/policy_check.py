@@ -120,6 +120,8 @@ CHECKS = [  # (what, workload, batch, switch, settings: the first is the default
     ("entry of sub-samples, 4096^2 -> 2048^2 num_samples 2 single", SS, 0, "geo_cache", (1, 0)),
     ("entry of sub-samples, general rotation 4096^2 -> 1024^2 num_samples 4 single", dict(GEN, out_size=1024, ns=4), 0, "geo_cache", (1, 0)),
     ("entry of sub-samples, bilinear rotated into a fisheye frame 4096^2 -> 2048^2 num_samples 2 single", dict(BL, out_size=2048, ns=2), 0, "geo_cache", (1, 0)),
+    ("entry of sub-samples, bilinear rotated into a fisheye frame 4096^2 -> 1024^2 num_samples 4 single", dict(BL, out_size=1024, ns=4), 0, "geo_cache", (1, 0)),
+    ("entry of sub-samples, equirect -> rect bilinear rotated 4096^2 -> 1365^2 num_samples 3 single", dict(GEN, interp=1, out_size=1365, ns=3), 0, "geo_cache", (1, 0)),
 ]
 bad = 0
 print(f"# default against the alternatives of every policy switch, us per frame (tolerance {tol:.0%}); box: {torch.cuda.get_device_name(0)}")
