@@ -143,8 +143,8 @@ void lrp_release_cached_tables(void);
  * instead of computing them: same values, same rendered bits, 1.2-1.9x the kernel rate.  Keyed on
  * (device, both lenses, both sizes, rotation, num_samples); least recently used entries are dropped when
  * `max_bytes` per device would be exceeded; a launch being captured into a hipGraph does not use it.
- * Bicubic with num_samples 2-4 (the reference's --samples) keeps an entry of its own kind: a coordinate pair per
- * SUB-SAMPLE, 8 x num_samples^2 bytes per output pixel.
+ * num_samples 2-4 (the reference's --samples) keep an entry of their own kind, shared by the three samplers: a coordinate
+ * pair per SUB-SAMPLE, 8 x num_samples^2 bytes per output pixel.
  *   max_bytes      bytes per device (default: min(4 GiB, 2 % of the device's memory), at least two entries of the largest
  *                  geometry seen; -2 restores it); 0 switches the cache off and frees it; -1 keeps the value
  *   min_sightings  a geometry is cached from its n-th launch on (default 1; 2 suits callers whose
