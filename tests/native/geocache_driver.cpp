@@ -232,6 +232,41 @@ static int scenario_layout() {
   }
   const lrp::GeoLayout no_boxes = lrp::geo_layout(640, 480, false);
   CHECK(no_boxes.box_bytes == 0 && no_boxes.list_bytes == 0);
+  // an entry of sub-samples (num_samples 2-4): a coordinate pair per sub-sample, the ns^2 of a pixel next to each other in the
+  // reference's order, no records; the last element lies inside the map
+  for (const auto &wh : sizes)
+    for (int ns = 2; ns <= 4; ++ns) {
+      const int w = wh[0], h = wh[1], n = ns * ns;
+      const lrp::GeoLayout L = lrp::geo_layout(w, h, true, ns);
+      CHECK(L.box_bytes == 0 && L.list_bytes == 0 && L.xy_bytes % 256 == 0 && L.xy_bytes >= (size_t)w * h * n * 8);
+      CHECK(lrp::geo_ss_map_index(0, 0, w, n, 0) == 0 && lrp::geo_ss_map_index(0, 0, w, n, n - 1) == (uint32_t)(n - 1));
+      CHECK(lrp::geo_ss_map_index(1, 0, w, n, 0) == (uint32_t)n && lrp::geo_ss_map_index(0, 1, w, n, 0) == (uint32_t)(w * n));
+      CHECK(((size_t)lrp::geo_ss_map_index(w - 1, h - 1, w, n, n - 1) + 1) * 8 <= L.xy_bytes);
+    }
+  return 0;
+}
+
+// Entries of sub-samples live beside plain ones: the key carries num_samples; they hold a map and nothing else.
+static int scenario_sub_sample_entries() {
+  lrp::geo_configure(64 << 20, 1);
+  lrp::GeoKey k1 = key_of(0, 320, 200, 3.0f), k2 = k1, k3 = k1;
+  k1.num_samples = 1, k2.num_samples = 2, k3.num_samples = 3;
+  const lrp::GeoUse a = fill(k1, S(0), true, true);
+  const lrp::GeoUse b = fill(k2, S(0), false);
+  const lrp::GeoUse c = fill(k3, S(0), false);
+  CHECK(a.mode == 1 && b.mode == 1 && c.mode == 1 && a.xy != b.xy && b.xy != c.xy && b.host_counts == nullptr);
+  lrp::GeoStats st;
+  lrp::geo_stats(&st);
+  CHECK(st.entries == 3);
+  CHECK(st.bytes == lrp::geo_layout(320, 200, true).bytes() + lrp::geo_layout(320, 200, true, 2).bytes() + lrp::geo_layout(320, 200, true, 3).bytes());
+  fake::complete_all();
+  lrp::GeoUse r;
+  lrp::geo_acquire(k2, false, S(1), &r); // nearest / bilinear / bicubic with num_samples 2: one entry
+  CHECK(r.mode == 2 && r.xy == b.xy && !r.lists);
+  lrp::geo_launched(&r, S(1), true);
+  lrp::geo_acquire(k1, true, S(1), &r);
+  CHECK(r.mode == 2 && r.xy == a.xy && r.lists);
+  lrp::geo_launched(&r, S(1), true);
   return 0;
 }
 
@@ -483,6 +518,7 @@ int main(int argc, char **argv) {
   if (name == "fill_read_lists") rc = scenario_fill_read_lists();
   if (name == "map_then_boxes") rc = scenario_map_then_boxes();
   if (name == "layout") rc = scenario_layout();
+  if (name == "sub_sample_entries") rc = scenario_sub_sample_entries();
   if (name == "eviction") rc = scenario_eviction_without_device_sync();
   if (name == "devices") rc = scenario_devices_are_independent();
   if (name == "default_cap") rc = scenario_default_cap_and_release();

@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "tests", "native", "_build")
-SCENARIOS = ["fill_read_lists", "map_then_boxes", "layout", "eviction", "devices", "default_cap", "failed_launch_and_key", "release_one_device",
+SCENARIOS = ["fill_read_lists", "map_then_boxes", "layout", "sub_sample_entries", "eviction", "devices", "default_cap", "failed_launch_and_key", "release_one_device",
              "marks_are_pruned", "failed_writer_without_mark", "threads"]
 HIP_INCLUDE = os.environ.get("HIP_INCLUDE", "/opt/rocm/include")
 
