@@ -58,6 +58,15 @@ def frame_cases():
         _case("4k_eqr_rect_bl", 4096, 4096, 4, "eqr_full", "rect", BILINEAR, (0.0, 0.0, 0.0), 0x5EED0008),
         _case("4k_eqr_rect_nn", 4096, 4096, 4, "eqr_full", "rect", NEAREST, (0.0, 0.0, 0.0), 0x5EED0008),
         _case("2k_eqd_rect_bc_ns2", 2048, 1024, 4, "eqd180", "rect", BICUBIC, (10.0, 20.0, 30.0), 0x5EED0009, ns=2),
+        # --- the --scale / --samples pairs the reference's help text prescribes (src/main.cpp:192-196; int(4096 * 0.33334) = 1365),
+        # bench.py's supersampling secondaries, and the other two samplers on the same entries of sub-samples
+        _case("4k_eqd_rect_bc_half_ns2", 4096, 2048, 4, "eqd180", "rect", BICUBIC, None, 0x5EED000A, ns=2),
+        _case("4k_eqd_rect_bc_third_ns3", 4096, 1365, 4, "eqd180", "rect", BICUBIC, None, 0x5EED000A, ns=3),
+        _case("4k_eqd_rect_bc_quarter_ns4", 4096, 1024, 4, "eqd180", "rect", BICUBIC, None, 0x5EED000A, ns=4),
+        _case("4k_rgbaz_eqr_rect_bc_rot_third_ns3_post", 4096, 1365, 5, "eqr_full", "rect", BICUBIC, (30.0, -15.0, 5.0), 0x5EED000B, depth=4,
+              post=(2.0, 4.0), ns=3),
+        _case("4k_eqr_eqd_bl_rot_third_ns3", 4096, 1365, 4, "eqr_full", "eqd180", BILINEAR, (30.0, -15.0, 5.0), 0x5EED000C, ns=3),
+        _case("4k_rgb_eqr_rect_nn_rot_quarter_ns4", 4096, 1024, 3, "eqr_full", "rect", NEAREST, (30.0, -15.0, 5.0), 0x5EED000C, ns=4),
     ]
     return {c["name"]: c for c in cs}
 

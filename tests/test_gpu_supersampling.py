@@ -186,3 +186,46 @@ def test_downscale_4k_whole_frame_rows(lrp, oracle, torch_cuda, ns, m):
         pixel = _render(lrp, torch, lin, d_in, lout, m, m, rot, ns=ns)
         lrp.debug_kernel(prev)
         assert np.array_equal(got.view(np.uint32), pixel.view(np.uint32)), f"{in_name} -> {out_name}: window (SS) and pixel kernels differ"
+
+
+@pytest.mark.parametrize("name", ["4k_eqd_rect_bc_half_ns2", "4k_eqd_rect_bc_third_ns3", "4k_eqd_rect_bc_quarter_ns4", "4k_rgbaz_eqr_rect_bc_rot_third_ns3_post",
+                                  "4k_eqr_eqd_bl_rot_third_ns3", "4k_rgb_eqr_rect_nn_rot_quarter_ns4"])
+def test_whole_frames_equal_the_committed_oracle_digests(lrp, torch_cuda, name):
+    """The reference's --scale / --samples pairs at full size against digests the oracle wrote in the build container
+    (tests/golden/fullframe_golden.json; no oracle call on the box): the launch that fills the entry of sub-samples, a launch
+    that reads it (bicubic: the GeoRead + SS window instantiations; nearest / bilinear: the gather kernel), a launch with the
+    cache off — all three must carry the committed bits."""
+    import json
+    import os
+
+    import fullframe_cases as ffc
+
+    torch = torch_cuda
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullframe_golden.json")) as f:
+        want = json.load(f)["frames"][name]
+    case = ffc.frame_cases()[name]
+    n, m, c = case["size"], case["out_size"], case["c"]
+    d_in = torch.empty((n, n, c), dtype=torch.float32, device="cuda")
+    lrp.synth_fill(d_in, n, n, c, case["seed"], case.get("depth", -1))
+    lin, lout = cases.lenses(lrp, n, n)[case["inp"]], cases.lenses(lrp, m, m)[case["out"]]
+    rot = cases.rotation(lrp, case["deg"])
+
+    def render():
+        d_out = torch.full((m, m, c), -12345.0, dtype=torch.float32, device="cuda")
+        lrp.reproject(lrp.Image(lin, n, n, c, d_in), lrp.Image(lout, m, m, c, d_out), case["ns"], case["interp"], rot,
+                      post=tuple(case["post"]) if case.get("post") else None)
+        torch.cuda.synchronize()
+        return d_out
+
+    stats0 = lrp.geometry_cache_stats()
+    for what in ("the launch that fills the entry", "a launch that reads it", "cache off"):
+        prev = lrp.debug_set("geo_cache", 0) if what == "cache off" else None
+        d_out = render()
+        if prev is not None:
+            lrp.debug_set("geo_cache", prev)
+        sha, bands, n_nan = ffc.frame_digests(d_out.cpu().numpy())
+        bad = [b for b in range(ffc.BANDS) if bands[b] != want["bands"][b]]
+        assert not bad, f"{name}, {what}: row bands {bad} of {ffc.BANDS} differ from the committed oracle digest"
+        assert sha == want["sha256"] and n_nan == want["nan"], f"{name}, {what}"
+    stats = lrp.geometry_cache_stats()
+    assert stats["fills"] == stats0["fills"] + 1 and stats["hits"] == stats0["hits"] + 1, name
